@@ -1,0 +1,259 @@
+"""Frame carrier for the pair-distance hot path.
+
+The reference's frame type is ``ase.Atoms`` and a "trajectory" is a Python list
+of them (reference amof/trajectory.py:27-35,56-59).  ASE is not available where
+this package is built and tested, so two carriers are defined here:
+
+* :class:`Frame` -- a small ``ase.Atoms`` look-alike exposing exactly the
+  methods the reference path calls (amof/rdf.py:71,74; amof/msd.py:218-237,263;
+  amof/atom.py:22,40-46,82-83; amof/bad.py:85,100; amof/cn.py:66,70).  Real
+  ``ase.Atoms`` objects are accepted everywhere a ``Frame`` is (duck typing).
+* :class:`PackedTrajectory` -- the packed form handed to the C ABI:
+  ``pos[F][N][3]`` f64, ``cell[F][3][3]`` f64 (or one cell for all frames),
+  ``numbers[N]``, ``masses[N]``, ``pbc[3]``.  ``pos`` may be a numpy array
+  (host) or a torch CUDA tensor (already resident in HBM).
+"""
+
+import numpy as np
+
+from . import data as _data
+
+
+class _Formula(object):
+    """Stand-in for ``ase.formula.Formula``: only ``_count`` is used
+    (reference amof/msd.py:263)."""
+
+    def __init__(self, symbols):
+        count = {}
+        for s in symbols:
+            count[s] = count.get(s, 0) + 1
+        self._count = count
+
+    def count(self):
+        return dict(self._count)
+
+
+class _Symbols(object):
+    """Stand-in for ``ase.symbols.Symbols`` (``atoms.symbols.formula._count``)."""
+
+    def __init__(self, numbers):
+        self._numbers = numbers
+
+    def __iter__(self):
+        return (_data.chemical_symbols[z] for z in self._numbers)
+
+    def __len__(self):
+        return len(self._numbers)
+
+    @property
+    def formula(self):
+        return _Formula(list(self))
+
+
+class Frame(object):
+    """Minimal ``ase.Atoms`` look-alike (one configuration of N atoms)."""
+
+    def __init__(self, numbers=None, positions=None, cell=None, pbc=True,
+                 masses=None, symbols=None):
+        if numbers is None:
+            numbers = [_data.atomic_numbers[s] for s in symbols]
+        self.numbers = np.array(numbers, dtype=np.int64)
+        self.positions = np.array(positions, dtype=np.float64).reshape(-1, 3)
+        if len(self.numbers) != len(self.positions):
+            raise ValueError("numbers and positions have different lengths")
+        cell = np.array(cell, dtype=np.float64)
+        if cell.shape == (3,):
+            cell = np.diag(cell)
+        if cell.shape != (3, 3):
+            raise ValueError("cell must be 3 lengths or a 3x3 matrix")
+        self.cell = cell
+        if isinstance(pbc, (bool, np.bool_)):
+            pbc = (pbc,) * 3
+        self.pbc = np.array(pbc, dtype=bool)
+        self._masses = None if masses is None else np.array(masses, dtype=np.float64)
+
+    # -- ase.Atoms API subset -------------------------------------------------
+    def __len__(self):
+        return len(self.numbers)
+
+    def get_global_number_of_atoms(self):
+        return len(self.numbers)
+
+    get_number_of_atoms = get_global_number_of_atoms
+
+    def get_positions(self):
+        return self.positions.copy()
+
+    def set_positions(self, newpositions):
+        self.positions[:] = newpositions
+
+    def get_atomic_numbers(self):
+        return self.numbers.copy()
+
+    def get_chemical_symbols(self):
+        return [_data.chemical_symbols[z] for z in self.numbers]
+
+    def get_cell(self):
+        return self.cell.copy()
+
+    def get_pbc(self):
+        return self.pbc.copy()
+
+    def get_cell_lengths_and_angles(self):
+        lengths = np.sqrt((self.cell ** 2).sum(axis=1))
+        angles = []
+        for i in range(3):
+            j, k = (i + 1) % 3, (i + 2) % 3
+            ll = lengths[j] * lengths[k]
+            if ll > 1e-16:
+                x = np.dot(self.cell[j], self.cell[k]) / ll
+                angles.append(180.0 / np.pi * np.arccos(x))
+            else:
+                angles.append(90.0)
+        return np.array(list(lengths) + angles)
+
+    def get_volume(self):
+        return abs(np.linalg.det(self.cell))
+
+    def get_masses(self):
+        if self._masses is None:
+            return np.array([_data.atomic_masses[z] for z in self.numbers])
+        return self._masses.copy()
+
+    def get_center_of_mass(self):
+        m = self.get_masses()
+        return np.dot(m, self.positions) / m.sum()
+
+    def translate(self, displacement):
+        self.positions += np.array(displacement)
+
+    @property
+    def symbols(self):
+        return _Symbols(self.numbers)
+
+    def copy(self):
+        return Frame(self.numbers, self.positions, self.cell, self.pbc, self._masses)
+
+    def __repr__(self):
+        return "Frame(N=%d, cell=%s)" % (len(self), np.array2string(self.cell, precision=4))
+
+
+def _is_torch_tensor(x):
+    return type(x).__module__.startswith("torch")
+
+
+class PackedTrajectory(object):
+    """Packed trajectory: the buffers the C ABI consumes.
+
+    Args:
+        pos: f64 ``[F][N][3]``, C-contiguous; numpy array or torch tensor
+            (CPU or CUDA).  A CUDA tensor is used in place (no copy).
+        cell: f64 ``[F][3][3]`` or ``[3][3]`` (constant cell).
+        numbers: int ``[N]`` atomic numbers (same for every frame, as the
+            reference assumes: amof/rdf.py:71, amof/msd.py:215).
+        masses: f64 ``[N]`` or None (standard atomic weights).
+        pbc: 3 bools.
+    """
+
+    def __init__(self, pos, cell, numbers, masses=None, pbc=(True, True, True)):
+        if _is_torch_tensor(pos):
+            import torch
+            if pos.dtype != torch.float64 or pos.dim() != 3 or pos.shape[2] != 3:
+                raise ValueError("pos must be float64 [F][N][3]")
+            if not pos.is_contiguous():
+                pos = pos.contiguous()
+            self.pos = pos
+        else:
+            pos = np.ascontiguousarray(pos, dtype=np.float64)
+            if pos.ndim != 3 or pos.shape[2] != 3:
+                raise ValueError("pos must be float64 [F][N][3]")
+            self.pos = pos
+        self.n_frames = int(self.pos.shape[0])
+        self.n_atoms = int(self.pos.shape[1])
+        cell = np.ascontiguousarray(cell, dtype=np.float64)
+        if cell.shape == (3, 3):
+            cell = cell.reshape(1, 3, 3)
+        if cell.ndim != 3 or cell.shape[1:] != (3, 3) or cell.shape[0] not in (1, self.n_frames):
+            raise ValueError("cell must be [3][3] or [F][3][3]")
+        self.cell = cell
+        self.numbers = np.ascontiguousarray(numbers, dtype=np.int64)
+        if self.numbers.shape != (self.n_atoms,):
+            raise ValueError("numbers must have N entries")
+        if masses is None:
+            masses = np.array([_data.atomic_masses[z] for z in self.numbers], dtype=np.float64)
+        self.masses = np.ascontiguousarray(masses, dtype=np.float64)
+        if isinstance(pbc, (bool, np.bool_)):
+            pbc = (pbc,) * 3
+        self.pbc = np.array(pbc, dtype=bool)
+
+    def __len__(self):
+        return self.n_frames
+
+    @property
+    def on_device(self):
+        return _is_torch_tensor(self.pos) and self.pos.is_cuda
+
+    def cell_of(self, k):
+        return self.cell[k if self.cell.shape[0] > 1 else 0]
+
+    def cells_full(self):
+        """``[F][3][3]`` view of the cells (broadcast when constant)."""
+        if self.cell.shape[0] == self.n_frames:
+            return self.cell
+        return np.broadcast_to(self.cell, (self.n_frames, 3, 3))
+
+    def cell_lengths(self):
+        return np.sqrt((self.cell ** 2).sum(axis=2))
+
+    def volumes(self):
+        return np.abs(np.linalg.det(self.cell))
+
+    def pos_host(self):
+        if _is_torch_tensor(self.pos):
+            return self.pos.detach().cpu().numpy()
+        return self.pos
+
+    def formula_count(self):
+        return _Formula([_data.chemical_symbols[z] for z in self.numbers])._count
+
+    def frame(self, k):
+        """Materialise frame ``k`` as a :class:`Frame` (host copy)."""
+        if _is_torch_tensor(self.pos):
+            p = self.pos[k].detach().cpu().numpy()
+        else:
+            p = self.pos[k]
+        return Frame(self.numbers, p, self.cell_of(k), self.pbc, self.masses)
+
+    def to_frames(self):
+        return [self.frame(k) for k in range(self.n_frames)]
+
+
+def pack_trajectory(trajectory):
+    """Pack a list of ``ase.Atoms``-like frames into a :class:`PackedTrajectory`.
+
+    Accepts a :class:`PackedTrajectory` unchanged.  Every frame must hold the
+    same atoms in the same order (the reference assumes it: species are read
+    from frame 0 only, amof/rdf.py:71, amof/cn.py:52, amof/msd.py:215).
+    """
+    if isinstance(trajectory, PackedTrajectory):
+        return trajectory
+    frames = list(trajectory)
+    if len(frames) == 0:
+        raise ValueError("empty trajectory")
+    first = frames[0]
+    numbers = np.array(first.get_atomic_numbers(), dtype=np.int64)
+    n = len(numbers)
+    pos = np.empty((len(frames), n, 3), dtype=np.float64)
+    cell = np.empty((len(frames), 3, 3), dtype=np.float64)
+    for k, atoms in enumerate(frames):
+        p = atoms.get_positions()
+        if len(p) != n:
+            raise ValueError("frame %d has %d atoms, frame 0 has %d" % (k, len(p), n))
+        pos[k] = p
+        cell[k] = np.array(atoms.get_cell())
+    if (cell == cell[0]).all():
+        cell = cell[:1].copy()
+    pbc = np.array(getattr(first, "pbc", (True, True, True)), dtype=bool)
+    if pbc.shape == ():
+        pbc = np.array([bool(pbc)] * 3)
+    return PackedTrajectory(pos, cell, numbers, np.array(first.get_masses(), dtype=np.float64), pbc)
