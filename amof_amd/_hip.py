@@ -1,0 +1,303 @@
+"""ctypes binding of ``libamofhip.so`` (the C ABI declared in include/amof_hip.h).
+
+This is the only compute back end of the package: there is no CPU fallback.
+If the shared library is missing, or no GPU is visible, the analysis classes
+raise -- they never silently compute somewhere else.
+"""
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from .frames import PackedTrajectory, _is_torch_tensor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libamofhip.so")
+
+AMOF_OK = 0
+AMOF_EINVAL = -1
+AMOF_ESINGULAR = -2
+AMOF_EANGLE = -3
+AMOF_ENOMEM = -4
+AMOF_EHIP = -5
+AMOF_ECAPACITY = -6
+AMOF_ENODEVICE = -7
+ABI_VERSION = 1
+
+EXPORTS = [
+    "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_destroy", "amof_last_error",
+    "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_last_kernel_seconds", "amof_last_kernel_launches",
+    "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
+    "amof_msd_window",
+]
+
+
+class AmofError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libamofhip error %d: %s" % (code, message))
+        self.code = code
+
+
+class AmofTraj(ctypes.Structure):
+    """``struct amof_traj`` (include/amof_hip.h)."""
+    _fields_ = [
+        ("pos", ctypes.c_void_p),
+        ("pos_on_device", ctypes.c_int32),
+        ("n_species", ctypes.c_int32),
+        ("cell", ctypes.c_void_p),
+        ("n_cells", ctypes.c_int64),
+        ("n_frames", ctypes.c_int64),
+        ("n_atoms", ctypes.c_int64),
+        ("species", ctypes.c_void_p),
+        ("masses", ctypes.c_void_p),
+        ("pbc", ctypes.c_uint8 * 3),
+        ("_pad", ctypes.c_uint8 * 5),
+    ]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """Load ``libamofhip.so`` (in-tree build) and declare the prototypes."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "amof_amd: %s not found. Build it with `make -C amof_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        P = ctypes.c_void_p
+        lib.amof_abi_version.restype = ctypes.c_int
+        lib.amof_device_count.restype = ctypes.c_int
+        lib.amof_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(P)]
+        lib.amof_ctx_destroy.argtypes = [P]
+        lib.amof_ctx_destroy.restype = None
+        lib.amof_last_error.argtypes = [P]
+        lib.amof_last_error.restype = ctypes.c_char_p
+        lib.amof_ctx_set_stream.argtypes = [P, P]
+        lib.amof_ctx_synchronize.argtypes = [P]
+        lib.amof_last_kernel_seconds.argtypes = [P, ctypes.c_int]
+        lib.amof_last_kernel_seconds.restype = ctypes.c_double
+        lib.amof_last_kernel_launches.argtypes = [P]
+        lib.amof_last_kernel_launches.restype = ctypes.c_int64
+        TP = ctypes.POINTER(AmofTraj)
+        lib.amof_rdf_accumulate.argtypes = [P, TP, ctypes.c_double, ctypes.c_int32, P, ctypes.POINTER(ctypes.c_double)]
+        lib.amof_rdf_accumulate_dev.argtypes = lib.amof_rdf_accumulate.argtypes
+        lib.amof_cn_count.argtypes = [P, TP, P, P, ctypes.c_int32, P, P]
+        lib.amof_bad_hist.argtypes = [P, TP, P, P, ctypes.c_int32, P, ctypes.c_int32, P, P]
+        lib.amof_bad_hist_dev.argtypes = lib.amof_bad_hist.argtypes
+        lib.amof_msd_window.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_int64, ctypes.c_int64, P]
+        if lib.amof_abi_version() != ABI_VERSION:
+            raise RuntimeError("libamofhip.so ABI version %d, expected %d" % (lib.amof_abi_version(), ABI_VERSION))
+        _lib = lib
+        return lib
+
+
+def device_count():
+    return load_library().amof_device_count()
+
+
+def species_index(numbers):
+    """Map atomic numbers to the C ABI's species indices.
+
+    Returns ``(kinds, species)``: ``kinds`` = sorted unique atomic numbers,
+    ``species[i]`` = index of atom i's number in ``kinds`` (int32)."""
+    numbers = np.asarray(numbers)
+    kinds = sorted(set(int(z) for z in numbers))
+    lut = {z: k for k, z in enumerate(kinds)}
+    return kinds, np.array([lut[int(z)] for z in numbers], dtype=np.int32)
+
+
+class _TrajHandle(object):
+    """Keeps the numpy buffers behind an ``AmofTraj`` alive."""
+
+    def __init__(self, packed, frame_range=None):
+        assert isinstance(packed, PackedTrajectory)
+        f0, f1 = (0, packed.n_frames) if frame_range is None else frame_range
+        self.kinds, self.species = species_index(packed.numbers)
+        pos = packed.pos
+        cell = packed.cell if packed.cell.shape[0] == 1 else packed.cell[f0:f1]
+        self.cell = np.ascontiguousarray(cell, dtype=np.float64)
+        self.masses = np.ascontiguousarray(packed.masses, dtype=np.float64)
+        t = AmofTraj()
+        if _is_torch_tensor(pos):
+            sub = pos[f0:f1]
+            if not sub.is_contiguous():
+                sub = sub.contiguous()
+            self._pos = sub
+            if sub.is_cuda:
+                t.pos = sub.data_ptr()
+                t.pos_on_device = 1
+                self.device_index = sub.device.index
+            else:
+                t.pos = sub.data_ptr()
+                t.pos_on_device = 0
+                self.device_index = None
+        else:
+            sub = np.ascontiguousarray(pos[f0:f1])
+            self._pos = sub
+            t.pos = sub.ctypes.data
+            t.pos_on_device = 0
+            self.device_index = None
+        t.n_species = len(self.kinds)
+        t.cell = self.cell.ctypes.data
+        t.n_cells = self.cell.shape[0]
+        t.n_frames = f1 - f0
+        t.n_atoms = packed.n_atoms
+        t.species = self.species.ctypes.data
+        t.masses = self.masses.ctypes.data
+        for k in range(3):
+            t.pbc[k] = 1 if packed.pbc[k] else 0
+        self.c = t
+        self.n_frames = f1 - f0
+        self.n_atoms = packed.n_atoms
+        self.S = len(self.kinds)
+
+
+class Context(object):
+    """One ``amof_ctx``: a device, a stream and its scratch memory."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        n = self._lib.amof_device_count()
+        if n <= 0:
+            raise RuntimeError("amof_amd: no GPU visible to HIP; the MI355X kernels cannot run "
+                               "(there is no CPU fallback)")
+        h = ctypes.c_void_p()
+        rc = self._lib.amof_ctx_create(int(device), ctypes.byref(h))
+        if rc != AMOF_OK:
+            raise AmofError(rc, "amof_ctx_create(device=%d) failed" % device)
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.amof_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == AMOF_OK:
+            return
+        msg = self._lib.amof_last_error(self._h).decode("utf-8", "replace")
+        if rc == AMOF_EANGLE:
+            raise ZeroDivisionError("Undefined angle")  # what ASE raises (reference amof/bad.py:100)
+        if rc == AMOF_EINVAL:
+            raise ValueError(msg)
+        raise AmofError(rc, msg)
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.amof_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        self._check(self._lib.amof_ctx_synchronize(self._h))
+
+    def last_kernel_seconds(self, dominant=True):
+        return self._lib.amof_last_kernel_seconds(self._h, 1 if dominant else 0)
+
+    def last_kernel_launches(self):
+        return self._lib.amof_last_kernel_launches(self._h)
+
+    # ------------------------------------------------------------ analyses --
+    def rdf_accumulate(self, packed, rmax, nbins, frame_range=None, out=None):
+        """ordered-pair histograms ``[S][S][nbins]`` (u64) and the volume sum.
+
+        ``out``: optional torch CUDA int64 tensor ``[S][S][nbins]`` to
+        accumulate into on the device (stays resident for an RCCL merge)."""
+        th = _TrajHandle(packed, frame_range)
+        vol = ctypes.c_double(0.0)
+        if out is not None:
+            assert out.is_cuda and out.is_contiguous() and out.numel() == th.S * th.S * nbins
+            self.use_torch_stream()
+            rc = self._lib.amof_rdf_accumulate_dev(self._h, ctypes.byref(th.c), float(rmax), int(nbins),
+                                                   ctypes.c_void_p(out.data_ptr()), ctypes.byref(vol))
+            self._check(rc)
+            return out, vol.value, th.kinds
+        hist = np.zeros((th.S, th.S, nbins), dtype=np.uint64)
+        rc = self._lib.amof_rdf_accumulate(self._h, ctypes.byref(th.c), float(rmax), int(nbins),
+                                           ctypes.c_void_p(hist.ctypes.data), ctypes.byref(vol))
+        self._check(rc)
+        return hist, vol.value, th.kinds
+
+    def cn_count(self, packed, cutoff, sets, frame_range=None, per_atom=False):
+        th = _TrajHandle(packed, frame_range)
+        cutoff = np.ascontiguousarray(cutoff, dtype=np.float64).reshape(th.S, th.S)
+        sets = np.ascontiguousarray(sets, dtype=np.int32).reshape(-1, 2)
+        sums = np.zeros((th.n_frames, len(sets)), dtype=np.int64)
+        pa = np.zeros((th.n_frames, len(sets), th.n_atoms), dtype=np.int32) if per_atom else None
+        rc = self._lib.amof_cn_count(self._h, ctypes.byref(th.c), ctypes.c_void_p(cutoff.ctypes.data),
+                                     ctypes.c_void_p(sets.ctypes.data), len(sets),
+                                     ctypes.c_void_p(sums.ctypes.data),
+                                     ctypes.c_void_p(pa.ctypes.data) if per_atom else None)
+        self._check(rc)
+        return (sums, pa) if per_atom else sums
+
+    def bad_hist(self, packed, cutoff, triples, edges, frame_range=None, out=None):
+        th = _TrajHandle(packed, frame_range)
+        cutoff = np.ascontiguousarray(cutoff, dtype=np.float64).reshape(th.S, th.S)
+        triples = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 2)
+        edges = np.ascontiguousarray(edges, dtype=np.float64)
+        nb = len(edges) - 1
+        if out is not None:
+            hist_t, nang_t = out
+            self.use_torch_stream()
+            rc = self._lib.amof_bad_hist_dev(self._h, ctypes.byref(th.c), ctypes.c_void_p(cutoff.ctypes.data),
+                                             ctypes.c_void_p(triples.ctypes.data), len(triples),
+                                             ctypes.c_void_p(edges.ctypes.data), nb,
+                                             ctypes.c_void_p(hist_t.data_ptr()), ctypes.c_void_p(nang_t.data_ptr()))
+            self._check(rc)
+            return hist_t, nang_t
+        hist = np.zeros((len(triples), nb), dtype=np.uint64)
+        nang = np.zeros(len(triples), dtype=np.uint64)
+        rc = self._lib.amof_bad_hist(self._h, ctypes.byref(th.c), ctypes.c_void_p(cutoff.ctypes.data),
+                                     ctypes.c_void_p(triples.ctypes.data), len(triples),
+                                     ctypes.c_void_p(edges.ctypes.data), nb,
+                                     ctypes.c_void_p(hist.ctypes.data), ctypes.c_void_p(nang.ctypes.data))
+        self._check(rc)
+        return hist, nang
+
+    def msd_window(self, packed, windows, unwrap=False, remove_com=True, atom_range=None):
+        """``(sumsq [S][W] f64, kinds)``: raw sums of squared displacements."""
+        th = _TrajHandle(packed)
+        windows = np.ascontiguousarray(windows, dtype=np.int32)
+        a0, a1 = (0, th.n_atoms) if atom_range is None else atom_range
+        out = np.zeros((th.S, len(windows)), dtype=np.float64)
+        rc = self._lib.amof_msd_window(self._h, ctypes.byref(th.c), ctypes.c_void_p(windows.ctypes.data),
+                                       len(windows), 1 if unwrap else 0, 1 if remove_com else 0,
+                                       int(a0), int(a1), ctypes.c_void_p(out.ctypes.data))
+        self._check(rc)
+        return out, th.kinds
+
+
+_contexts = {}
+_ctx_lock = threading.Lock()
+
+
+def get_context(device=None):
+    """Cached :class:`Context` of a device (default: LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+        if device >= max(device_count(), 1):
+            device = 0
+    with _ctx_lock:
+        ctx = _contexts.get(device)
+        if ctx is None:
+            ctx = Context(device)
+            _contexts[device] = ctx
+        return ctx

@@ -1,0 +1,142 @@
+"""Bond-angle distributions on MI355X (mirror of reference amof/bad.py).
+
+``Bad`` keeps the reference's signatures and ``.data`` schema
+(amof/bad.py:33-169).  Neighbour search, minimum-image bond vectors, angles and
+the histogram counts (amof/bad.py:70-114 + numpy.histogram at :160) run in the
+HIP kernel behind ``amof_bad_hist``; the host keeps species / column logic and
+the density normalisation.  Angles are never materialised as Python floats
+(the reference keeps every angle of every frame in lists, amof/bad.py:156-160).
+
+Deviation: when the cutoff keys cover every species the reference appends the
+string "X" to its element list (amof/bad.py:127-128) and then indexes
+``ase.data.chemical_symbols["X"]`` (amof/bad.py:111), which raises TypeError.
+Here "X" (any species) works and is spelled 'X' in the column names.
+"""
+
+import logging
+
+import numpy as np
+import pandas as pd
+
+from . import _hip
+from . import atom as amatom
+from . import data as _data
+from . import dist as _dist
+from .files import path as _path
+from .frames import pack_trajectory
+
+logger = logging.getLogger(__name__)
+
+
+def _symbol(c):
+    return "X" if isinstance(c, str) else _data.chemical_symbols[c]
+
+
+class CoreBad(object):
+    """
+    Core material for every Bad function
+    """
+
+    @classmethod
+    def from_trajectory(cls, trajectory, nb_set_and_cutoff, dtheta=0.05, normalization='total', parallel=False,
+                        device=None, distributed=None):
+        """
+        constructor of bad class from a trajectory
+        Args:
+            nb_set_and_cutoff: dict, keys are str indicating pair of neighbours,
+                values are cutoffs float, in Angstrom
+            dtheta: float, in degrees
+            normalization: str, unused (as in the reference, amof/bad.py:120)
+            parallel: accepted for compatibility; frames always run in
+                parallel on the GPU
+        """
+        bad_class = cls()
+        bad_class.compute_bad(trajectory, nb_set_and_cutoff, dtheta, normalization, parallel,
+                              device=device, distributed=distributed)
+        return bad_class
+
+    @classmethod
+    def from_file(cls, filename):
+        """constructor of bad class from bad file"""
+        bad_class = cls()
+        bad_class.read_bad_file(filename)
+        return bad_class
+
+
+class Bad(CoreBad):
+    """
+    Main class for bad
+    """
+
+    def __init__(self):
+        """default constructor"""
+        self.data = pd.DataFrame({"theta": np.empty([0])})
+
+    def compute_bad(self, trajectory, nb_set_and_cutoff, dtheta, normalization='total', parallel=False,
+                    device=None, distributed=None):
+        """compute bond-angle distributions (reference amof/bad.py:116-160)"""
+        packed = pack_trajectory(trajectory)
+        atomic_numbers_unique = list(set(packed.numbers))
+
+        cutoff_dict = amatom.format_cutoff(nb_set_and_cutoff)
+        elements_present_unique = list(set([_data.atomic_numbers[i] for nb_set in nb_set_and_cutoff.keys()
+                                            for i in nb_set.split('-')]))
+        if len(elements_present_unique) == len(atomic_numbers_unique):
+            elements_present_unique.append("X")
+        elements = [(a, b) for b in elements_present_unique for a in elements_present_unique
+                    if (a not in [b, "X"] or ((a, b) == ("X", "X")))]
+
+        logger.info("Start computing bad for %s frames with dtheta = %s", len(packed), dtheta)
+        bins = int(180 // dtheta)       # Python float floor-division (amof/bad.py:142)
+        theta_bins = np.arange(bins + 2) * dtheta
+        theta = np.arange(bins + 1) * dtheta + dtheta / 2
+        self.data = pd.DataFrame({"theta": theta})
+
+        kinds, _ = _hip.species_index(packed.numbers)
+        lut = {z: k for k, z in enumerate(kinds)}
+        rcm = amatom.cutoff_matrix(cutoff_dict, kinds)
+
+        def sidx(c):
+            return -1 if isinstance(c, str) else lut.get(c, None)
+
+        names, triples = [], []
+        for A, B in elements:
+            aba_str = "-".join([_symbol(C) for C in [B, A, B]])
+            ia, ib = sidx(A), sidx(B)
+            if ia is None or ib is None:
+                continue                # species absent from the trajectory: no angle, column omitted
+            names.append(aba_str)
+            triples.append((ia, ib))
+
+        rank, world = (0, 1) if distributed is False else _dist.world()
+        F = len(packed)
+        frame_range = _dist.shard_range(F, rank, world) if (world > 1 and distributed != 'local') else (0, F)
+        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        ctx = _hip.get_context(dev)
+        if triples:
+            hist, nang = ctx.bad_hist(packed, rcm, triples, theta_bins, frame_range=frame_range)
+        else:
+            hist, nang = np.zeros((0, bins + 1), dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+        if world > 1:
+            hist = _dist.all_reduce_sum(hist)
+            nang = _dist.all_reduce_sum(nang)
+        self.hist = hist
+        self.n_angles = nang
+        self.columns = names
+
+        cols = {}
+        db = np.array(np.diff(theta_bins), float)
+        for k, aba_str in enumerate(names):
+            if nang[k] != 0:            # columns without any angle are omitted (amof/bad.py:159)
+                n = hist[k].astype(np.int64)
+                cols[aba_str] = n / db / n.sum()      # numpy.histogram(density=True)
+        if cols:
+            self.data = pd.concat([self.data, pd.DataFrame(cols)], axis=1)
+
+    def write_to_file(self, filename):
+        filename = _path.append_suffix(filename, 'bad')
+        self.data.to_feather(filename)
+
+    def read_bad_file(self, path_to_data):
+        path_to_data = _path.append_suffix(path_to_data, 'bad')
+        self.data = pd.read_feather(path_to_data)

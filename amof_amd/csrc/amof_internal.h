@@ -1,0 +1,152 @@
+// Internal declarations shared by the translation units of libamofhip.so.
+// gfx950 only; compiled with -ffp-contract=off: every fused multiply-add in the
+// pair arithmetic is an explicit fma() so that integer results are reproducible
+// bit for bit on any conforming IEEE-754 implementation (the CPU oracle).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/amof_hip.h"
+
+namespace amof {
+
+// ---------------------------------------------------------------- context --
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum Slot {
+    SLOT_POS = 0,   // staged positions (host input)
+    SLOT_GEOM,      // per-frame geometry records
+    SLOT_IMG,       // per-frame extra image vectors
+    SLOT_NIMG,      // per-frame extra image counts
+    SLOT_PERM,      // species-sorted atom permutation
+    SLOT_TILES,     // tile descriptors
+    SLOT_PAIRS,     // tile-pair work list
+    SLOT_HISTU,     // unordered-key histograms (u64)
+    SLOT_SELF,      // self-image histogram (u64)
+    SLOT_SPEC,      // species index per atom
+    SLOT_AUX0,
+    SLOT_AUX1,
+    SLOT_AUX2,
+    SLOT_AUX3,
+    SLOT_AUX4,
+    SLOT_AUX5,
+    SLOT_OUT0,
+    SLOT_OUT1,
+    SLOT_FLAGS,
+    SLOT_COUNT
+};
+
+}  // namespace amof
+
+struct amof_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_all0 = nullptr, ev_all1 = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
+    bool ev_valid = false;
+    int64_t dom_launches = 0;
+    std::string err;
+    amof::DevBuf buf[amof::SLOT_COUNT];
+};
+
+namespace amof {
+
+int fail(amof_ctx *ctx, int code, const char *fmt, ...);
+int ensure(amof_ctx *ctx, Slot s, size_t bytes, void **out);
+
+#define AMOF_HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return amof::fail((ctx), AMOF_EHIP, "%s failed: %s (%s:%d)", #expr,              \
+                              hipGetErrorString(_e), __FILE__, __LINE__);                    \
+    } while (0)
+
+#define AMOF_TRY(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != AMOF_OK) return _rc; \
+    } while (0)
+
+// --------------------------------------------------------------- geometry --
+// One record per distinct cell: 24 doubles.
+//   [0..8]  cell rows          [9..17] cell^-1 with non-periodic columns zeroed
+//   [18..20] perpendicular heights   [21] volume   [22] ortho flag   [23] pad
+constexpr int GEOM_STRIDE = 24;
+
+struct HostGeom {
+    std::vector<double> rec;      // [n_cells][GEOM_STRIDE]
+    std::vector<double> invfull;  // [n_cells][9] (host-side use)
+    bool all_ortho = true;
+    double volume_sum = 0.0;      // over FRAMES (constant cell counted F times)
+};
+
+int validate_traj(amof_ctx *ctx, const amof_traj *t, bool need_masses);
+int build_geometry(amof_ctx *ctx, const amof_traj *t, HostGeom &g);
+// extra periodic images for cutoff R: per cell record a list of lattice vectors
+int build_images(amof_ctx *ctx, const amof_traj *t, const HostGeom &g, double R,
+                 std::vector<double> &img /* [n_cells][max_img][3] */, std::vector<int32_t> &nimg,
+                 int &max_img);
+
+// species-sorted tiling of the atoms
+struct Tile {
+    int32_t start;    // offset into perm
+    int32_t count;
+    int32_t species;
+    int32_t _pad;
+};
+struct HostTiles {
+    std::vector<int32_t> perm;     // atoms sorted by species (stable)
+    std::vector<Tile> tiles;
+    std::vector<int64_t> nsp;      // atoms per species
+    std::vector<int32_t> sp_first_tile, sp_ntiles;
+};
+void build_tiles(const amof_traj *t, int tile, HostTiles &out);
+
+// staging of the position array (host -> device) or pass-through
+int stage_positions(amof_ctx *ctx, const amof_traj *t, const double **pos_dev);
+int upload(amof_ctx *ctx, Slot s, const void *src, size_t bytes, void **out);
+
+void timing_begin(amof_ctx *ctx);
+void timing_end(amof_ctx *ctx);
+void timing_dom_begin(amof_ctx *ctx);
+void timing_dom_end(amof_ctx *ctx, int64_t launches);
+
+// ------------------------------------------------------- device arithmetic --
+// Canonical minimum-image pair vector (see oracle/amof_oracle.c header and
+// DESIGN.md "canonical arithmetic").  g points at a geometry record.
+template <bool ORTHO>
+__device__ __forceinline__ void pair_base(const double *__restrict__ g, double d0x, double d0y,
+                                          double d0z, double &dx, double &dy, double &dz)
+{
+    if (ORTHO) {
+        // off-diagonal terms are exact zeros: identical bits to the general form
+        double n0 = rint(d0x * g[9]);
+        double n1 = rint(d0y * g[13]);
+        double n2 = rint(d0z * g[17]);
+        dx = fma(-n0, g[0], d0x);
+        dy = fma(-n1, g[4], d0y);
+        dz = fma(-n2, g[8], d0z);
+    } else {
+        double s0 = fma(d0z, g[15], fma(d0y, g[12], d0x * g[9]));
+        double s1 = fma(d0z, g[16], fma(d0y, g[13], d0x * g[10]));
+        double s2 = fma(d0z, g[17], fma(d0y, g[14], d0x * g[11]));
+        double n0 = rint(s0), n1 = rint(s1), n2 = rint(s2);
+        dx = fma(-n2, g[6], fma(-n1, g[3], fma(-n0, g[0], d0x)));
+        dy = fma(-n2, g[7], fma(-n1, g[4], fma(-n0, g[1], d0y)));
+        dz = fma(-n2, g[8], fma(-n1, g[5], fma(-n0, g[2], d0z)));
+    }
+}
+
+__device__ __forceinline__ double norm2(double dx, double dy, double dz)
+{
+    return fma(dz, dz, fma(dy, dy, dx * dx));
+}
+
+}  // namespace amof

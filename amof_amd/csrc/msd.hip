@@ -1,0 +1,386 @@
+// Window-averaged MSD kernels (gfx950).
+//
+// Replaces amof.trajectory.get_delta_pos (amof/trajectory.py:285-303, i.e.
+// ase wrap_positions(center=0)), WindowMsd.compute_msd_of_m
+// (amof/msd.py:185-205) and the centre-of-mass / unwrap preamble of
+// amof/msd.py:222-237.
+//
+// Data flow (all float64):
+//   frame-major pos[F][N][3]  --com_kernel-->      com[F][3]
+//   pos, com  --delta_transpose_kernel-->          D_T[3N][Fp]   wrapped
+//       frame-to-frame displacements, TRANSPOSED to atom-major through an LDS
+//       tile so that a column (one coordinate of one atom over time) is
+//       contiguous;  Fp = F rounded up to 32
+//   D_T --msd_group_kernel-->  partial[group][W]: per column the whole time
+//       series sits in LDS (F*8 bytes), is prefix-summed in place (running
+//       position u) and every window m reduces sum_k (u[k+m]-u[k])^2 from LDS.
+//   partial --msd_reduce_kernel--> sumsq[S][W]  (fixed order: deterministic)
+// HBM traffic: pos read twice (com + delta), D_T written once and read once.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "amof_internal.h"
+
+namespace amof {
+
+constexpr int MSD_THREADS = 256;
+constexpr int MSD_GEOM = 24;  // cell[9], full inverse[9], pbc[3], pad
+constexpr int TR_F = 32;      // frames per transpose tile
+constexpr int TR_A = 64;      // atoms per transpose tile
+constexpr int MSD_GROUP = 4;  // atoms per msd workgroup
+
+// ase.geometry.wrap_positions(d, cell, center=(0,0,0), eps=1e-7) ([3P-memory],
+// call site amof/trajectory.py:302): fractional = d.cell^-1 - shift with
+// shift = -0.5 - eps; periodic axes: fractional %= 1; fractional += shift;
+// result = fractional . cell
+__device__ __forceinline__ void wrap_delta(const double *__restrict__ g, double dx, double dy, double dz,
+                                           double &ox, double &oy, double &oz)
+{
+    const double shift = 0.0 - 0.5 - 1e-7;
+    double fr[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double s = dx * g[9 + k] + dy * g[12 + k] + dz * g[15 + k];
+        if (g[18 + k] != 0.0) {
+            double t = s - shift;
+            t = t - floor(t);
+            s = t + shift;
+        }
+        fr[k] = s;
+    }
+    ox = fr[0] * g[0] + fr[1] * g[3] + fr[2] * g[6];
+    oy = fr[0] * g[1] + fr[1] * g[4] + fr[2] * g[7];
+    oz = fr[0] * g[2] + fr[1] * g[5] + fr[2] * g[8];
+}
+
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int k = 0; k < MSD_THREADS / 64; k++) s += red[k];
+    return s;  // every thread holds the total
+}
+
+// mass-weighted centre of mass of every frame (ase get_center_of_mass:
+// masses @ positions / masses.sum(); amof/msd.py:236)
+__global__ __launch_bounds__(MSD_THREADS) void com_kernel(const double *__restrict__ pos,
+                                                          const double *__restrict__ masses, int64_t N,
+                                                          double total_mass, double *__restrict__ com)
+{
+    __shared__ double red[MSD_THREADS / 64];
+    const int f = blockIdx.x;
+    const double *__restrict__ p = pos + (size_t)f * (size_t)N * 3;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += MSD_THREADS) {
+        double m = masses[i];
+        sx += m * p[3 * i];
+        sy += m * p[3 * i + 1];
+        sz += m * p[3 * i + 2];
+    }
+    sx = block_sum(sx, red);
+    sy = block_sum(sy, red);
+    sz = block_sum(sz, red);
+    if (threadIdx.x == 0) {
+        com[3 * f] = sx / total_mass;
+        com[3 * f + 1] = sy / total_mass;
+        com[3 * f + 2] = sz / total_mass;
+    }
+}
+
+// D_T[3a+c][k] = wrap((pos[k][a]-com[k]) - (pos[k-1][a]-com[k-1]); cell[k-1]),  D_T[.][0] = 0
+__global__ __launch_bounds__(MSD_THREADS) void delta_transpose_kernel(const double *__restrict__ pos,
+                                                                      const double *__restrict__ com,
+                                                                      const double *__restrict__ geom,
+                                                                      int n_cells, int64_t N, int F, int64_t Fp,
+                                                                      double *__restrict__ DT)
+{
+    __shared__ double tile[TR_F][3 * TR_A + 1];
+    const int k0 = blockIdx.y * TR_F;
+    const int64_t a0 = (int64_t)blockIdx.x * TR_A;
+    for (int idx = threadIdx.x; idx < TR_F * TR_A; idx += MSD_THREADS) {
+        const int kl = idx / TR_A, al = idx % TR_A;
+        const int k = k0 + kl;
+        const int64_t a = a0 + al;
+        double dx = 0.0, dy = 0.0, dz = 0.0;
+        if (k < F && a < N && k >= 1) {
+            const double *p1 = pos + ((size_t)k * N + a) * 3;
+            const double *p0 = pos + ((size_t)(k - 1) * N + a) * 3;
+            double x1 = p1[0], y1 = p1[1], z1 = p1[2];
+            double x0 = p0[0], y0 = p0[1], z0 = p0[2];
+            if (com) {
+                x1 -= com[3 * k]; y1 -= com[3 * k + 1]; z1 -= com[3 * k + 2];
+                x0 -= com[3 * (k - 1)]; y0 -= com[3 * (k - 1) + 1]; z0 -= com[3 * (k - 1) + 2];
+            }
+            const double *g = geom + (size_t)(n_cells == 1 ? 0 : k - 1) * MSD_GEOM;
+            wrap_delta(g, x1 - x0, y1 - y0, z1 - z0, dx, dy, dz);
+        }
+        tile[kl][3 * al] = dx;
+        tile[kl][3 * al + 1] = dy;
+        tile[kl][3 * al + 2] = dz;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TR_F * 3 * TR_A; idx += MSD_THREADS) {
+        const int cl = idx / TR_F, kl = idx % TR_F;
+        const int64_t col = 3 * a0 + cl;
+        if (col < 3 * N) DT[(size_t)col * Fp + k0 + kl] = tile[kl][cl];
+    }
+}
+
+// in-place inclusive prefix sum of u[0..F) held in LDS by the whole workgroup
+__device__ __forceinline__ void lds_scan(double *u, int F, double *wtot, double carry_init)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double carry = carry_init;
+    for (int base = 0; base < F; base += MSD_THREADS) {
+        const int k = base + tid;
+        double v = k < F ? u[k] : 0.0;
+        for (int off = 1; off < 64; off <<= 1) {
+            double n = __shfl_up(v, off, 64);
+            if (lane >= off) v += n;
+        }
+        __syncthreads();
+        if (lane == 63) wtot[wv] = v;
+        __syncthreads();
+        double pre = carry;
+        for (int q = 0; q < wv; q++) pre += wtot[q];
+        if (k < F) u[k] = v + pre;
+        double tot = 0.0;
+        for (int q = 0; q < MSD_THREADS / 64; q++) tot += wtot[q];
+        carry += tot;
+    }
+    __syncthreads();
+}
+
+struct MsdGroup {
+    int32_t start;    // into perm
+    int32_t count;    // atoms
+    int32_t species;
+    int32_t _pad;
+};
+
+// one workgroup = one group of <= MSD_GROUP atoms of one species
+__global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__restrict__ DT, int64_t Fp, int F,
+                                                                const int32_t *__restrict__ perm,
+                                                                const MsdGroup *__restrict__ groups,
+                                                                const int32_t *__restrict__ windows, int W,
+                                                                double *__restrict__ partial)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *u = reinterpret_cast<double *>(lds_raw);  // [F]
+    double *wsum = u + F;                             // [W]
+    __shared__ double red[MSD_THREADS / 64];
+    const int tid = threadIdx.x;
+    const MsdGroup gr = groups[blockIdx.x];
+    for (int w = tid; w < W; w += MSD_THREADS) wsum[w] = 0.0;
+    for (int c = 0; c < 3 * gr.count; c++) {
+        const int64_t atom = perm[gr.start + c / 3];
+        const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
+        __syncthreads();
+        for (int k = tid; k < F; k += MSD_THREADS) u[k] = col[k];
+        __syncthreads();
+        lds_scan(u, F, red, 0.0);
+        for (int w = 0; w < W; w++) {
+            const int m = windows[w];
+            double acc = 0.0;
+            for (int k = 1 + tid; k + m < F; k += MSD_THREADS) {
+                double d = u[k + m] - u[k];
+                acc = fma(d, d, acc);
+            }
+            acc = block_sum(acc, red);
+            if (tid == 0) wsum[w] += acc;
+        }
+    }
+    __syncthreads();
+    for (int w = tid; w < W; w += MSD_THREADS) partial[(size_t)blockIdx.x * W + w] = wsum[w];
+}
+
+// sumsq[s][w] = sum over the groups of species s, in group order
+__global__ void msd_reduce_kernel(const double *__restrict__ partial, const MsdGroup *__restrict__ groups,
+                                  int n_groups, int W, int S, double *__restrict__ sumsq)
+{
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * W) return;
+    int s = idx / W, w = idx % W;
+    double acc = 0.0;
+    for (int g = 0; g < n_groups; g++)
+        if (groups[g].species == s) acc += partial[(size_t)g * W + w];
+    sumsq[idx] = acc;
+}
+
+// ---- unwrap path (amof/msd.py:222-230) in atom-major layout ----
+// U_T[col][k] = pos[0][col] + sum_{j<=k} D_T[col][j]
+__global__ __launch_bounds__(MSD_THREADS) void unwrap_scan_kernel(const double *__restrict__ DT,
+                                                                  const double *__restrict__ pos0, int64_t Fp,
+                                                                  int F, double *__restrict__ UT)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *u = reinterpret_cast<double *>(lds_raw);
+    __shared__ double red[MSD_THREADS / 64];
+    const size_t col = blockIdx.x;
+    for (int k = threadIdx.x; k < F; k += MSD_THREADS) u[k] = DT[col * Fp + k];
+    __syncthreads();
+    lds_scan(u, F, red, 0.0);
+    const double x0 = pos0[col];
+    for (int k = threadIdx.x; k < F; k += MSD_THREADS) UT[col * Fp + k] = x0 + u[k];
+}
+
+__global__ __launch_bounds__(MSD_THREADS) void com_T_kernel(const double *__restrict__ UT,
+                                                            const double *__restrict__ masses, int64_t N,
+                                                            int64_t Fp, int F, double total_mass,
+                                                            double *__restrict__ com)
+{
+    const int k = blockIdx.x * MSD_THREADS + threadIdx.x;
+    const int c = blockIdx.y;
+    if (k >= F) return;
+    double s = 0.0;
+    for (int64_t i = 0; i < N; i++) s += masses[i] * UT[(size_t)(3 * i + c) * Fp + k];
+    com[3 * k + c] = s / total_mass;
+}
+
+__global__ __launch_bounds__(MSD_THREADS) void delta_T_kernel(const double *__restrict__ UT,
+                                                              const double *__restrict__ com,
+                                                              const double *__restrict__ geom, int n_cells,
+                                                              int64_t N, int64_t Fp, int F,
+                                                              double *__restrict__ DT)
+{
+    const int k = blockIdx.y * MSD_THREADS + threadIdx.x;
+    const size_t a = blockIdx.x;
+    if (k >= F) return;
+    double dx = 0.0, dy = 0.0, dz = 0.0;
+    if (k >= 1) {
+        double x1 = UT[(3 * a) * Fp + k], y1 = UT[(3 * a + 1) * Fp + k], z1 = UT[(3 * a + 2) * Fp + k];
+        double x0 = UT[(3 * a) * Fp + k - 1], y0 = UT[(3 * a + 1) * Fp + k - 1], z0 = UT[(3 * a + 2) * Fp + k - 1];
+        if (com) {
+            x1 -= com[3 * k]; y1 -= com[3 * k + 1]; z1 -= com[3 * k + 2];
+            x0 -= com[3 * (k - 1)]; y0 -= com[3 * (k - 1) + 1]; z0 -= com[3 * (k - 1) + 2];
+        }
+        const double *g = geom + (size_t)(n_cells == 1 ? 0 : k - 1) * MSD_GEOM;
+        wrap_delta(g, x1 - x0, y1 - y0, z1 - z0, dx, dy, dz);
+    }
+    DT[(3 * a) * Fp + k] = dx;
+    DT[(3 * a + 1) * Fp + k] = dy;
+    DT[(3 * a + 2) * Fp + k] = dz;
+}
+
+}  // namespace amof
+
+using namespace amof;
+
+extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W,
+                               int32_t unwrap, int32_t remove_com, int64_t atom_begin, int64_t atom_end,
+                               double *sumsq)
+{
+    if (!ctx) return AMOF_EINVAL;
+    AMOF_TRY(validate_traj(ctx, t, remove_com != 0));
+    const int S = t->n_species;
+    const int64_t N = t->n_atoms, F = t->n_frames;
+    if (W < 0 || (W > 0 && !windows) || !sumsq) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    if (atom_begin < 0 || atom_end > N || atom_begin > atom_end) return fail(ctx, AMOF_EINVAL, "bad atom range");
+    for (int w = 0; w < W; w++)
+        if (windows[w] < 0 || (F > 0 && windows[w] >= F)) return fail(ctx, AMOF_EINVAL, "window %d out of range", windows[w]);
+    for (int k = 0; k < S * W; k++) sumsq[k] = 0.0;
+    if (F == 0 || N == 0 || W == 0 || atom_begin == atom_end) return AMOF_OK;
+    if (F > 0x7fffffffLL) return fail(ctx, AMOF_EINVAL, "too many frames");
+    const size_t lds_need = ((size_t)F + (size_t)W) * sizeof(double);
+    if (lds_need > 150 * 1024)
+        return fail(ctx, AMOF_ECAPACITY, "n_frames + n_windows = %lld exceeds the LDS-resident limit of %d",
+                    (long long)(F + W), (int)(150 * 1024 / sizeof(double)));
+
+    // geometry records with the FULL inverse (wrap_positions semantics)
+    HostGeom hg;
+    AMOF_TRY(build_geometry(ctx, t, hg));
+    std::vector<double> grec((size_t)t->n_cells * MSD_GEOM, 0.0);
+    for (int64_t k = 0; k < t->n_cells; k++) {
+        for (int q = 0; q < 9; q++) grec[(size_t)k * MSD_GEOM + q] = t->cell[9 * k + q];
+        for (int q = 0; q < 9; q++) grec[(size_t)k * MSD_GEOM + 9 + q] = hg.invfull[(size_t)k * 9 + q];
+        for (int q = 0; q < 3; q++) grec[(size_t)k * MSD_GEOM + 18 + q] = t->pbc[q] ? 1.0 : 0.0;
+    }
+    // species-sorted groups of the selected atoms
+    std::vector<int32_t> perm;
+    std::vector<MsdGroup> groups;
+    for (int s = 0; s < S; s++) {
+        size_t first = perm.size();
+        for (int64_t i = atom_begin; i < atom_end; i++)
+            if (t->species[i] == s) perm.push_back((int32_t)i);
+        for (size_t off = first; off < perm.size(); off += MSD_GROUP) {
+            MsdGroup g;
+            g.start = (int32_t)off;
+            g.count = (int32_t)std::min<size_t>(MSD_GROUP, perm.size() - off);
+            g.species = s;
+            g._pad = 0;
+            groups.push_back(g);
+        }
+    }
+    double total_mass = 0.0;
+    if (remove_com)
+        for (int64_t i = 0; i < N; i++) total_mass += t->masses[i];
+
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    timing_begin(ctx);
+    const double *pos_dev = nullptr;
+    AMOF_TRY(stage_positions(ctx, t, &pos_dev));
+    const int64_t Fp = (F + 31) / 32 * 32;
+    const size_t dt_bytes = (size_t)3 * N * Fp * sizeof(double);
+    void *d_geom, *d_perm, *d_groups, *d_win, *d_mass = nullptr, *d_com = nullptr, *d_DT, *d_UT = nullptr, *d_part, *d_out;
+    AMOF_TRY(upload(ctx, SLOT_GEOM, grec.data(), grec.size() * sizeof(double), &d_geom));
+    AMOF_TRY(upload(ctx, SLOT_PERM, perm.data(), perm.size() * sizeof(int32_t), &d_perm));
+    AMOF_TRY(upload(ctx, SLOT_TILES, groups.data(), groups.size() * sizeof(MsdGroup), &d_groups));
+    AMOF_TRY(upload(ctx, SLOT_AUX0, windows, (size_t)W * sizeof(int32_t), &d_win));
+    if (remove_com) {
+        AMOF_TRY(upload(ctx, SLOT_AUX1, t->masses, (size_t)N * sizeof(double), &d_mass));
+        AMOF_TRY(ensure(ctx, SLOT_AUX2, (size_t)F * 3 * sizeof(double), &d_com));
+    }
+    AMOF_TRY(ensure(ctx, SLOT_AUX3, dt_bytes, &d_DT));
+    AMOF_TRY(ensure(ctx, SLOT_AUX5, groups.size() * (size_t)W * sizeof(double), &d_part));
+    AMOF_TRY(ensure(ctx, SLOT_OUT0, (size_t)S * W * sizeof(double), &d_out));
+
+    dim3 tgrid((unsigned)((N + TR_A - 1) / TR_A), (unsigned)((F + TR_F - 1) / TR_F));
+    if (!unwrap) {
+        if (remove_com) {
+            hipLaunchKernelGGL(com_kernel, dim3((unsigned)F), dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
+                               (const double *)d_mass, N, total_mass, (double *)d_com);
+        }
+        hipLaunchKernelGGL(delta_transpose_kernel, tgrid, dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
+                           (const double *)d_com, (const double *)d_geom, (int)t->n_cells, N, (int)F, Fp,
+                           (double *)d_DT);
+    } else {
+        AMOF_TRY(ensure(ctx, SLOT_AUX4, dt_bytes, &d_UT));
+        hipLaunchKernelGGL(delta_transpose_kernel, tgrid, dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
+                           (const double *)nullptr, (const double *)d_geom, (int)t->n_cells, N, (int)F, Fp,
+                           (double *)d_DT);
+        AMOF_HIP_TRY(ctx, hipFuncSetAttribute((const void *)unwrap_scan_kernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F * sizeof(double))));
+        hipLaunchKernelGGL(unwrap_scan_kernel, dim3((unsigned)(3 * N)), dim3(MSD_THREADS), (size_t)F * sizeof(double),
+                           ctx->stream, (const double *)d_DT, pos_dev, Fp, (int)F, (double *)d_UT);
+        if (remove_com) {
+            hipLaunchKernelGGL(com_T_kernel, dim3((unsigned)((F + MSD_THREADS - 1) / MSD_THREADS), 3),
+                               dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_UT, (const double *)d_mass, N, Fp,
+                               (int)F, total_mass, (double *)d_com);
+        }
+        hipLaunchKernelGGL(delta_T_kernel, dim3((unsigned)N, (unsigned)((F + MSD_THREADS - 1) / MSD_THREADS)),
+                           dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_UT, (const double *)d_com,
+                           (const double *)d_geom, (int)t->n_cells, N, Fp, (int)F, (double *)d_DT);
+    }
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    AMOF_HIP_TRY(ctx, hipFuncSetAttribute((const void *)msd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds_need));
+    timing_dom_begin(ctx);
+    hipLaunchKernelGGL(msd_group_kernel, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds_need, ctx->stream,
+                       (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
+                       (const int32_t *)d_win, (int)W, (double *)d_part);
+    timing_dom_end(ctx, 1);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(msd_reduce_kernel, dim3((unsigned)((S * W + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double *)d_part, (const MsdGroup *)d_groups, (int)groups.size(), (int)W, S,
+                       (double *)d_out);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    timing_end(ctx);
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(sumsq, d_out, (size_t)S * W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMOF_OK;
+}

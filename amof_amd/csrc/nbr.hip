@@ -1,0 +1,485 @@
+// Cutoff-neighbour kernels (gfx950): coordination numbers and bond angles.
+//
+// CN  replaces amof.atom.get_neighborlist + the counting loop of
+//     amof/cn.py:58-73 (ase.neighborlist.neighbor_list('ij', atoms, dict)).
+// BAD replaces amof.atom.get_neighborlist + ase.Atoms.get_angles(mic=True) +
+//     numpy.histogram as driven by amof/bad.py:70-114,154-160.
+//
+// Both kernels only ever look at species pairs that have a cutoff: atoms are
+// sorted by species into tiles (as for the RDF) and a centre tile is compared
+// with the tiles of its partner species only, staged through LDS and read by
+// broadcast.  All results are integer counts (exact, order independent).
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "amof_internal.h"
+
+namespace amof {
+
+constexpr int CN_TILE = 256;
+constexpr int BAD_TILE = 64;
+
+struct NbrArgs {
+    const double *pos;
+    const double *geom;
+    const double *img;
+    const int32_t *nimg;
+    const int32_t *perm;
+    const Tile *tiles;
+    const int32_t *sp_first_tile;  // [S]
+    const int32_t *sp_ntiles;      // [S]
+    const double *cutoff;          // [S][S]
+    const int4 *work;              // (set/triple index, centre tile, A, B)
+    int64_t N;
+    int32_t F;
+    int32_t n_cells;
+    int32_t frames_per_chunk;
+    int32_t S;
+    int32_t max_img;
+    int32_t n_sets;
+    // CN outputs
+    unsigned long long *sums;  // [F][n_sets]
+    int32_t *per_atom;         // [F][n_sets][N] or null
+    // BAD
+    const double *edges;       // [nb+1]
+    int32_t nb;
+    unsigned long long *hist;  // [T][nb]
+    unsigned long long *n_angles;
+    int32_t *flags;            // [0] zero-length vector, [1] neighbour overflow
+};
+
+// ------------------------------------------------------------------- CN ----
+template <bool ORTHO, bool EXTRA>
+__global__ __launch_bounds__(CN_TILE) void cn_kernel(NbrArgs a)
+{
+    __shared__ double tjx[CN_TILE], tjy[CN_TILE], tjz[CN_TILE];
+    __shared__ int tja[CN_TILE];
+    __shared__ unsigned long long wsum[CN_TILE / 64];
+    const int tid = threadIdx.x;
+    const int4 w = a.work[blockIdx.x];
+    const int set = w.x, A = w.z, B = w.w;
+    const Tile ti = a.tiles[w.y];
+    const double rc = a.cutoff[A * a.S + B];
+    const int64_t ai = tid < ti.count ? a.perm[ti.start + tid] : -1;
+    const int f0 = blockIdx.y * a.frames_per_chunk;
+    const int f1 = min(f0 + a.frames_per_chunk, a.F);
+    const int tb0 = a.sp_first_tile[B], tb1 = tb0 + a.sp_ntiles[B];
+
+    for (int f = f0; f < f1; f++) {
+        const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+        const int gi = a.n_cells == 1 ? 0 : f;
+        const double *__restrict__ g = a.geom + (size_t)gi * GEOM_STRIDE;
+        const int ne = EXTRA ? a.nimg[gi] : 0;
+        const double *__restrict__ E = EXTRA ? a.img + (size_t)gi * a.max_img * 3 : nullptr;
+        double xi = 0.0, yi = 0.0, zi = 0.0;
+        if (ai >= 0) {
+            xi = p[ai * 3 + 0];
+            yi = p[ai * 3 + 1];
+            zi = p[ai * 3 + 2];
+        }
+        int cnt = 0;
+        if (rc > 0.0) {
+            for (int tb = tb0; tb < tb1; tb++) {
+                const Tile tj = a.tiles[tb];
+                __syncthreads();
+                if (tid < tj.count) {
+                    int64_t aj = a.perm[tj.start + tid];
+                    tjx[tid] = p[aj * 3 + 0];
+                    tjy[tid] = p[aj * 3 + 1];
+                    tjz[tid] = p[aj * 3 + 2];
+                    tja[tid] = (int)aj;
+                }
+                __syncthreads();
+                if (ai >= 0) {
+                    for (int j = 0; j < tj.count; j++) {
+                        const bool self = tja[j] == (int)ai;
+                        if (self && !EXTRA) continue;
+                        double dx, dy, dz;
+                        pair_base<ORTHO>(g, tjx[j] - xi, tjy[j] - yi, tjz[j] - zi, dx, dy, dz);
+                        if (!self && sqrt(norm2(dx, dy, dz)) < rc) cnt++;
+                        if (EXTRA) {
+                            for (int m = 0; m < ne; m++)
+                                if (sqrt(norm2(dx + E[3 * m], dy + E[3 * m + 1], dz + E[3 * m + 2])) < rc) cnt++;
+                        }
+                    }
+                }
+            }
+        }
+        if (a.per_atom && ai >= 0) a.per_atom[((size_t)f * a.n_sets + set) * (size_t)a.N + ai] = cnt;
+        // workgroup sum of the integer counts
+        unsigned long long v = ai >= 0 ? (unsigned long long)cnt : 0ull;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) wsum[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long s = 0;
+            for (int k = 0; k < CN_TILE / 64; k++) s += wsum[k];
+            if (s) atomicAdd(&a.sums[(size_t)f * a.n_sets + set], s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ BAD ----
+// numpy.histogram with explicit edges: bin k holds edges[k] <= x < edges[k+1],
+// the last bin is right-closed; outside -> -1.
+__device__ __forceinline__ int hist_bin(const double *__restrict__ edges, int nb, double x)
+{
+    if (!(x >= edges[0]) || !(x <= edges[nb])) return -1;
+    double w = (edges[nb] - edges[0]) / nb;
+    int k = (int)((x - edges[0]) / w);
+    k = max(0, min(k, nb - 1));
+    while (k > 0 && x < edges[k]) k--;
+    while (k < nb - 1 && x >= edges[k + 1]) k++;
+    return k;
+}
+
+template <bool ORTHO, bool EXTRA>
+__global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // unit vectors of the neighbours, [slot][lane] so that a lane's accesses
+    // never conflict with its neighbours'
+    double *ux = reinterpret_cast<double *>(lds_raw);
+    double *uy = ux + AMOF_MAX_NEIGHBOURS * BAD_TILE;
+    double *uz = uy + AMOF_MAX_NEIGHBOURS * BAD_TILE;
+    double *tjx = uz + AMOF_MAX_NEIGHBOURS * BAD_TILE;
+    double *tjy = tjx + BAD_TILE;
+    double *tjz = tjy + BAD_TILE;
+    int *tja = reinterpret_cast<int *>(tjz + BAD_TILE);
+    unsigned *hist = reinterpret_cast<unsigned *>(tja + BAD_TILE);
+
+    const int tid = threadIdx.x;
+    const int4 w = a.work[blockIdx.x];
+    const int trip = w.x, B = w.w;
+    const Tile ti = a.tiles[w.y];
+    const int sa = ti.species;
+    const int64_t ai = tid < ti.count ? a.perm[ti.start + tid] : -1;
+    const int f0 = blockIdx.y * a.frames_per_chunk;
+    const int f1 = min(f0 + a.frames_per_chunk, a.F);
+    const int nb = a.nb;
+    for (int k = tid; k < nb; k += BAD_TILE) hist[k] = 0u;
+    unsigned long long nang = 0;
+
+    for (int f = f0; f < f1; f++) {
+        const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+        const int gi = a.n_cells == 1 ? 0 : f;
+        const double *__restrict__ g = a.geom + (size_t)gi * GEOM_STRIDE;
+        const int ne = EXTRA ? a.nimg[gi] : 0;
+        const double *__restrict__ E = EXTRA ? a.img + (size_t)gi * a.max_img * 3 : nullptr;
+        double xi = 0.0, yi = 0.0, zi = 0.0;
+        if (ai >= 0) {
+            xi = p[ai * 3 + 0];
+            yi = p[ai * 3 + 1];
+            zi = p[ai * 3 + 2];
+        }
+        int n = 0;
+        for (int sb = 0; sb < a.S; sb++) {
+            if (!(B < 0 || sb == B)) continue;
+            const double rc = a.cutoff[sa * a.S + sb];
+            if (!(rc > 0.0)) continue;
+            const int tb0 = a.sp_first_tile[sb], tb1 = tb0 + a.sp_ntiles[sb];
+            for (int tb = tb0; tb < tb1; tb += 1) {
+                // partner tiles hold up to 256 atoms: stage them 64 at a time
+                const Tile tj = a.tiles[tb];
+                for (int base = 0; base < tj.count; base += BAD_TILE) {
+                    const int cntj = min(BAD_TILE, tj.count - base);
+                    __syncthreads();
+                    if (tid < cntj) {
+                        int64_t aj = a.perm[tj.start + base + tid];
+                        tjx[tid] = p[aj * 3 + 0];
+                        tjy[tid] = p[aj * 3 + 1];
+                        tjz[tid] = p[aj * 3 + 2];
+                        tja[tid] = (int)aj;
+                    }
+                    __syncthreads();
+                    if (ai < 0) continue;
+                    for (int j = 0; j < cntj; j++) {
+                        const bool self = tja[j] == (int)ai;
+                        if (self && !EXTRA) continue;
+                        double dx, dy, dz;
+                        pair_base<ORTHO>(g, tjx[j] - xi, tjy[j] - yi, tjz[j] - zi, dx, dy, dz);
+                        double best2 = norm2(dx, dy, dz), bx = dx, by = dy, bz = dz;
+                        int hits = (!self && sqrt(best2) < rc) ? 1 : 0;
+                        if (EXTRA) {
+                            for (int m = 0; m < ne; m++) {
+                                double ex = dx + E[3 * m], ey = dy + E[3 * m + 1], ez = dz + E[3 * m + 2];
+                                double e2 = norm2(ex, ey, ez);
+                                if (sqrt(e2) < rc) hits++;
+                                if (e2 < best2) { best2 = e2; bx = ex; by = ey; bz = ez; }
+                            }
+                        }
+                        if (hits) {
+                            // ase.geometry.get_angles: v /= |v| before the dot product
+                            double nv = sqrt(bx * bx + by * by + bz * bz);
+                            if (!(nv > 0.0)) { a.flags[0] = 1; continue; }
+                            double qx = bx / nv, qy = by / nv, qz = bz / nv;
+                            for (int h = 0; h < hits; h++) {
+                                if (n < AMOF_MAX_NEIGHBOURS) {
+                                    ux[n * BAD_TILE + tid] = qx;
+                                    uy[n * BAD_TILE + tid] = qy;
+                                    uz[n * BAD_TILE + tid] = qz;
+                                    n++;
+                                } else {
+                                    a.flags[1] = 1;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // every unordered pair of neighbours of this centre -> one angle
+        for (int u = 0; u < n; u++) {
+            const double ax = ux[u * BAD_TILE + tid], ay = uy[u * BAD_TILE + tid], az = uz[u * BAD_TILE + tid];
+            for (int v = u + 1; v < n; v++) {
+                double dot = ax * ux[v * BAD_TILE + tid] + ay * uy[v * BAD_TILE + tid] + az * uz[v * BAD_TILE + tid];
+                if (dot > 1.0) dot = 1.0;
+                if (dot < -1.0) dot = -1.0;
+                double ang = (180.0 / M_PI) * acos(dot);
+                nang++;
+                int k = hist_bin(a.edges, nb, ang);
+                if (k >= 0) atomicAdd(&hist[k], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long *H = a.hist + (size_t)trip * nb;
+    for (int k = tid; k < nb; k += BAD_TILE) {
+        unsigned v = hist[k];
+        if (v) atomicAdd(&H[k], (unsigned long long)v);
+    }
+    for (int off = 32; off > 0; off >>= 1) nang += __shfl_down(nang, off, 64);
+    if (tid == 0 && nang) atomicAdd(&a.n_angles[trip], nang);
+}
+
+// ------------------------------------------------------------ host side ----
+struct NbrSetup {
+    HostGeom geom;
+    std::vector<double> img;
+    std::vector<int32_t> nimg;
+    int max_img = 0;
+    HostTiles tiles;
+    NbrArgs a;
+};
+
+static int nbr_setup(amof_ctx *ctx, const amof_traj *t, const double *cutoff, int tile, NbrSetup &s)
+{
+    const int S = t->n_species;
+    double R = 0.0;
+    for (int k = 0; k < S * S; k++) {
+        if (!(cutoff[k] >= 0.0) || !isfinite(cutoff[k])) return fail(ctx, AMOF_EINVAL, "cutoff must be finite and >= 0");
+        R = std::max(R, cutoff[k]);
+    }
+    for (int x = 0; x < S; x++)
+        for (int y = 0; y < S; y++)
+            if (cutoff[x * S + y] != cutoff[y * S + x]) return fail(ctx, AMOF_EINVAL, "cutoff matrix must be symmetric");
+    AMOF_TRY(build_geometry(ctx, t, s.geom));
+    AMOF_TRY(build_images(ctx, t, s.geom, R, s.img, s.nimg, s.max_img));
+    build_tiles(t, tile, s.tiles);
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    timing_begin(ctx);
+    const double *pos_dev = nullptr;
+    AMOF_TRY(stage_positions(ctx, t, &pos_dev));
+    void *d_geom, *d_img, *d_nimg, *d_perm, *d_tiles, *d_ft, *d_nt, *d_cut;
+    AMOF_TRY(upload(ctx, SLOT_GEOM, s.geom.rec.data(), s.geom.rec.size() * sizeof(double), &d_geom));
+    AMOF_TRY(upload(ctx, SLOT_IMG, s.img.data(), s.img.size() * sizeof(double), &d_img));
+    AMOF_TRY(upload(ctx, SLOT_NIMG, s.nimg.data(), s.nimg.size() * sizeof(int32_t), &d_nimg));
+    AMOF_TRY(upload(ctx, SLOT_PERM, s.tiles.perm.data(), s.tiles.perm.size() * sizeof(int32_t), &d_perm));
+    AMOF_TRY(upload(ctx, SLOT_TILES, s.tiles.tiles.data(), s.tiles.tiles.size() * sizeof(Tile), &d_tiles));
+    AMOF_TRY(upload(ctx, SLOT_AUX0, s.tiles.sp_first_tile.data(), S * sizeof(int32_t), &d_ft));
+    AMOF_TRY(upload(ctx, SLOT_AUX1, s.tiles.sp_ntiles.data(), S * sizeof(int32_t), &d_nt));
+    AMOF_TRY(upload(ctx, SLOT_AUX2, cutoff, (size_t)S * S * sizeof(double), &d_cut));
+    NbrArgs &a = s.a;
+    a = NbrArgs{};
+    a.pos = pos_dev;
+    a.geom = (const double *)d_geom;
+    a.img = (const double *)d_img;
+    a.nimg = (const int32_t *)d_nimg;
+    a.perm = (const int32_t *)d_perm;
+    a.tiles = (const Tile *)d_tiles;
+    a.sp_first_tile = (const int32_t *)d_ft;
+    a.sp_ntiles = (const int32_t *)d_nt;
+    a.cutoff = (const double *)d_cut;
+    a.N = t->n_atoms;
+    a.F = (int32_t)t->n_frames;
+    a.n_cells = (int32_t)t->n_cells;
+    a.S = S;
+    a.max_img = s.max_img;
+    return AMOF_OK;
+}
+
+static void pick_chunks(int64_t F, size_t nwork, int32_t &fpc, unsigned &chunks)
+{
+    int64_t want = (4 * 2048 + (int64_t)nwork - 1) / (int64_t)std::max<size_t>(1, nwork);
+    int64_t f = std::max<int64_t>(1, F / std::max<int64_t>(1, want));
+    f = std::min<int64_t>(f, 64);
+    int64_t c = (F + f - 1) / f;
+    if (c > 65535) {
+        f = (F + 65534) / 65535;
+        c = (F + f - 1) / f;
+    }
+    fpc = (int32_t)f;
+    chunks = (unsigned)c;
+}
+
+}  // namespace amof
+
+using namespace amof;
+
+extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cutoff, const int32_t *sets,
+                             int32_t n_sets, int64_t *sums, int32_t *per_atom)
+{
+    if (!ctx) return AMOF_EINVAL;
+    AMOF_TRY(validate_traj(ctx, t, false));
+    if (!cutoff || n_sets < 0 || (n_sets > 0 && (!sets || !sums))) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    const int S = t->n_species;
+    for (int s = 0; s < n_sets; s++)
+        if (sets[2 * s] < 0 || sets[2 * s] >= S || sets[2 * s + 1] < 0 || sets[2 * s + 1] >= S)
+            return fail(ctx, AMOF_EINVAL, "set %d names a species out of range", s);
+    if (n_sets == 0 || t->n_frames == 0) return AMOF_OK;
+    NbrSetup st;
+    AMOF_TRY(nbr_setup(ctx, t, cutoff, CN_TILE, st));
+    std::vector<int4> work;
+    for (int s = 0; s < n_sets; s++) {
+        int A = sets[2 * s], B = sets[2 * s + 1];
+        for (int k = 0; k < st.tiles.sp_ntiles[A]; k++)
+            work.push_back(make_int4(s, st.tiles.sp_first_tile[A] + k, A, B));
+    }
+    const size_t F = (size_t)t->n_frames, N = (size_t)t->n_atoms;
+    void *d_work, *d_sums, *d_pa = nullptr;
+    AMOF_TRY(upload(ctx, SLOT_PAIRS, work.data(), work.size() * sizeof(int4), &d_work));
+    AMOF_TRY(ensure(ctx, SLOT_OUT0, F * n_sets * sizeof(int64_t), &d_sums));
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(d_sums, 0, F * n_sets * sizeof(int64_t), ctx->stream));
+    if (per_atom) {
+        AMOF_TRY(ensure(ctx, SLOT_OUT1, F * n_sets * N * sizeof(int32_t), &d_pa));
+        AMOF_HIP_TRY(ctx, hipMemsetAsync(d_pa, 0xFF, F * n_sets * N * sizeof(int32_t), ctx->stream));
+    }
+    NbrArgs &a = st.a;
+    a.work = (const int4 *)d_work;
+    a.n_sets = n_sets;
+    a.sums = (unsigned long long *)d_sums;
+    a.per_atom = (int32_t *)d_pa;
+    if (!work.empty()) {
+        unsigned chunks;
+        pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
+        dim3 grid((unsigned)work.size(), chunks);
+        const bool extra = st.max_img > 0, ortho = st.geom.all_ortho;
+        timing_dom_begin(ctx);
+        if (ortho && !extra) hipLaunchKernelGGL((cn_kernel<true, false>), grid, dim3(CN_TILE), 0, ctx->stream, a);
+        else if (ortho && extra) hipLaunchKernelGGL((cn_kernel<true, true>), grid, dim3(CN_TILE), 0, ctx->stream, a);
+        else if (!ortho && !extra) hipLaunchKernelGGL((cn_kernel<false, false>), grid, dim3(CN_TILE), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((cn_kernel<false, true>), grid, dim3(CN_TILE), 0, ctx->stream, a);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
+        timing_dom_end(ctx, 1);
+    }
+    timing_end(ctx);
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(sums, d_sums, F * n_sets * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (per_atom)
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(per_atom, d_pa, F * n_sets * N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMOF_OK;
+}
+
+static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, const int32_t *triples,
+                   int32_t T, const double *edges, int32_t nb, unsigned long long *hist_dev,
+                   unsigned long long *nang_dev)
+{
+    NbrSetup st;
+    AMOF_TRY(nbr_setup(ctx, t, cutoff, BAD_TILE, st));
+    std::vector<int4> work;
+    for (int k = 0; k < T; k++) {
+        int A = triples[2 * k], B = triples[2 * k + 1];
+        for (int tl = 0; tl < (int)st.tiles.tiles.size(); tl++)
+            if (A < 0 || st.tiles.tiles[tl].species == A) work.push_back(make_int4(k, tl, A, B));
+    }
+    void *d_work, *d_edges, *d_flags;
+    AMOF_TRY(upload(ctx, SLOT_PAIRS, work.data(), work.size() * sizeof(int4), &d_work));
+    AMOF_TRY(upload(ctx, SLOT_AUX3, edges, (size_t)(nb + 1) * sizeof(double), &d_edges));
+    AMOF_TRY(ensure(ctx, SLOT_FLAGS, 2 * sizeof(int32_t), &d_flags));
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 2 * sizeof(int32_t), ctx->stream));
+    NbrArgs &a = st.a;
+    a.work = (const int4 *)d_work;
+    a.edges = (const double *)d_edges;
+    a.nb = nb;
+    a.hist = hist_dev;
+    a.n_angles = nang_dev;
+    a.flags = (int32_t *)d_flags;
+    if (!work.empty() && t->n_frames > 0) {
+        unsigned chunks;
+        pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
+        dim3 grid((unsigned)work.size(), chunks);
+        size_t lds = (size_t)(3 * AMOF_MAX_NEIGHBOURS * BAD_TILE + 3 * BAD_TILE) * sizeof(double) +
+                     BAD_TILE * sizeof(int) + (size_t)nb * sizeof(unsigned);
+        const bool extra = st.max_img > 0, ortho = st.geom.all_ortho;
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(BAD_TILE), lds, ctx->stream, a);
+            return hipGetLastError();
+        };
+        timing_dom_begin(ctx);
+        hipError_t e;
+        if (ortho && !extra) e = launch(bad_kernel<true, false>);
+        else if (ortho && extra) e = launch(bad_kernel<true, true>);
+        else if (!ortho && !extra) e = launch(bad_kernel<false, false>);
+        else e = launch(bad_kernel<false, true>);
+        AMOF_HIP_TRY(ctx, e);
+        timing_dom_end(ctx, 1);
+    }
+    timing_end(ctx);
+    int32_t flags[2] = {0, 0};
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
+    if (flags[1]) return fail(ctx, AMOF_ECAPACITY, "an atom has more than %d neighbours within the cutoffs", AMOF_MAX_NEIGHBOURS);
+    return AMOF_OK;
+}
+
+static int bad_check(amof_ctx *ctx, const amof_traj *t, const double *cutoff, const int32_t *triples,
+                     int32_t T, const double *edges, int32_t nb, const void *hist, const void *nang)
+{
+    AMOF_TRY(validate_traj(ctx, t, false));
+    if (!cutoff || T < 0 || (T > 0 && !triples) || !edges || !hist || !nang) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    if (nb <= 0) return fail(ctx, AMOF_EINVAL, "nb must be positive");
+    if (nb > AMOF_MAX_LDS_BINS - 16384) return fail(ctx, AMOF_ECAPACITY, "at most %d angle bins", AMOF_MAX_LDS_BINS - 16384);
+    for (int k = 0; k < nb; k++)
+        if (!(edges[k + 1] > edges[k])) return fail(ctx, AMOF_EINVAL, "edges must increase strictly");
+    for (int k = 0; k < T; k++)
+        for (int c = 0; c < 2; c++)
+            if (triples[2 * k + c] < -1 || triples[2 * k + c] >= t->n_species)
+                return fail(ctx, AMOF_EINVAL, "triple %d names a species out of range", k);
+    return AMOF_OK;
+}
+
+extern "C" int amof_bad_hist_dev(amof_ctx *ctx, const amof_traj *t, const double *cutoff, const int32_t *triples,
+                                 int32_t T, const double *edges, int32_t nb, uint64_t *hist_dev,
+                                 uint64_t *n_angles_dev)
+{
+    if (!ctx) return AMOF_EINVAL;
+    AMOF_TRY(bad_check(ctx, t, cutoff, triples, T, edges, nb, hist_dev, n_angles_dev));
+    if (T == 0) return AMOF_OK;
+    return bad_run(ctx, t, cutoff, triples, T, edges, nb, (unsigned long long *)hist_dev,
+                   (unsigned long long *)n_angles_dev);
+}
+
+extern "C" int amof_bad_hist(amof_ctx *ctx, const amof_traj *t, const double *cutoff, const int32_t *triples,
+                             int32_t T, const double *edges, int32_t nb, uint64_t *hist, uint64_t *n_angles)
+{
+    if (!ctx) return AMOF_EINVAL;
+    AMOF_TRY(bad_check(ctx, t, cutoff, triples, T, edges, nb, hist, n_angles));
+    if (T == 0) return AMOF_OK;
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d_hist, *d_nang;
+    size_t hb = (size_t)T * nb * sizeof(uint64_t), nbts = (size_t)T * sizeof(uint64_t);
+    AMOF_TRY(upload(ctx, SLOT_OUT0, hist, hb, &d_hist));
+    AMOF_TRY(upload(ctx, SLOT_OUT1, n_angles, nbts, &d_nang));
+    int rc = bad_run(ctx, t, cutoff, triples, T, edges, nb, (unsigned long long *)d_hist, (unsigned long long *)d_nang);
+    if (rc) return rc;
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, hb, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(n_angles, d_nang, nbts, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMOF_OK;
+}

@@ -1,0 +1,128 @@
+"""Mean-squared displacement on MI355X (mirror of reference amof/msd.py).
+
+``WindowMsd`` keeps the reference's signatures and ``.data`` schema
+(amof/msd.py:140-268).  Centre-of-mass removal, optional unwrap, wrapped
+frame-to-frame displacements and the per-window sums
+(amof/msd.py:185-205,222-248; amof/trajectory.py:285-303) run in the HIP
+kernels behind ``amof_msd_window``; the host keeps the window arithmetic, the
+reference's normalisation quirk and the formula-weighted total.
+
+Unlike the reference (amof/msd.py:230,237) the caller's frames are NOT
+mutated; ``.data`` is the same.
+"""
+
+import logging
+
+import numpy as np
+import pandas as pd
+
+from . import _hip
+from . import data as _data
+from . import dist as _dist
+from .files import path as _path
+from .frames import pack_trajectory, PackedTrajectory
+
+logger = logging.getLogger(__name__)
+
+
+class Msd(object):
+    """
+    Main class for MSD
+    """
+
+    def write_to_file(self, path_to_output):
+        """path_to_output: where the MSD object will be written"""
+        path_to_output = _path.append_suffix(path_to_output, 'msd')
+        self.data.to_feather(path_to_output)
+
+    @classmethod
+    def from_msd(cls, *args):
+        logger.exception('from_msd is deprecated, use from_file instead')
+
+    @classmethod
+    def from_file(cls, path_to_msd):
+        """constructor of msd class from msd file"""
+        msd_class = cls()
+        msd_class.read_msd_file(path_to_msd)
+        return msd_class
+
+    def read_msd_file(self, path_to_data):
+        """path_to_data: where the MSD object is"""
+        path_to_data = _path.append_suffix(path_to_data, 'msd')
+        self.data = pd.read_feather(path_to_data)
+
+
+class WindowMsd(Msd):
+    """
+    Window MSD
+
+    MSD(m) = 1/N_particles sum_i 1/(N-m) sum_k (r_i(k+m) - r_i(k))^2, with the
+    reference's actual summation range k = 1 .. N-m-1 (amof/msd.py:195-204:
+    time origin 0 is never written but the mean still divides by N-m).
+    Time is expressed in fs.
+    """
+
+    def __init__(self):
+        """default constructor"""
+        self.data = pd.DataFrame({"Time": np.empty([0])})
+
+    @classmethod
+    def from_trajectory(cls, trajectory, delta_time=100, max_time="half", timestep=1, parallel=False,
+                        unwrap=False, device=None, distributed=None):
+        """
+        constructor of msd class
+
+        Args:
+            trajectory: list of ase.Atoms-like frames, or a PackedTrajectory
+            delta_time: int, time between two computed values of the MSD, in fs
+            max_time: int or "half"
+            timestep: int, time between two frames of the trajectory
+            parallel: accepted for compatibility (atoms always run in parallel on the GPU)
+            unwrap: Boolean, unwrap the trajectory before computing the MSD
+        """
+        msd_class = cls()
+        half_time = (len(trajectory) // 2) * timestep
+        if (isinstance(max_time, str) and max_time == "half") or max_time > half_time:
+            max_time = half_time
+        if delta_time < timestep:
+            logger.exception("Delta_time should be larger than timestep")
+        delta_m = delta_time // timestep
+        window = np.arange(0, max_time // timestep, delta_m)
+        time = timestep * window
+        msd_class.compute_msd(trajectory, window, time, parallel, unwrap, device=device, distributed=distributed)
+        return msd_class
+
+    def compute_msd(self, trajectory, window, time, parallel=False, unwrap=False, device=None, distributed=None):
+        """compute the window MSD (reference amof/msd.py:207-268)"""
+        packed = pack_trajectory(trajectory)
+        elements = list(set(packed.numbers))
+        if unwrap == True:  # noqa: E712  (the reference compares with ==)
+            logger.info("Unwrap trajectory before computing msd")
+        logger.info("Start computing msd at %s times on a trajectory of %s frames", len(window), len(packed))
+
+        rank, world = (0, 1) if distributed is False else _dist.world()
+        N, F = packed.n_atoms, len(packed)
+        atom_range = _dist.shard_range(N, rank, world) if world > 1 and distributed != 'local' else (0, N)
+        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        ctx = _hip.get_context(dev)
+        sumsq, kinds = ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
+                                      atom_range=atom_range)
+        if world > 1 and distributed != 'local':
+            sumsq = _dist.all_reduce_sum(sumsq)
+        self.sumsq = sumsq
+        idx = {z: k for k, z in enumerate(kinds)}
+
+        self.data = pd.DataFrame({"Time": time})
+        denom = (F - np.asarray(window)).astype(np.float64)
+        for e in elements:
+            n_e = int((packed.numbers == e).sum())
+            self.data[_data.chemical_symbols[int(e)]] = sumsq[idx[int(e)]] / n_e / denom
+        # formula-weighted total (amof/msd.py:263-268)
+        if isinstance(trajectory, PackedTrajectory):
+            formula_dict = packed.formula_count()
+        else:
+            formula_dict = trajectory[0].symbols.formula._count
+        acc = 0.0
+        for k, v in formula_dict.items():
+            acc = acc + self.data[k].values * v
+        self.data['X'] = acc / sum(formula_dict.values())

@@ -1,0 +1,153 @@
+"""Radial distribution functions on MI355X (mirror of reference amof/rdf.py).
+
+``Rdf`` keeps the reference's signatures and ``.data`` schema
+(amof/rdf.py:28-122).  The per-frame neighbour search + histogramming that the
+reference delegates to ``asap3.analysis.rdf.RadialDistributionFunction``
+(amof/rdf.py:88-93) runs in the HIP kernels behind ``amof_rdf_accumulate``;
+this module keeps the O(bins) host logic: rmax clamp, bin-count arithmetic with
+Python float semantics, asap3-style normalisation, column naming.
+"""
+
+import logging
+
+import numpy as np
+import pandas as pd
+
+from . import _hip
+from . import data as _data
+from . import dist as _dist
+from .files import path as _path
+from .frames import pack_trajectory
+
+logger = logging.getLogger(__name__)
+
+
+def normalize_rdf(hist, ncount, natoms, mean_volume, rmax, nbins):
+    """asap3 ``RadialDistributionFunction.get_rdf`` normalisation ([3P-memory],
+    consumed at amof/rdf.py:96,109):
+
+        g[b] = V * H[b] / (4 pi r_b^2 delta * N * ncount),
+        delta = rmax / nbins, r_b = (b + 1/2) delta
+
+    ``ncount`` = frames * N for the total RDF, frames * N_a for the partial
+    a -> b (partials are normalised with the TOTAL density, so that
+    g_XX = sum_ab (N_a/N) g_ab; corroborated by amof/rdf.py:114,216-227)."""
+    delta = rmax / nbins
+    r = (np.arange(nbins) + 0.5) * delta
+    shell = 4 * np.pi * r * r * delta
+    return np.asarray(hist, dtype=np.float64) * (mean_volume / (natoms * ncount)) / shell
+
+
+class Rdf(object):
+    """
+    Main class for rdf
+    """
+
+    def __init__(self):
+        """default constructor"""
+        self.data = pd.DataFrame({"r": np.empty([0])})
+
+    @classmethod
+    def from_trajectory(cls, trajectory, dr=0.01, rmax='half_cell', device=None, distributed=None):
+        """
+        Constructor of rdf class
+
+        Args:
+            trajectory: list of ase.Atoms-like frames, or a PackedTrajectory
+            dr, rmax: floats in Angstrom
+                If rmax is 'half_cell', half of the minimum cell length over
+                the trajectory is used (reference amof/rdf.py:74-79).
+            device: GPU index (default: LOCAL_RANK or 0)
+            distributed: None -> shard frames over the ranks of an initialised
+                torch.distributed group (every rank holds the whole
+                trajectory); 'local' -> ``trajectory`` already is this rank's
+                own block of frames; False -> single process.
+        """
+        rdf_class = cls()
+        rdf_class.compute_rdf(trajectory, dr, rmax, device=device, distributed=distributed)
+        return rdf_class
+
+    @classmethod
+    def from_rdf(cls, *args):
+        logger.exception('from_rdf is deprecated, use from_file instead')
+
+    @classmethod
+    def from_file(cls, path_to_rdf):
+        """constructor of rdf class from rdf file"""
+        rdf_class = cls()
+        rdf_class.read_rdf_file(path_to_rdf)
+        return rdf_class
+
+    def compute_rdf(self, trajectory, dr, rmax, device=None, distributed=None):
+        """compute rdf from a trajectory (reference amof/rdf.py:67-114)"""
+        packed = pack_trajectory(trajectory)
+        atomic_numbers_unique = list(set(packed.numbers))
+        N_species = len(atomic_numbers_unique)
+        rank, world = (0, 1) if distributed is False else _dist.world()
+
+        # min over ALL frames of the three cell lengths, halved (amof/rdf.py:74)
+        rmax_half_cell = np.min(packed.cell_lengths()) / 2
+        if distributed == 'local' and world > 1:
+            rmax_half_cell = _dist.all_reduce_min(rmax_half_cell)
+        if isinstance(rmax, str) and rmax == 'half_cell':
+            rmax = rmax_half_cell
+        elif rmax > rmax_half_cell:
+            logger.info("Specified rmax %s is larger than half cell; will use half_cell rmax", rmax)
+            rmax = rmax_half_cell
+        rmax = float(rmax)
+
+        logger.info("Start computing rdf for %s frames with dr = %s and rmax = %s", len(packed), dr, rmax)
+        bins = int(rmax // dr)          # Python float floor-division, as the reference (amof/rdf.py:82)
+        r = np.arange(bins) * dr
+        self.data = pd.DataFrame({"r": r})
+        if bins <= 0:
+            raise ValueError("rmax // dr gives no bin")
+
+        F_local = len(packed)
+        if world > 1 and distributed != 'local':
+            frame_range = _dist.shard_range(F_local, rank, world)
+        else:
+            frame_range = (0, F_local)
+        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        ctx = _hip.get_context(dev)
+        hist, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range)
+        n_frames = frame_range[1] - frame_range[0]
+        if world > 1:
+            hist = _dist.all_reduce_sum(hist)
+            tot = _dist.all_reduce_sum(np.array([vol_sum, float(n_frames)]))
+            vol_sum, n_frames = float(tot[0]), int(round(tot[1]))
+        self.hist = hist                      # integer ordered-pair counts [S][S][bins]
+        self.kinds = kinds
+        self.n_frames = n_frames
+        self.rmax = rmax
+
+        natoms = packed.n_atoms
+        mean_volume = vol_sum / n_frames
+        counts = {z: int((packed.numbers == z).sum()) for z in kinds}
+        idx = {z: k for k, z in enumerate(kinds)}
+
+        # Total RDF
+        self.data["X-X"] = normalize_rdf(hist.sum(axis=(0, 1)), n_frames * natoms, natoms, mean_volume, rmax, bins)
+
+        # Partial RDFs (cartesian product of the species, reference order)
+        partial_rdf = [[None for y in atomic_numbers_unique] for x in atomic_numbers_unique]
+        cols = {}
+        for i in range(N_species):
+            for j in range(N_species):
+                za, zb = int(atomic_numbers_unique[i]), int(atomic_numbers_unique[j])
+                xx_str = _data.chemical_symbols[za] + "-" + _data.chemical_symbols[zb]
+                partial_rdf[i][j] = normalize_rdf(hist[idx[za], idx[zb]], n_frames * counts[za], natoms,
+                                                  mean_volume, rmax, bins)
+                cols[xx_str] = partial_rdf[i][j]
+        for i in range(N_species):
+            za = int(atomic_numbers_unique[i])
+            cols[_data.chemical_symbols[za] + "-X"] = sum([partial_rdf[i][j] for j in range(N_species)])
+        self.data = pd.concat([self.data, pd.DataFrame(cols)], axis=1)
+
+    def write_to_file(self, filename):
+        filename = _path.append_suffix(filename, 'rdf')
+        self.data.to_feather(filename)
+
+    def read_rdf_file(self, path_to_data):
+        path_to_data = _path.append_suffix(path_to_data, 'rdf')
+        self.data = pd.read_feather(path_to_data)

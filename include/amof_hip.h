@@ -1,0 +1,167 @@
+/*
+ * amof_hip.h -- C ABI of libamofhip.so: MI355X (gfx950) kernels for aMOF's
+ * per-frame pair-distance hot path (RDF / CN / BAD / window MSD).
+ *
+ * The reference (coudertlab/amof v1.1.0) is pure Python and has no FFI of its
+ * own; the seam this library fills is the set of third-party / numpy call
+ * sites underneath its analysis classes.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference root).  Host Python
+ * (the amof_amd Python package) keeps everything that is O(bins): bin-count arithmetic,
+ * normalisation, column naming, DataFrames.
+ *
+ * Conventions
+ *   - plain C types only; no C++ exceptions cross the boundary; never aborts.
+ *   - return value: 0 = AMOF_OK, negative = error; amof_last_error(ctx) gives
+ *     a human-readable message for the last failing call on that context.
+ *   - buffers are caller-owned; the library keeps no caller pointer after a
+ *     host-output call returns.  "_dev" entry points take caller-owned DEVICE
+ *     output buffers and enqueue work on the context's stream (see
+ *     amof_ctx_set_stream); the caller synchronises.
+ *   - a context is bound to one device and is not thread-safe; distinct
+ *     contexts may be used concurrently.  ctypes releases the GIL during calls.
+ *   - all integer results are exact and independent of launch geometry.
+ */
+#ifndef AMOF_HIP_H
+#define AMOF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMOF_OK 0
+#define AMOF_EINVAL (-1)     /* bad argument */
+#define AMOF_ESINGULAR (-2)  /* singular cell */
+#define AMOF_EANGLE (-3)     /* undefined angle (zero-length bond vector): ASE raises ZeroDivisionError */
+#define AMOF_ENOMEM (-4)     /* host or device allocation failed */
+#define AMOF_EHIP (-5)       /* HIP runtime error (message in amof_last_error) */
+#define AMOF_ECAPACITY (-6)  /* a documented kernel capacity was exceeded */
+#define AMOF_ENODEVICE (-7)  /* no usable GPU */
+
+#define AMOF_ABI_VERSION 1
+
+/* capacities (AMOF_ECAPACITY when exceeded) */
+#define AMOF_MAX_LDS_BINS 36864     /* histogram bins held in LDS per workgroup (u32) */
+#define AMOF_MAX_NEIGHBOURS 32      /* neighbours per centre atom in the BAD kernel */
+#define AMOF_MAX_IMAGES 4096        /* extra periodic images per frame */
+
+typedef struct amof_ctx amof_ctx;
+
+/*
+ * A trajectory as the reference sees it: a list of F frames of the same N atoms
+ * (amof/trajectory.py:27-35; species read from frame 0 only, amof/rdf.py:71).
+ */
+typedef struct amof_traj {
+    const double *pos;      /* [F][N][3] xyz, float64, C-contiguous                  */
+    int32_t pos_on_device;  /* 0: pos is a host pointer; 1: device pointer (resident) */
+    int32_t n_species;      /* S                                                     */
+    const double *cell;     /* HOST [n_cells][3][3], rows = cell vectors (ASE)       */
+    int64_t n_cells;        /* 1 (constant cell) or F                                */
+    int64_t n_frames;       /* F                                                     */
+    int64_t n_atoms;        /* N                                                     */
+    const int32_t *species; /* HOST [N], species index 0..S-1                        */
+    const double *masses;   /* HOST [N]; MSD only (centre of mass), else may be NULL */
+    uint8_t pbc[3];         /* periodic flags per cell vector (ase.Atoms.pbc)        */
+    uint8_t _pad[5];
+} amof_traj;
+
+int amof_abi_version(void);
+
+/* number of visible GPUs (hipGetDeviceCount); 0 when none */
+int amof_device_count(void);
+
+int amof_ctx_create(int device, amof_ctx **out);
+void amof_ctx_destroy(amof_ctx *ctx);
+const char *amof_last_error(const amof_ctx *ctx);
+
+/* Run subsequent work on the caller's hipStream_t (e.g. torch's current
+ * stream).  NULL restores the context's own stream. */
+int amof_ctx_set_stream(amof_ctx *ctx, void *hip_stream);
+int amof_ctx_synchronize(amof_ctx *ctx);
+
+/* Seconds spent inside kernels of the last call, measured with HIP events on
+ * the context's stream around the dominant kernel's launches:
+ * which = 0 total, 1 dominant kernel only. Returns < 0 if unavailable. */
+double amof_last_kernel_seconds(const amof_ctx *ctx, int which);
+/* number of launches of the dominant kernel in the last call */
+int64_t amof_last_kernel_launches(const amof_ctx *ctx);
+
+/*
+ * RDF histogram accumulation.
+ * Replaces asap3.analysis.rdf.RadialDistributionFunction(atoms, rMax, nBins)
+ * + .update() per frame, as driven by amof/rdf.py:88-93 (and :181-185).
+ *   hist[(a*S + b)*nbins + k] += number of ORDERED pairs (i of species a,
+ *       j of species b, any periodic image, zero-shift self pair excluded)
+ *       with bin k = (int)(r / (rmax/nbins)), r < rmax
+ *   *volume_sum += sum over frames of the cell volume (asap3 keeps it for
+ *       the normalisation done by get_rdf, amof/rdf.py:96,109)
+ * The total histogram is the sum over (a,b).  hist is accumulated into
+ * (+=), so the caller zeroes it first.
+ */
+int amof_rdf_accumulate(amof_ctx *ctx, const amof_traj *traj, double rmax, int32_t nbins,
+                        uint64_t *hist /* host [S*S][nbins] */, double *volume_sum);
+int amof_rdf_accumulate_dev(amof_ctx *ctx, const amof_traj *traj, double rmax, int32_t nbins,
+                            uint64_t *hist_dev /* device [S*S][nbins] */, double *volume_sum);
+
+/*
+ * Coordination-number counts.
+ * Replaces amof.atom.get_neighborlist (amof/atom.py:72-87, i.e.
+ * ase.neighborlist.neighbor_list('ij', atoms, {(Z1,Z2): rc})) + the counting
+ * loop of amof/cn.py:67-73.
+ *   cutoff[a*S + b]: per-species-pair cutoff (symmetric); 0 = never neighbours.
+ *       Neighbour test is strict: sqrt(d2) < rc, every periodic image counts.
+ *   sets[s] = (A, B): sums[f*n_sets + s] = sum over atoms i of species A of
+ *       the number of neighbours of species B (the mean is sums / N_A).
+ *   per_atom (optional, may be NULL) [F][n_sets][N]: that count per atom,
+ *       -1 where the atom is not of species A.
+ */
+int amof_cn_count(amof_ctx *ctx, const amof_traj *traj, const double *cutoff /* [S][S] */,
+                  const int32_t *sets /* [n_sets][2] */, int32_t n_sets,
+                  int64_t *sums /* host [F][n_sets] */, int32_t *per_atom /* host or NULL */);
+
+/*
+ * Bond-angle histograms.
+ * Replaces amof.atom.get_neighborlist + ase.Atoms.get_angles(idx, mic=True) +
+ * numpy.histogram(bins=edges) as driven by amof/bad.py:70-114,154-160.
+ *   triples[t] = (A, B): centre species A, neighbour species B; -1 = "X" (any).
+ *   edges[nb+1]: histogram edges in degrees (host builds arange(bins+2)*dtheta,
+ *       amof/bad.py:143); bin k holds edges[k] <= x < edges[k+1], last bin
+ *       right-closed, values outside are dropped (numpy.histogram).
+ *   hist[t*nb + k] += counts;  n_angles[t] += number of angles found
+ * Returns AMOF_EANGLE for a zero-length bond vector (ASE: ZeroDivisionError).
+ */
+int amof_bad_hist(amof_ctx *ctx, const amof_traj *traj, const double *cutoff /* [S][S] */,
+                  const int32_t *triples /* [T][2] */, int32_t n_triples,
+                  const double *edges /* [nb+1] */, int32_t nb,
+                  uint64_t *hist /* host [T][nb] */, uint64_t *n_angles /* host [T] */);
+int amof_bad_hist_dev(amof_ctx *ctx, const amof_traj *traj, const double *cutoff,
+                      const int32_t *triples, int32_t n_triples, const double *edges, int32_t nb,
+                      uint64_t *hist_dev /* device [T][nb] */, uint64_t *n_angles_dev /* device [T] */);
+
+/*
+ * Window-averaged MSD partial sums.
+ * Replaces amof.trajectory.get_delta_pos (amof/trajectory.py:285-303, i.e.
+ * ase.geometry.wrap_positions(d, cell[k], center=0)) + the per-window loop
+ * WindowMsd.compute_msd_of_m (amof/msd.py:185-205) + the centre-of-mass
+ * removal and optional unwrap of amof/msd.py:222-237.
+ *   windows[w] = m (frames); 0 <= m < F
+ *   sumsq[s*W + w] = sum over atoms i of species s in [atom_begin, atom_end)
+ *                    of sum_{k=1}^{F-m-1} |u_i(k+m) - u_i(k)|^2
+ *       where u_i is the running sum of wrapped frame-to-frame displacements.
+ *       (The reference never evaluates time origin k=0 and divides by F-m:
+ *        MSD_s(m) = sumsq / N_s / (F-m); the host applies it.)
+ *   unwrap != 0: rebuild unwrapped positions first (amof/msd.py:222-230).
+ *   remove_com != 0: subtract the mass-weighted centre of mass of ALL atoms
+ *       per frame (amof/msd.py:235-237; always on in the reference).
+ * [atom_begin, atom_end) lets several devices split the atoms; partial sums
+ * add up exactly like the full call up to float64 summation order.
+ */
+int amof_msd_window(amof_ctx *ctx, const amof_traj *traj, const int32_t *windows, int32_t n_windows,
+                    int32_t unwrap, int32_t remove_com, int64_t atom_begin, int64_t atom_end,
+                    double *sumsq /* host [S][W] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMOF_HIP_H */

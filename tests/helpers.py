@@ -1,0 +1,62 @@
+"""Shared builders for the parity tests (seeded synthetic trajectories)."""
+
+import os
+
+import numpy as np
+
+from amof_amd.frames import Frame, PackedTrajectory
+from amof_amd.io import read_extxyz
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def species_of(numbers):
+    kinds = sorted(set(int(z) for z in numbers))
+    return kinds, np.array([kinds.index(int(z)) for z in numbers], dtype=np.int32)
+
+
+def zif4_frame():
+    return read_extxyz(os.path.join(GOLDEN, "ZIF-4.xyz"), 0)
+
+
+def replicate(frame, reps):
+    """replicate a frame reps = (nx, ny, nz) times along its cell vectors"""
+    pos, num = [], []
+    for a in range(reps[0]):
+        for b in range(reps[1]):
+            for c in range(reps[2]):
+                pos.append(frame.positions + a * frame.cell[0] + b * frame.cell[1] + c * frame.cell[2])
+                num.append(frame.numbers)
+    cell = frame.cell * np.array(reps)[:, None]
+    return Frame(np.concatenate(num), np.concatenate(pos), cell, frame.pbc)
+
+
+def random_walk(base, F, sigma, seed, wrap=True, cell_jitter=0.0, ortho=False):
+    """PackedTrajectory: base + cumulative Gaussian steps, wrapped into the cell"""
+    rng = np.random.default_rng(seed)
+    cell0 = np.diag(np.diag(base.cell)) if ortho else base.cell.copy()
+    pos = base.positions.copy()
+    P = np.empty((F,) + pos.shape)
+    C = np.empty((F, 3, 3))
+    for k in range(F):
+        cell = cell0 * (1.0 + cell_jitter * rng.normal()) if cell_jitter else cell0
+        p = pos
+        if wrap:
+            s = np.linalg.solve(cell.T, p.T).T
+            s -= np.floor(s)
+            p = s @ cell
+        P[k] = p
+        C[k] = cell
+        pos = pos + rng.normal(scale=sigma, size=pos.shape)
+    if not cell_jitter:
+        C = C[:1]
+    return PackedTrajectory(P, C, base.numbers, pbc=base.pbc)
+
+
+def random_gas(N, cell, numbers, seed, F=1):
+    rng = np.random.default_rng(seed)
+    cell = np.asarray(cell, dtype=float)
+    if cell.shape == (3,):
+        cell = np.diag(cell)
+    P = rng.uniform(-0.3, 1.3, size=(F, N, 3)) @ cell
+    return PackedTrajectory(P, cell, numbers)
