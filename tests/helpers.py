@@ -58,5 +58,6 @@ def random_gas(N, cell, numbers, seed, F=1):
     cell = np.asarray(cell, dtype=float)
     if cell.shape == (3,):
         cell = np.diag(cell)
-    P = rng.uniform(-0.3, 1.3, size=(F, N, 3)) @ cell
+    # uniform in the cell, then displaced by whole lattice vectors (still uniform modulo the cell)
+    P = (rng.uniform(0, 1, size=(F, N, 3)) + rng.integers(-1, 2, size=(F, N, 3))) @ cell
     return PackedTrajectory(P, cell, numbers)

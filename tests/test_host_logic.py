@@ -1,0 +1,133 @@
+"""Host-side logic and the C-ABI surface (no GPU needed)."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import amof_amd
+from amof_amd import _hip, atom, data, dist
+from amof_amd.files.path import append_suffix
+from amof_amd.frames import Frame, PackedTrajectory, pack_trajectory
+from tests import helpers as H
+from tests.conftest import ROOT
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _hip.load_library()
+    header = open(os.path.join(ROOT, "include", "amof_hip.h")).read()
+    declared = set(re.findall(r"\b(amof_[a-z_]+)\s*\(", header))
+    assert declared == set(_hip.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.amof_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    # 8 + 4 + 4 + 8 + 8*3 + 8 + 8 + 3 + 5 = 72 bytes, 8-byte aligned
+    assert ctypes.sizeof(_hip.AmofTraj) == 72
+    assert _hip.AmofTraj.cell.offset == 16 and _hip.AmofTraj.species.offset == 48
+    assert _hip.AmofTraj.pbc.offset == 64
+
+
+def test_product_fails_loudly_without_gpu():
+    if _hip.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no GPU"):
+        _hip.Context(0)
+    from amof_amd.rdf import Rdf
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Rdf.from_trajectory(H.random_walk(H.zif4_frame(), 2, 0.05, 0))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "amof_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "libamof_oracle" not in src, f
+
+
+def test_append_suffix():
+    assert str(append_suffix("a/b", "rdf")) == "a/b.rdf"
+    assert str(append_suffix("a/b.rdf", ".rdf")) == "a/b.rdf"
+    assert str(append_suffix("a/b.msd", "rdf")) == "a/b.msd.rdf"
+    assert str(append_suffix("x", "")) == "x"
+
+
+def test_format_cutoff_and_matrix():
+    d = atom.format_cutoff({'Zn-N': 2.5, 'N-Zn': 3.0, 'C-H': 1.2})
+    assert d == {(30, 7): 2.5, (7, 30): 3.0, (6, 1): 1.2}
+    assert atom.format_cutoff({'Zn-N': 2.5}, sort_pair=True) == {(7, 30): 2.5}
+    m = atom.cutoff_matrix(d, [1, 6, 7, 30])
+    assert m[3, 2] == m[2, 3] == 3.0 and m[0, 1] == m[1, 0] == 1.2 and m[0, 0] == 0
+    assert atom.cutoff_matrix({(8, 1): 1.0}, [1, 6]).sum() == 0     # species absent
+
+
+def test_element_tables():
+    assert data.chemical_symbols[0] == 'X' and data.chemical_symbols[30] == 'Zn'
+    assert data.atomic_numbers['N'] == 7 and len(data.chemical_symbols) == 119
+    assert data.atomic_masses[1] == pytest.approx(1.008) and data.atomic_masses[30] == pytest.approx(65.38)
+
+
+def test_bin_count_arithmetic_is_python_floor_division():
+    # SURVEY TL;DR: never compute bin counts in C
+    assert int(10 // 0.01) == 999 and int(7.5 // 0.01) == 749 and int(180 // 0.05) == 3599
+    assert int(180 // 0.5) == 360
+
+
+def test_frame_api(zif4):
+    f = zif4
+    assert len(f) == 272 and f.get_global_number_of_atoms() == 272
+    assert f.get_volume() == pytest.approx(4380.4858, abs=1e-3)
+    assert atom.get_number_density(f) == pytest.approx(0.0620936, abs=1e-6)
+    assert f.symbols.formula._count == {'C': 96, 'H': 96, 'N': 64, 'Zn': 16}
+    com = f.get_center_of_mass()
+    g = f.copy(); g.translate(-com)
+    np.testing.assert_allclose(g.get_center_of_mass(), 0, atol=1e-12)
+    assert atom.select_species_positions(f, 30).shape == (16, 3)
+    assert sorted(int(z) for z in atom.get_atomic_numbers_unique(f)) == [1, 6, 7, 30]
+    la = f.get_cell_lengths_and_angles()
+    assert la[0] == pytest.approx(15.4231) and la[3] == pytest.approx(90.0, abs=1e-2)
+
+
+def test_pack_trajectory(zif4):
+    frames = [zif4.copy() for _ in range(3)]
+    frames[1].positions += 0.1
+    p = pack_trajectory(frames)
+    assert p.pos.shape == (3, 272, 3) and p.cell.shape == (1, 3, 3) and p.n_frames == 3
+    assert pack_trajectory(p) is p
+    frames[2].cell = frames[2].cell * 1.01
+    assert pack_trajectory(frames).cell.shape == (3, 3, 3)
+    with pytest.raises(ValueError):
+        pack_trajectory([])
+    with pytest.raises(ValueError):
+        PackedTrajectory(np.zeros((2, 3, 2)), np.eye(3), [1, 1, 1])
+    kinds, sp = _hip.species_index(p.numbers)
+    assert kinds == [1, 6, 7, 30] and sp.dtype == np.int32 and sp.max() == 3
+
+
+def test_normalize_rdf_formula():
+    from amof_amd.rdf import normalize_rdf
+    nb, rmax, N, F, V = 10, 5.0, 100, 4, 1000.0
+    h = np.arange(nb) * 7
+    g = normalize_rdf(h, F * N, N, V, rmax, nb)
+    d = rmax / nb
+    r = (np.arange(nb) + 0.5) * d
+    np.testing.assert_allclose(g, V * h / (4 * np.pi * r ** 2 * d * N * F * N), rtol=1e-15)
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 5000, 9792):
+        for w in (1, 2, 3, 8):
+            r = [dist.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    assert dist.world() == (0, 1)
+    x = np.arange(4, dtype=np.uint64)
+    assert dist.all_reduce_sum(x) is x
