@@ -1,0 +1,130 @@
+"""Class-level parity on the GPU: the drop-in classes against the DataFrames
+the reference's own drivers produced (tests/golden/reference_e2e_*.npz), and
+feather round trips."""
+
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from amof_amd.frames import Frame, PackedTrajectory
+from amof_amd.rdf import Rdf
+from amof_amd.msd import WindowMsd
+from amof_amd.bad import Bad
+from amof_amd.cn import CoordinationNumber
+from tests import helpers as H
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6   # north_star: floats within 1e-6 relative
+
+
+def _frames(g):
+    cell = g["cell"]
+    return [Frame(g["numbers"], g["pos"][k], cell[k if len(cell) > 1 else 0]) for k in range(len(g["pos"]))]
+
+
+def _check_df(df, g, rtol=RTOL, atol=1e-12):
+    assert list(df.columns) == [str(c) for c in g["columns"]]
+    np.testing.assert_allclose(df.values.astype(float), g["values"], rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", ["zif4_default", "zif4_dr0p05_rmax6"])
+@pytest.mark.parametrize("packed", [False, True])
+def test_rdf_matches_reference_dataframe(name, packed):
+    g = np.load(os.path.join(GOLDEN, "reference_e2e_rdf_%s.npz" % name))
+    rmax = str(g["rmax"]) if g["rmax"].dtype.kind == "U" else float(g["rmax"])
+    traj = _frames(g)
+    if packed:
+        traj = PackedTrajectory(g["pos"], g["cell"], g["numbers"])
+    rdf = Rdf.from_trajectory(traj, dr=float(g["dr"]), rmax=rmax)
+    _check_df(rdf.data, g)
+    # integer sum rule and symmetry of the raw counts
+    assert np.array_equal(rdf.hist, rdf.hist.transpose(1, 0, 2))
+
+
+@pytest.mark.parametrize("name", ["ortho_raw", "ortho_unwrap", "tri_raw", "tri_unwrap", "zif4_rattle"])
+def test_msd_matches_reference_dataframe(name):
+    g = np.load(os.path.join(GOLDEN, "reference_e2e_msd_%s.npz" % name))
+    frames = _frames(g)
+    before = [f.positions.copy() for f in frames]
+    msd = WindowMsd.from_trajectory(frames, delta_time=int(g["delta_time"]), timestep=int(g["timestep"]),
+                                    unwrap=bool(g["unwrap"]))
+    _check_df(msd.data, g, rtol=1e-9)
+    for f, b in zip(frames, before):           # unlike the reference, inputs are not mutated
+        assert np.array_equal(f.positions, b)
+
+
+def test_cn_matches_reference_dataframe():
+    g = np.load(os.path.join(GOLDEN, "reference_e2e_cn_zif4.npz"))
+    cn = CoordinationNumber.from_trajectory(_frames(g), json.loads(str(g["cutoffs"])),
+                                            delta_Step=int(g["delta_Step"]), first_frame=int(g["first_frame"]))
+    assert list(cn.data.columns) == [str(c) for c in g["columns"]]
+    assert np.array_equal(cn.data.values.astype(float), g["values"])      # integer counts / N_A: exact
+
+
+@pytest.mark.parametrize("tag", ["0p05", "0p5"])
+def test_bad_matches_reference_dataframe(tag):
+    g = np.load(os.path.join(GOLDEN, "reference_e2e_bad_zif4_dtheta%s.npz" % tag))
+    bad = Bad.from_trajectory(_frames(g), json.loads(str(g["cutoffs"])), dtheta=float(g["dtheta"]))
+    _check_df(bad.data, g, rtol=1e-12, atol=0)
+    assert "Zn-N-Zn" not in bad.data.columns                   # empty columns are omitted (amof/bad.py:159)
+
+
+def test_bad_with_all_species_uses_X(zif4):
+    packed = H.random_walk(zif4, 2, 0.02, 5)
+    cut = {'Zn-N': 2.5, 'C-H': 1.3, 'C-N': 1.6}
+    bad = Bad.from_trajectory(packed, cut, dtheta=0.5)
+    assert "X-X-X" in bad.data.columns and "X-Zn-X" in bad.data.columns and "N-Zn-N" in bad.data.columns
+    # every Zn neighbour is an N here, so X-Zn-X == N-Zn-N
+    assert np.array_equal(bad.data["X-Zn-X"].values, bad.data["N-Zn-N"].values)
+    w = np.diff(np.arange(int(180 // 0.5) + 2) * 0.5)
+    assert (bad.data["X-X-X"].values * w).sum() == pytest.approx(1.0, rel=1e-12)
+
+
+def test_feather_round_trips(tmp_path, zif4):
+    pytest.importorskip("pyarrow")       # feather backend; the reference uses it too (amof/rdf.py:118)
+    packed = H.random_walk(zif4, 6, 0.05, 1)
+    rdf = Rdf.from_trajectory(packed, dr=0.05)
+    rdf.write_to_file(tmp_path / "a")
+    assert (tmp_path / "a.rdf").exists()
+    back = Rdf.from_file(tmp_path / "a")
+    assert np.allclose(back.data, rdf.data) and list(back.data.columns) == list(rdf.data.columns)
+    msd = WindowMsd.from_trajectory(packed, delta_time=1, timestep=1)
+    msd.write_to_file(tmp_path / "m.msd")
+    assert np.array_equal(WindowMsd.from_file(tmp_path / "m").data.values, msd.data.values)
+    cn = CoordinationNumber.from_trajectory(packed, {'Zn-N': 2.5})
+    cn.write_to_file(tmp_path / "c")
+    assert np.array_equal(CoordinationNumber.from_file(tmp_path / "c").data.values, cn.data.values)
+    bad = Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=1.0)
+    bad.write_to_file(tmp_path / "b")
+    assert np.array_equal(Bad.from_file(tmp_path / "b").data.values, bad.data.values)
+    assert list(cn.data.columns) == ["Step", "Zn-N"] and (cn.data["Zn-N"] == 4.0).all()
+
+
+def test_sum_rules_on_dataframe(zif4):
+    packed = H.random_walk(zif4, 5, 0.05, 2)
+    rdf = Rdf.from_trajectory(packed)
+    d = rdf.data
+    counts = packed.formula_count()
+    N = packed.n_atoms
+    # 'A-X' = sum_j g_Aj  and  g_XX = sum_a (N_a / N) g_aX
+    for a in counts:
+        np.testing.assert_allclose(d[a + "-X"], sum(d[a + "-" + b] for b in counts), rtol=1e-13)
+    np.testing.assert_allclose(d["X-X"], sum(counts[a] / N * d[a + "-X"] for a in counts), rtol=1e-12)
+    assert len(d) == int(rdf.rmax // 0.01) and d["r"][1] == 0.01
+
+
+def test_torch_resident_trajectory_matches_host(zif4):
+    import torch
+    packed = H.random_walk(zif4, 8, 0.05, 3)
+    dev = PackedTrajectory(torch.tensor(packed.pos, device="cuda:0"), packed.cell, packed.numbers)
+    a = Rdf.from_trajectory(packed).hist
+    b = Rdf.from_trajectory(dev).hist
+    assert np.array_equal(a, b)
+    m1 = WindowMsd.from_trajectory(packed, delta_time=1, timestep=1).data.values
+    m2 = WindowMsd.from_trajectory(dev, delta_time=1, timestep=1).data.values
+    assert np.array_equal(m1, m2)                 # same kernels, same order: bitwise

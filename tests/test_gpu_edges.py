@@ -1,0 +1,189 @@
+"""Edge cases and size-independent properties of the HIP path (GPU)."""
+
+import numpy as np
+import pytest
+
+from amof_amd import _hip
+from amof_amd.frames import PackedTrajectory
+from amof_amd.rdf import Rdf
+from amof_amd.msd import WindowMsd
+from oracle import clib, numpy_oracle as no
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_rdf(packed, rmax, nb):
+    kinds, sp = H.species_of(packed.numbers)
+    return clib.rdf_hist(packed.pos_host(), packed.cell, sp, len(kinds), rmax, nb, pbc=packed.pbc)[0]
+
+
+def test_sc_lattice_and_exact_half_cell(hip_ctx):
+    # 216-atom simple-cubic KAT of BASELINE cfg1: atoms exactly L/2 apart are NOT counted (strict <)
+    a, n = 2.5, 6
+    g = np.arange(n) * a
+    pos = np.array([[x, y, z] for x in g for y in g for z in g], dtype=float)
+    idx = np.array([[i, j, k] for i in range(n) for j in range(n) for k in range(n)])
+    numbers = np.where(idx.sum(axis=1) % 2 == 0, 11, 17)
+    packed = PackedTrajectory(pos[None], np.diag([n * a] * 3), numbers)
+    rdf = Rdf.from_trajectory(packed)
+    assert rdf.rmax == 7.5 and len(rdf.data) == 749
+    assert np.array_equal(rdf.hist, _oracle_rdf(packed, 7.5, 749))
+    tot = rdf.hist.sum(axis=(0, 1))
+    # lattice vectors with |v| < 3a: 6 + 12 + 8 + 6 + 24 + 24 + 12 (k = 1,2,3,4,5,6,8); k = 9 is |v| = L/2: excluded
+    assert tot.sum() == (6 + 12 + 8 + 6 + 24 + 24 + 12) * 216
+
+
+@pytest.mark.parametrize("n_atoms", [1, 2, 63, 64, 65, 255, 256, 257, 513])
+def test_ragged_tile_sizes(hip_ctx, n_atoms):
+    rng = np.random.default_rng(n_atoms)
+    numbers = rng.choice([1, 8, 14], size=n_atoms)
+    packed = H.random_gas(n_atoms, [9.0, 10.0, 11.0], numbers, n_atoms, F=3)
+    h, _, _ = hip_ctx.rdf_accumulate(packed, 4.5, 450)
+    assert np.array_equal(h, _oracle_rdf(packed, 4.5, 450))
+
+
+def test_empty_inputs(hip_ctx):
+    z = H.zif4_frame()
+    empty = PackedTrajectory(np.zeros((0, 272, 3)), z.cell, z.numbers)
+    h, vol, _ = hip_ctx.rdf_accumulate(empty, 5.0, 50)
+    assert h.sum() == 0 and vol == 0.0
+    one = H.random_walk(z, 1, 0.0, 0)
+    s, _ = hip_ctx.msd_window(one, [0])
+    assert (s == 0).all()
+    sums = hip_ctx.cn_count(one, np.zeros((4, 4)), [(0, 1)])
+    assert sums.shape == (1, 1) and sums[0, 0] == 0
+
+
+def test_argument_errors(hip_ctx):
+    z = H.random_walk(H.zif4_frame(), 2, 0.01, 0)
+    with pytest.raises(ValueError):
+        hip_ctx.rdf_accumulate(z, -1.0, 10)
+    with pytest.raises(ValueError):
+        hip_ctx.rdf_accumulate(z, 5.0, 0)
+    with pytest.raises(ValueError):
+        hip_ctx.msd_window(z, [5])                        # window >= F
+    bad_cell = PackedTrajectory(z.pos, np.zeros((3, 3)), z.numbers)
+    with pytest.raises(_hip.AmofError) as e:
+        hip_ctx.rdf_accumulate(bad_cell, 5.0, 10)
+    assert e.value.code == _hip.AMOF_ESINGULAR
+    with pytest.raises(ValueError):
+        hip_ctx.cn_count(z, np.array([[0, 1.0], [2.0, 0]]).repeat(2, 0).repeat(2, 1), [(0, 1)])   # asymmetric
+
+
+def test_undefined_angle_raises_like_ase(hip_ctx):
+    pos = np.array([[[1.0, 1, 1], [2.0, 1, 1], [1.0, 1, 1]]])
+    packed = PackedTrajectory(pos, np.diag([20.0, 20, 20]), [30, 7, 7])
+    rcm = np.array([[0, 1.5], [1.5, 0]])
+    with pytest.raises(ZeroDivisionError):
+        hip_ctx.bad_hist(packed, rcm, [(1, 0)], np.arange(181.0))
+
+
+def test_neighbour_capacity_error(hip_ctx):
+    packed = H.random_gas(200, [6.0, 6.0, 6.0], np.ones(200, int), 5)
+    with pytest.raises(_hip.AmofError) as e:
+        hip_ctx.bad_hist(packed, [[2.9]], [(0, 0)], np.arange(181.0))
+    assert e.value.code == _hip.AMOF_ECAPACITY
+
+
+def test_many_bins_uses_global_histogram_path(hip_ctx):
+    packed = H.random_walk(H.zif4_frame(), 2, 0.05, 9)
+    nb = _hip.load_library() and 40000                     # > AMOF_MAX_LDS_BINS
+    h, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, nb)
+    assert np.array_equal(h, _oracle_rdf(packed, 7.0, nb))
+
+
+def test_non_periodic_axis(hip_ctx):
+    packed = H.random_gas(150, [8.0, 9.0, 10.0], np.array([1, 8] * 75), 4, F=2)
+    packed.pbc = np.array([True, False, True])
+    h, _, _ = hip_ctx.rdf_accumulate(packed, 4.0, 200)
+    assert np.array_equal(h, _oracle_rdf(packed, 4.0, 200))
+    kinds, sp = H.species_of(packed.numbers)
+    rcm = np.array([[0, 1.9], [1.9, 1.5]])
+    sets = [(0, 1), (1, 0), (1, 1)]
+    assert np.array_equal(hip_ctx.cn_count(packed, rcm, sets),
+                          clib.cn_counts(packed.pos, packed.cell, sp, 2, rcm, sets, pbc=packed.pbc))
+
+
+def test_small_skewed_cell_counts_images(hip_ctx):
+    cell = np.array([[4.0, 0, 0], [2.5, 3.5, 0], [1.0, 1.5, 3.0]])
+    rng = np.random.default_rng(12)
+    N = 40
+    packed = PackedTrajectory((rng.uniform(-1, 2, (3, N, 3))) @ cell, cell, rng.choice([6, 7], N))
+    for rmax, nb in [(2.0, 100), (5.5, 275)]:             # 5.5 > every perpendicular height
+        h, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        assert np.array_equal(h, _oracle_rdf(packed, rmax, nb))
+    kinds, sp = H.species_of(packed.numbers)
+    rcm = np.array([[3.2, 2.1], [2.1, 0.0]])
+    sets = [(0, 0), (0, 1), (1, 0)]
+    s_gpu, pa_gpu = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+    s_cpu, pa_cpu = clib.cn_counts(packed.pos, packed.cell, sp, 2, rcm, sets, per_atom=True)
+    assert np.array_equal(s_gpu, s_cpu) and np.array_equal(pa_gpu, pa_cpu)
+
+
+def test_permutation_and_frame_order_invariance(hip_ctx):
+    packed = H.random_walk(H.zif4_frame(), 6, 0.05, 13, cell_jitter=0.005)
+    rng = np.random.default_rng(0)
+    h0, v0, _ = hip_ctx.rdf_accumulate(packed, 7.0, 350)
+    pa = rng.permutation(packed.n_atoms)
+    pf = rng.permutation(packed.n_frames)
+    shuffled = PackedTrajectory(packed.pos[pf][:, pa], packed.cell[pf], packed.numbers[pa])
+    h1, v1, _ = hip_ctx.rdf_accumulate(shuffled, 7.0, 350)
+    assert np.array_equal(h0, h1)
+    # linearity in frames: hist(A + B) = hist(A) + hist(B)
+    a, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, 350, frame_range=(0, 2))
+    b, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, 350, frame_range=(2, 6))
+    assert np.array_equal(a + b, h0)
+    # idempotence: same call twice gives the same integers
+    assert np.array_equal(hip_ctx.rdf_accumulate(packed, 7.0, 350)[0], h0)
+
+
+def test_msd_atom_sharding_adds_up(hip_ctx):
+    packed = H.random_walk(H.zif4_frame(), 30, 0.2, 14)
+    w = np.arange(0, 15, 2)
+    full, _ = hip_ctx.msd_window(packed, w)
+    parts = sum(hip_ctx.msd_window(packed, w, atom_range=r)[0] for r in [(0, 100), (100, 101), (101, 272)])
+    np.testing.assert_allclose(parts, full, rtol=1e-13)
+
+
+def test_msd_changing_cell_and_long_windows(hip_ctx):
+    packed = H.random_walk(H.zif4_frame(), 70, 0.3, 15, cell_jitter=0.004)
+    window, _ = no.msd_window_setup(70, delta_time=1, timestep=1)
+    for unwrap in (False, True):
+        sumsq, kinds = hip_ctx.msd_window(packed, window, unwrap=unwrap)
+        elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window,
+                                           unwrap=unwrap)
+        for e, r in zip(elements, ref):
+            got = sumsq[kinds.index(int(e))] / (packed.numbers == e).sum() / (70 - window)
+            np.testing.assert_allclose(got, r, rtol=1e-9, atol=1e-12)
+
+
+def test_msd_frame_capacity_error(hip_ctx):
+    z = H.zif4_frame()
+    big = PackedTrajectory(np.zeros((20000, 4, 3)) + 1.0, z.cell, [1, 1, 8, 8])
+    with pytest.raises(_hip.AmofError) as e:
+        hip_ctx.msd_window(big, [0, 1])
+    assert e.value.code == _hip.AMOF_ECAPACITY
+
+
+def test_headline_shape_properties(hip_ctx):
+    """cfg3-sized frames (9792 atoms): oracle on 1 frame, properties on more."""
+    base = H.replicate(H.zif4_frame(), (3, 3, 4))
+    packed = H.random_walk(base, 6, 0.05, 16, ortho=True)
+    rdf = Rdf.from_trajectory(packed)
+    assert len(rdf.data) == 2310 and packed.n_atoms == 9792
+    one = PackedTrajectory(packed.pos[:1], packed.cell, packed.numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    h_cpu, _ = clib.rdf_hist(one.pos, one.cell, sp, 4, rdf.rmax, 2310, cell_list=True)
+    h_gpu, _, _ = hip_ctx.rdf_accumulate(one, rdf.rmax, 2310)
+    assert np.array_equal(h_gpu, h_cpu)
+    # symmetry + checksum of checksums: per-frame histograms add up to the trajectory's
+    acc = sum(hip_ctx.rdf_accumulate(packed, rdf.rmax, 2310, frame_range=(k, k + 1))[0] for k in range(6))
+    assert np.array_equal(acc, rdf.hist) and np.array_equal(rdf.hist, rdf.hist.transpose(1, 0, 2))
+    # MSD vs the vectorised oracle at full width
+    msd = WindowMsd.from_trajectory(packed, delta_time=1, timestep=1)
+    window, _ = no.msd_window_setup(6, 1, "half", 1)
+    el, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window)
+    from amof_amd import data as eldata
+    for e, r in zip(el, ref):
+        np.testing.assert_allclose(msd.data[eldata.chemical_symbols[int(e)]].values, r, rtol=1e-9, atol=1e-12)
