@@ -14,7 +14,7 @@ import numpy as np
 from .frames import PackedTrajectory, _is_torch_tensor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libamofhip.so")
+LIB_PATH = os.environ.get("AMOF_HIP_LIB") or os.path.join(_HERE, "csrc", "libamofhip.so")
 
 AMOF_OK = 0
 AMOF_EINVAL = -1

@@ -12,6 +12,8 @@
 // per frame chunk.  Nothing but the 24*N bytes of a frame is read from HBM per
 // frame; every frame is re-read ~2*ntiles times from L2, never from HBM.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -177,6 +179,257 @@ __global__ __launch_bounds__(RDF_TILE) void rdf_tile_kernel_global(RdfArgs a)
     }
 }
 
+// --------------------------------------------------------------------------
+// Fast path (fully periodic cells whose cutoff needs no extra images).
+//
+// quantize_kernel folds every atom into the cell once per frame and stores its
+// fractional coordinates as 32-bit fixed point, species-sorted (16 B / atom).
+// In the pair loop the minimum image is then free -- the u32 difference wraps --
+// and an f32 candidate bin q~ = sqrt(d2~)/dr is accepted only when it is
+// provably the canonical one:  |q~ - q| <= g  with
+//     g = nbins * 1e-6  +  2 * quant / dr,   quant = 2^-31 * (|c0|+|c1|+|c2|)
+// (f32 chain: cvt, scale, 3 squares/fma, v_sqrt_f32 <= 1 ulp, scale: relative
+// error < 5.1e-7 on q; the fixed-point grid moves a distance by < quant).  A
+// lane whose q~ lies within g of an integer (or of nbins) recomputes the pair
+// with the canonical f64 arithmetic and exact sqrt/divide.  Where the two
+// disagree on the periodic image (|s_k| ~ 1/2) both distances are >= rmax(1-2e-7),
+// i.e. inside the guard of nbins, so the slow path decides those too.
+struct QAtom {
+    uint32_t ux, uy, uz, idx;
+};
+
+__global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict__ pos,
+                                                       const double *__restrict__ geom, int n_cells,
+                                                       const int32_t *__restrict__ perm, int64_t N, int f0,
+                                                       int nf, QAtom *__restrict__ Q, int32_t *flag)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int fl = blockIdx.y;
+    if (k >= N || fl >= nf) return;
+    const int f = f0 + fl;
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const int64_t a = perm[k];
+    const double *__restrict__ p = pos + ((size_t)f * N + a) * 3;
+    const double x = p[0], y = p[1], z = p[2];
+    uint32_t u[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double s = fma(z, g[15 + c], fma(y, g[12 + c], x * g[9 + c]));
+        if (!(fabs(s) < 1.0e4)) *flag = 1;   // absurdly far from the cell (or NaN): caller falls back
+        s = s - floor(s);
+        double t = s * 4294967296.0;
+        u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    }
+    QAtom q;
+    q.ux = u[0]; q.uy = u[1]; q.uz = u[2]; q.idx = (uint32_t)a;
+    Q[(size_t)fl * N + k] = q;
+}
+
+struct RdfFastArgs {
+    RdfArgs a;
+    const QAtom *Q;     // [nf][N] species-sorted
+    int32_t f_base;     // first frame of this batch
+    int32_t nf;         // frames in this batch
+    float scale[9];     // ORTHO: scale[0..2] = L_k * 2^-32 / dr ; else cell[k][c] * 2^-32 / dr (row-major)
+    float guard;        // g_f (bins): f32 candidate
+    float nbins_f;
+    double scale64[9];  // the same factors in f64 (medium path)
+    double guard64;     // g_m (bins): f64-from-fixed-point candidate
+    double geom[GEOM_STRIDE];  // the (constant) cell record: canonical path reads it from SGPRs
+};
+
+constexpr int FAST_THREADS = 256;
+constexpr int FAST_TILE = 512;      // two centre atoms per thread
+
+// candidate bin coordinate q~ = |r_j - r_i| / dr from the fixed-point fractional coordinates
+template <bool ORTHO>
+__device__ __forceinline__ float fast_q(const float *sc, int ix, int iy, int iz)
+{
+    const float fx = (float)ix, fy = (float)iy, fz = (float)iz;
+    float t;
+    if (ORTHO) {
+        const float dx = fx * sc[0], dy = fy * sc[1], dz = fz * sc[2];
+        t = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    } else {
+        const float dx = fmaf(fz, sc[6], fmaf(fy, sc[3], fx * sc[0]));
+        const float dy = fmaf(fz, sc[7], fmaf(fy, sc[4], fx * sc[1]));
+        const float dz = fmaf(fz, sc[8], fmaf(fy, sc[5], fx * sc[2]));
+        t = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    }
+    return __builtin_amdgcn_sqrtf(t);
+}
+
+// squared candidate coordinate (bins^2) in f64 from the fixed-point differences
+template <bool ORTHO>
+__device__ __forceinline__ double medium_t(const double *sc, int ix, int iy, int iz)
+{
+    const double fx = (double)ix, fy = (double)iy, fz = (double)iz;
+    double dx, dy, dz;
+    if (ORTHO) {
+        dx = fx * sc[0]; dy = fy * sc[1]; dz = fz * sc[2];
+    } else {
+        dx = fma(fz, sc[6], fma(fy, sc[3], fx * sc[0]));
+        dy = fma(fz, sc[7], fma(fy, sc[4], fx * sc[1]));
+        dz = fma(fz, sc[8], fma(fy, sc[5], fx * sc[2]));
+    }
+    return fma(dz, dz, fma(dy, dy, dx * dx));
+}
+
+// Refinement of a pair whose f32 candidate q sits within g_f of the bin edge
+// e = rint(q).  Level 2 decides on which side of e the pair lies from the f64
+// squared distance T of the same fixed-point differences (error: the 2^-32 grid
+// only): T >= (e+g_m)^2 -> bin e, T < (e-g_m)^2 -> bin e-1 (bin nbins = out of
+// range).  Level 3 (|q - e| <= g_m, or coincident atoms): canonical arithmetic
+// on the original float64 positions with exact sqrt and divide.
+template <bool ORTHO>
+__device__ __forceinline__ void rdf_pair_refine(unsigned *hist, const RdfFastArgs &fa, float q, uint32_t uix,
+                                                uint32_t uiy, uint32_t uiz, uint4 qj,
+                                                const double *__restrict__ p, uint32_t idx_i)
+{
+    const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
+    const double T = medium_t<ORTHO>(fa.scale64, ix, iy, iz);
+    const float ef = rintf(q);
+    const double e = (double)ef, gm = fa.guard64;
+    const double hi = (e + gm) * (e + gm), lo = (e - gm) * (e - gm);
+    const int ei = (int)ef;
+    int b = -1;
+    if (T >= hi) b = ei;
+    else if (T < lo && ei > 0) b = ei - 1;
+    if (b >= 0) {
+        if (b < fa.a.nbins) atomicAdd(&hist[b], 1u);
+        return;
+    }
+    const double *pi = p + (size_t)idx_i * 3, *pj = p + (size_t)qj.w * 3;
+    double dx, dy, dz;
+    pair_base<ORTHO>(fa.geom, pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2], dx, dy, dz);
+    rdf_count(hist, norm2(dx, dy, dz), fa.a.rmax2, fa.a.dr, fa.a.nbins);
+}
+
+// One pair on the fast path.  With g = guard_f: a candidate whose fractional
+// part is > g away from both bin edges is certainly in bin (int)q -- and if
+// that bin is >= nbins the pair is certainly out of range; everything else
+// below nbins + g is refined.  Returns true when the pair needs refinement.
+template <bool ORTHO>
+__device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool live, float half_m_guard,
+                                         float nb_hi, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj,
+                                         float &q)
+{
+    const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
+    q = fast_q<ORTHO>(sc, ix, iy, iz);
+    const bool in = live && (q < nb_hi);
+    const bool safe = fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard;
+#ifdef AMOF_EXP_NOATOMIC
+    if (in && safe) hist[(threadIdx.x & 63) + 64] = (unsigned)q;
+#else
+    if (in && safe) atomicAdd(&hist[(int)q], 1u);
+#endif
+    return in && !safe;
+}
+
+template <bool ORTHO, bool DIAG, bool TAIL>
+__device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const float *sc, const uint4 *tq,
+                                          int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
+                                          float half_m_guard, float nb_hi, uint32_t uax, uint32_t uay,
+                                          uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
+                                          uint32_t idb, const double *__restrict__ p)
+{
+    // four partner atoms per trip, read by broadcast before any LDS atomic
+    uint4 qj[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) qj[u] = tq[j0 + u];
+    float qa[4], qb[4];
+    bool na[4], nb[4];   // per-pair "needs refinement" flags (kept as lane masks)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int j = j0 + u;
+        const bool la = has_a && (!TAIL || j < cntj) && (!DIAG || j > ia);
+        const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
+        na[u] = fast_bin<ORTHO>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u]);
+        nb[u] = fast_bin<ORTHO>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u]);
+    }
+    if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {   // a few % of the pairs
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (na[u]) rdf_pair_refine<ORTHO>(hist, fa, qa[u], uax, uay, uaz, qj[u], p, ida);
+            if (nb[u]) rdf_pair_refine<ORTHO>(hist, fa, qb[u], ubx, uby, ubz, qj[u], p, idb);
+        }
+    }
+}
+
+template <bool ORTHO>
+__global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs fa)
+{
+    const RdfArgs &a = fa.a;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    uint4 *tq = reinterpret_cast<uint4 *>(lds_raw);                 // [FAST_TILE]
+    unsigned *hist = reinterpret_cast<unsigned *>(tq + FAST_TILE);   // [nbins]
+
+    const int tid = threadIdx.x;
+    const int2 pr = a.pairs[blockIdx.x];
+    const Tile ti = a.tiles[pr.x];
+    const Tile tj = a.tiles[pr.y];
+    const bool diag = pr.x == pr.y;
+    const int nbins = a.nbins;
+    for (int k = tid; k < nbins; k += FAST_THREADS) hist[k] = 0u;
+
+    const int f0 = blockIdx.y * a.frames_per_chunk;
+    const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
+    // centre atoms tid and tid + 256 of tile I
+    const int ia = tid, ib = tid + FAST_THREADS;
+    const bool has_a = ia < ti.count, has_b = ib < ti.count;
+    const float half_m_guard = 0.5f - fa.guard;
+    const float nb_hi = fa.nbins_f + fa.guard;
+    float sc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) sc[k] = fa.scale[k];
+    const int cntj = tj.count;
+    const int cntj4 = (cntj + 3) & ~3;
+
+    for (int fl = f0; fl < f1; fl++) {
+        const int f = fa.f_base + fl;
+        const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+        const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
+        __syncthreads();
+        for (int k = tid; k < cntj4; k += FAST_THREADS) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (k < cntj) {
+                const QAtom qa = Qf[tj.start + k];
+                v = make_uint4(qa.ux, qa.uy, qa.uz, qa.idx);
+            }
+            tq[k] = v;
+        }
+        uint32_t uax = 0, uay = 0, uaz = 0, ida = 0, ubx = 0, uby = 0, ubz = 0, idb = 0;
+        if (has_a) {
+            const QAtom qa = Qf[ti.start + ia];
+            uax = qa.ux; uay = qa.uy; uaz = qa.uz; ida = qa.idx;
+        }
+        if (has_b) {
+            const QAtom qb = Qf[ti.start + ib];
+            ubx = qb.ux; uby = qb.uy; ubz = qb.uz; idb = qb.idx;
+        }
+        __syncthreads();
+        const int full = cntj & ~3;
+        if (diag) {
+            for (int j0 = 0; j0 < cntj4; j0 += 4)
+                fast_quad<ORTHO, true, true>(hist, fa, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
+                                             uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+        } else {
+            for (int j0 = 0; j0 < full; j0 += 4)
+                fast_quad<ORTHO, false, false>(hist, fa, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
+                                               uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+            if (full < cntj)
+                fast_quad<ORTHO, false, true>(hist, fa, sc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
+                                              uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+        }
+    }
+    __syncthreads();
+    unsigned long long *U = a.U + ((size_t)ti.species * a.S + tj.species) * (size_t)nbins;
+    for (int k = tid; k < nbins; k += FAST_THREADS) {
+        unsigned v = hist[k];
+        if (v) atomicAdd(&U[k], (unsigned long long)v);
+    }
+}
+
 // hist[a][b][k] += (a == b) ? 2*U[a][a][k] + nsp[a]*selfh[k] : U[min][max][k]
 __global__ void rdf_finalize_kernel(const unsigned long long *U, const unsigned long long *selfh,
                                     const long long *nsp, unsigned long long *hist, int S, int nbins)
@@ -262,20 +515,125 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         a.max_img = max_img;
         a.rmax2 = rmax2;
         a.dr = dr;
-        // enough workgroups to fill 256 CUs several times over, few enough
-        // flushes that the u64 global atomics stay negligible
-        int64_t want_chunks = (8 * 2048 + (int64_t)pairs.size() - 1) / (int64_t)pairs.size();
-        int64_t fpc = std::max<int64_t>(1, t->n_frames / std::max<int64_t>(1, want_chunks));
-        fpc = std::min<int64_t>(fpc, 64);
-        int64_t chunks = (t->n_frames + fpc - 1) / fpc;
-        if (chunks > 65535) {
-            fpc = (t->n_frames + 65534) / 65535;
-            chunks = (t->n_frames + fpc - 1) / fpc;
-        }
-        a.frames_per_chunk = (int32_t)fpc;
-        dim3 grid((unsigned)pairs.size(), (unsigned)chunks);
         const bool extra = max_img > 0;
         const bool ortho = geom.all_ortho;
+        auto pick_chunks = [&](int64_t nframes, int32_t &fpc_out, unsigned &chunks_out) {
+            // enough workgroups to fill 256 CUs several times over, few enough
+            // flushes that the u64 global atomics stay negligible
+            int64_t want_chunks = (8 * 2048 + (int64_t)pairs.size() - 1) / (int64_t)pairs.size();
+            int64_t fpc = std::max<int64_t>(1, nframes / std::max<int64_t>(1, want_chunks));
+            fpc = std::min<int64_t>(fpc, 64);
+            int64_t chunks = (nframes + fpc - 1) / fpc;
+            if (chunks > 65535) {
+                fpc = (nframes + 65534) / 65535;
+                chunks = (nframes + fpc - 1) / fpc;
+            }
+            fpc_out = (int32_t)fpc;
+            chunks_out = (unsigned)chunks;
+        };
+
+        // ---- fast path: fixed-point minimum image + guarded candidate bins ----
+        double csum = 0.0;   // sum of cell-vector lengths: bounds the fixed-point grid error
+        {
+            const double *c = t->cell;
+            csum = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + sqrt(c[3] * c[3] + c[4] * c[4] + c[5] * c[5]) +
+                   sqrt(c[6] * c[6] + c[7] * c[7] + c[8] * c[8]);
+        }
+        // fractional coordinates are truncated to 2^-32: a pair vector moves by < csum * 2^-32;
+        // quant carries a factor 2 of margin (it also covers the f64 rounding of the fold, |s| < 1e4)
+        const double quant = csum * (1.0 / 2147483648.0);
+        const double guard_m = quant / dr + (double)nbins * 1e-12;
+        // f32 candidate: cvt, scale, product (3u each component), square, two fmas -> 9u on the
+        // squared distance, 4.5u after the root, + v_sqrt_f32 (1 ulp = 2u): 6.5u = 3.9e-7 relative;
+        // 5.5e-7 also covers a 2-ulp root
+        const double guard_f = (double)nbins * 5.5e-7 + guard_m;
+        const char *force = getenv("AMOF_RDF_KERNEL");
+        // (a changing cell would need per-frame scale factors: handled by the exact kernel for now)
+        bool fast = !extra && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS &&
+                    guard_f < 0.25 && t->n_cells == 1 && !(force && strcmp(force, "v1") == 0);
+        bool done = false;
+        if (fast) {
+            HostTiles ftiles;
+            build_tiles(t, FAST_TILE, ftiles);
+            std::vector<int2> fpairs;
+            for (int i = 0; i < (int)ftiles.tiles.size(); i++)
+                for (int j = i; j < (int)ftiles.tiles.size(); j++) fpairs.push_back(make_int2(i, j));
+            void *d_ftiles, *d_fpairs;
+            AMOF_TRY(upload(ctx, SLOT_AUX2, ftiles.tiles.data(), ftiles.tiles.size() * sizeof(Tile), &d_ftiles));
+            AMOF_TRY(upload(ctx, SLOT_AUX3, fpairs.data(), fpairs.size() * sizeof(int2), &d_fpairs));
+            int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
+            FB = std::min<int64_t>(std::min<int64_t>(FB, 65535), t->n_frames);
+            void *d_Q, *d_flag;
+            AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB * t->n_atoms * sizeof(QAtom), &d_Q));
+            AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag));
+            AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int32_t), ctx->stream));
+            RdfFastArgs fa;
+            fa.a = a;
+            fa.a.tiles = (const Tile *)d_ftiles;
+            fa.a.pairs = (const int2 *)d_fpairs;
+            fa.Q = (const QAtom *)d_Q;
+            const double *c = t->cell;
+            const double two32 = 1.0 / 4294967296.0;
+            for (int k = 0; k < 9; k++) fa.scale64[k] = 0.0;
+            if (ortho) {
+                fa.scale64[0] = c[0] * two32 / dr;
+                fa.scale64[1] = c[4] * two32 / dr;
+                fa.scale64[2] = c[8] * two32 / dr;
+            } else {
+                for (int k = 0; k < 9; k++) fa.scale64[k] = c[k] * two32 / dr;
+            }
+            for (int k = 0; k < 9; k++) fa.scale[k] = (float)fa.scale64[k];
+            fa.guard = (float)guard_f;
+            fa.nbins_f = (float)nbins;
+            fa.guard64 = guard_m;
+            for (int k = 0; k < GEOM_STRIDE; k++) fa.geom[k] = geom.rec[k];
+            size_t lds = FAST_TILE * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
+            int64_t launches = 0;
+            for (int64_t fb = 0; fb < t->n_frames; fb += FB) {
+                const int64_t nf = std::min<int64_t>(FB, t->n_frames - fb);
+                dim3 qgrid((unsigned)((t->n_atoms + 255) / 256), (unsigned)nf);
+                hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(256), 0, ctx->stream, pos_dev,
+                                   (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm, t->n_atoms,
+                                   (int)fb, (int)nf, (QAtom *)d_Q, (int32_t *)d_flag);
+                AMOF_HIP_TRY(ctx, hipGetLastError());
+                fa.f_base = (int32_t)fb;
+                fa.nf = (int32_t)nf;
+                int64_t want_chunks = (8 * 2048 + (int64_t)fpairs.size() - 1) / (int64_t)fpairs.size();
+                int64_t fpc = std::max<int64_t>(1, nf / std::max<int64_t>(1, want_chunks));
+                fpc = std::min<int64_t>(fpc, 32);
+                int64_t chunks = (nf + fpc - 1) / fpc;
+                fa.a.frames_per_chunk = (int32_t)fpc;
+                dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
+                if (launches == 0) timing_dom_begin(ctx);
+                hipError_t e;
+                if (ortho) {
+                    e = hipFuncSetAttribute((const void *)rdf_tile_kernel_fast<true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e == hipSuccess) hipLaunchKernelGGL(rdf_tile_kernel_fast<true>, grid, dim3(FAST_THREADS), lds, ctx->stream, fa);
+                } else {
+                    e = hipFuncSetAttribute((const void *)rdf_tile_kernel_fast<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e == hipSuccess) hipLaunchKernelGGL(rdf_tile_kernel_fast<false>, grid, dim3(FAST_THREADS), lds, ctx->stream, fa);
+                }
+                AMOF_HIP_TRY(ctx, e);
+                AMOF_HIP_TRY(ctx, hipGetLastError());
+                launches++;
+            }
+            timing_dom_end(ctx, launches);
+            int32_t flag = 0;
+            AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+            AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (flag) {
+                // some atom lies > 1e4 cells away from the origin: redo with the exact kernel
+                AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));
+            } else {
+                done = true;
+            }
+        }
+        if (!done) {
+        unsigned chunks;
+        pick_chunks(t->n_frames, a.frames_per_chunk, chunks);
+        dim3 grid((unsigned)pairs.size(), chunks);
         timing_dom_begin(ctx);
         if (nbins <= AMOF_MAX_LDS_BINS) {
             size_t lds = 3 * RDF_TILE * sizeof(double) + (size_t)nbins * sizeof(unsigned);
@@ -300,6 +658,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             AMOF_HIP_TRY(ctx, hipGetLastError());
         }
         timing_dom_end(ctx, 1);
+        }
     }
     {
         size_t total = (size_t)S * S * nbins;
