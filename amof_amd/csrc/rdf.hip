@@ -198,17 +198,10 @@ struct QAtom {
     uint32_t ux, uy, uz, idx;
 };
 
-__global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict__ pos,
-                                                       const double *__restrict__ geom, int n_cells,
-                                                       const int32_t *__restrict__ perm, int64_t N, int f0,
-                                                       int nf, QAtom *__restrict__ Q, int32_t *flag)
+__device__ __forceinline__ QAtom quantize_atom(const double *__restrict__ pos, const double *__restrict__ g,
+                                                int64_t N, int f, int64_t a, int ax0, int ax1, int ax2,
+                                                int32_t *flag)
 {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int fl = blockIdx.y;
-    if (k >= N || fl >= nf) return;
-    const int f = f0 + fl;
-    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
-    const int64_t a = perm[k];
     const double *__restrict__ p = pos + ((size_t)f * N + a) * 3;
     const double x = p[0], y = p[1], z = p[2];
     uint32_t u[3];
@@ -220,9 +213,57 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
         double t = s * 4294967296.0;
         u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
     }
+    // components are stored in the order (ax0, ax1, ax2): the host puts the slab axis last
     QAtom q;
-    q.ux = u[0]; q.uy = u[1]; q.uz = u[2]; q.idx = (uint32_t)a;
-    Q[(size_t)fl * N + k] = q;
+    q.ux = u[ax0]; q.uy = u[ax1]; q.uz = u[ax2]; q.idx = (uint32_t)a;
+    return q;
+}
+
+// One workgroup per (species, frame): fold the atoms into the cell, quantise, and
+// counting-sort the species segment into 256 slabs along cell axis `axis`
+// (order inside a slab is arbitrary -- every result downstream is an integer
+// count, independent of the order).
+constexpr int SLABS = 256;
+__global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict__ pos,
+                                                       const double *__restrict__ geom, int n_cells,
+                                                       const int32_t *__restrict__ perm,
+                                                       const int64_t *__restrict__ sp_first, int64_t N, int f0,
+                                                       int axis, QAtom *__restrict__ Q, int32_t *flag)
+{
+    __shared__ unsigned cnt[SLABS];
+    __shared__ unsigned wsum[4];
+    const int sp = blockIdx.x, fl = blockIdx.y, tid = threadIdx.x;
+    const int f = f0 + fl;
+    const int ax0 = (axis + 1) % 3, ax1 = (axis + 2) % 3;   // stored order: (ax0, ax1, axis)
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const int64_t k0 = sp_first[sp], k1 = sp_first[sp + 1];
+    cnt[tid] = 0u;
+    __syncthreads();
+    for (int64_t k = k0 + tid; k < k1; k += 256) {
+        const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        atomicAdd(&cnt[q.uz >> 24], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 256 counters (one per thread)
+    unsigned v = cnt[tid], incl = v;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wv; w++) base += wsum[w];
+    __syncthreads();
+    cnt[tid] = base + incl - v;
+    __syncthreads();
+    QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
+    for (int64_t k = k0 + tid; k < k1; k += 256) {
+        const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        const unsigned slot = atomicAdd(&cnt[q.uz >> 24], 1u);
+        Qf[slot] = q;
+    }
 }
 
 struct RdfFastArgs {
@@ -235,6 +276,8 @@ struct RdfFastArgs {
     float nbins_f;
     double scale64[9];  // the same factors in f64 (medium path)
     double guard64;     // g_m (bins): f64-from-fixed-point candidate
+    uint32_t cull_gap;  // skip a (wave, partner quad) block when its slab gap exceeds this (0 = off)
+    int32_t cull_axis;
     double geom[GEOM_STRIDE];  // the (constant) cell record: canonical path reads it from SGPRs
 };
 
@@ -326,9 +369,9 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
     return in && !safe;
 }
 
-template <bool ORTHO, bool DIAG, bool TAIL>
+template <bool ORTHO, bool DIAG, bool TAIL, bool CULL>
 __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const float *sc, const uint4 *tq,
-                                          int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
+                                          uint32_t wlo, uint32_t whi, int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
                                           float half_m_guard, float nb_hi, uint32_t uax, uint32_t uay,
                                           uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
                                           uint32_t idb, const double *__restrict__ p)
@@ -337,6 +380,21 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
     uint4 qj[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) qj[u] = tq[j0 + u];
+    if (CULL) {
+        // wave-uniform test: slab keys (.z) of the four partners against the wave's key range
+        uint32_t qlo = 0xffffffffu, qhi = 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t key = __builtin_amdgcn_readfirstlane(qj[u].z);
+            if (!TAIL || j0 + u < cntj) {
+                qlo = min(qlo, key);
+                qhi = max(qhi, key);
+            }
+        }
+        const bool overlap = qlo <= whi && wlo <= qhi;
+        const uint32_t gap = min(qlo - whi, wlo - qhi);   // circular, mod 2^32
+        if (!overlap && gap > fa.cull_gap) return;
+    }
     float qa[4], qb[4];
     bool na[4], nb[4];   // per-pair "needs refinement" flags (kept as lane masks)
 #pragma unroll
@@ -356,7 +414,7 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
     }
 }
 
-template <bool ORTHO>
+template <bool ORTHO, bool CULL>
 __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
     const RdfArgs &a = fa.a;
@@ -374,8 +432,8 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
 
     const int f0 = blockIdx.y * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
-    // centre atoms tid and tid + 256 of tile I
-    const int ia = tid, ib = tid + FAST_THREADS;
+    // two adjacent centre atoms of tile I per thread (adjacent = close in slab order)
+    const int ia = 2 * tid, ib = 2 * tid + 1;
     const bool has_a = ia < ti.count, has_b = ib < ti.count;
     const float half_m_guard = 0.5f - fa.guard;
     const float nb_hi = fa.nbins_f + fa.guard;
@@ -408,18 +466,32 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
             ubx = qb.ux; uby = qb.uy; ubz = qb.uz; idb = qb.idx;
         }
         __syncthreads();
+        uint32_t wlo = 0u, whi = 0xffffffffu;
+        if (CULL) {
+            // key range of this wave's centre atoms along the slab axis (wave reduction -> SGPRs)
+            uint32_t lo = has_a ? uaz : 0xffffffffu, hi = has_a ? uaz : 0u;
+            if (has_b) { lo = min(lo, ubz); hi = max(hi, ubz); }
+            for (int off = 32; off > 0; off >>= 1) {
+                lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+                hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+            }
+            wlo = __builtin_amdgcn_readfirstlane(lo);
+            whi = __builtin_amdgcn_readfirstlane(hi);
+        }
         const int full = cntj & ~3;
-        if (diag) {
-            for (int j0 = 0; j0 < cntj4; j0 += 4)
-                fast_quad<ORTHO, true, true>(hist, fa, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
-                                             uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
-        } else {
-            for (int j0 = 0; j0 < full; j0 += 4)
-                fast_quad<ORTHO, false, false>(hist, fa, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
-                                               uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
-            if (full < cntj)
-                fast_quad<ORTHO, false, true>(hist, fa, sc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
-                                              uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+        if (wlo <= whi) {      // (a wave without centre atoms has nothing to do)
+            if (diag) {
+                for (int j0 = 0; j0 < cntj4; j0 += 4)
+                    fast_quad<ORTHO, true, true, CULL>(hist, fa, sc, tq, wlo, whi, j0, cntj, has_a, has_b, ia, ib,
+                                                       half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+            } else {
+                for (int j0 = 0; j0 < full; j0 += 4)
+                    fast_quad<ORTHO, false, false, CULL>(hist, fa, sc, tq, wlo, whi, j0, cntj, has_a, has_b, ia, ib,
+                                                         half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+                if (full < cntj)
+                    fast_quad<ORTHO, false, true, CULL>(hist, fa, sc, tq, wlo, whi, full, cntj, has_a, has_b, ia, ib,
+                                                        half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+            }
         }
     }
     __syncthreads();
@@ -567,20 +639,39 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB * t->n_atoms * sizeof(QAtom), &d_Q));
             AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag));
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int32_t), ctx->stream));
+            // slab axis = largest perpendicular height; culling only pays when 2 rmax < h
+            int axis = 0;
+            for (int k = 1; k < 3; k++)
+                if (geom.rec[18 + k] > geom.rec[18 + axis]) axis = k;
+            const double hax = geom.rec[18 + axis];
+            const char *nocull = getenv("AMOF_RDF_NOCULL");
+            const bool cull = !(nocull && nocull[0] == '1') && 2.0 * rmax * 1.05 < hax;
+            std::vector<int64_t> sp_first(S + 1, 0);
+            for (int sidx = 0; sidx < S; sidx++) sp_first[sidx + 1] = sp_first[sidx] + ftiles.nsp[sidx];
+            void *d_spfirst;
+            AMOF_TRY(upload(ctx, SLOT_AUX4, sp_first.data(), sp_first.size() * sizeof(int64_t), &d_spfirst));
             RdfFastArgs fa;
+            fa.cull_axis = axis;
+            // a block is skipped when the slab gap alone exceeds rmax (1e-6 relative and 4 grid units of slack)
+            fa.cull_gap = cull ? (uint32_t)std::min(4294967295.0, ceil(rmax / hax * 4294967296.0 * (1.0 + 1e-6)) + 4.0) : 0u;
+            {
+                const char *dbg = getenv("AMOF_RDF_CULLGAP_DEBUG");   // timing experiments only (breaks results)
+                if (dbg && cull) fa.cull_gap = (uint32_t)strtoul(dbg, nullptr, 10);
+            }
             fa.a = a;
             fa.a.tiles = (const Tile *)d_ftiles;
             fa.a.pairs = (const int2 *)d_fpairs;
             fa.Q = (const QAtom *)d_Q;
             const double *c = t->cell;
             const double two32 = 1.0 / 4294967296.0;
+            // fixed-point components are stored in the order (ax0, ax1, axis): permute the cell rows alike
+            const int ord[3] = {(axis + 1) % 3, (axis + 2) % 3, axis};
             for (int k = 0; k < 9; k++) fa.scale64[k] = 0.0;
             if (ortho) {
-                fa.scale64[0] = c[0] * two32 / dr;
-                fa.scale64[1] = c[4] * two32 / dr;
-                fa.scale64[2] = c[8] * two32 / dr;
+                for (int k = 0; k < 3; k++) fa.scale64[k] = c[4 * ord[k]] * two32 / dr;
             } else {
-                for (int k = 0; k < 9; k++) fa.scale64[k] = c[k] * two32 / dr;
+                for (int k = 0; k < 3; k++)
+                    for (int x = 0; x < 3; x++) fa.scale64[3 * k + x] = c[3 * ord[k] + x] * two32 / dr;
             }
             for (int k = 0; k < 9; k++) fa.scale[k] = (float)fa.scale64[k];
             fa.guard = (float)guard_f;
@@ -591,10 +682,11 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             int64_t launches = 0;
             for (int64_t fb = 0; fb < t->n_frames; fb += FB) {
                 const int64_t nf = std::min<int64_t>(FB, t->n_frames - fb);
-                dim3 qgrid((unsigned)((t->n_atoms + 255) / 256), (unsigned)nf);
+                dim3 qgrid((unsigned)S, (unsigned)nf);
                 hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(256), 0, ctx->stream, pos_dev,
-                                   (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm, t->n_atoms,
-                                   (int)fb, (int)nf, (QAtom *)d_Q, (int32_t *)d_flag);
+                                   (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm,
+                                   (const int64_t *)d_spfirst, t->n_atoms, (int)fb, axis, (QAtom *)d_Q,
+                                   (int32_t *)d_flag);
                 AMOF_HIP_TRY(ctx, hipGetLastError());
                 fa.f_base = (int32_t)fb;
                 fa.nf = (int32_t)nf;
@@ -605,16 +697,18 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.a.frames_per_chunk = (int32_t)fpc;
                 dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
                 if (launches == 0) timing_dom_begin(ctx);
+                auto launch = [&](auto kern) -> hipError_t {
+                    hipError_t e2 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)lds);
+                    if (e2 != hipSuccess) return e2;
+                    hipLaunchKernelGGL(kern, grid, dim3(FAST_THREADS), lds, ctx->stream, fa);
+                    return hipSuccess;
+                };
                 hipError_t e;
-                if (ortho) {
-                    e = hipFuncSetAttribute((const void *)rdf_tile_kernel_fast<true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e == hipSuccess) hipLaunchKernelGGL(rdf_tile_kernel_fast<true>, grid, dim3(FAST_THREADS), lds, ctx->stream, fa);
-                } else {
-                    e = hipFuncSetAttribute((const void *)rdf_tile_kernel_fast<false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e == hipSuccess) hipLaunchKernelGGL(rdf_tile_kernel_fast<false>, grid, dim3(FAST_THREADS), lds, ctx->stream, fa);
-                }
+                if (ortho && cull) e = launch(rdf_tile_kernel_fast<true, true>);
+                else if (ortho) e = launch(rdf_tile_kernel_fast<true, false>);
+                else if (cull) e = launch(rdf_tile_kernel_fast<false, true>);
+                else e = launch(rdf_tile_kernel_fast<false, false>);
                 AMOF_HIP_TRY(ctx, e);
                 AMOF_HIP_TRY(ctx, hipGetLastError());
                 launches++;
