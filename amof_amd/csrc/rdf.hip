@@ -369,9 +369,9 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
     return in && !safe;
 }
 
-template <bool ORTHO, bool DIAG, bool TAIL, bool CULL>
+template <bool ORTHO, bool DIAG, bool TAIL>
 __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const float *sc, const uint4 *tq,
-                                          uint32_t wlo, uint32_t whi, int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
+                                          int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
                                           float half_m_guard, float nb_hi, uint32_t uax, uint32_t uay,
                                           uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
                                           uint32_t idb, const double *__restrict__ p)
@@ -380,21 +380,6 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
     uint4 qj[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) qj[u] = tq[j0 + u];
-    if (CULL) {
-        // wave-uniform test: slab keys (.z) of the four partners against the wave's key range
-        uint32_t qlo = 0xffffffffu, qhi = 0u;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t key = __builtin_amdgcn_readfirstlane(qj[u].z);
-            if (!TAIL || j0 + u < cntj) {
-                qlo = min(qlo, key);
-                qhi = max(qhi, key);
-            }
-        }
-        const bool overlap = qlo <= whi && wlo <= qhi;
-        const uint32_t gap = min(qlo - whi, wlo - qhi);   // circular, mod 2^32
-        if (!overlap && gap > fa.cull_gap) return;
-    }
     float qa[4], qb[4];
     bool na[4], nb[4];   // per-pair "needs refinement" flags (kept as lane masks)
 #pragma unroll
@@ -414,6 +399,12 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
     }
 }
 
+// Work item = (tile I, 128-atom sub-tile of I, tile J) x a chunk of frames.  All four
+// waves of the workgroup hold the SAME 128 centre atoms (two adjacent ones per lane) and
+// share the quads of tile J round-robin, so the slab culling -- which depends only on the
+// centre atoms' slab range -- removes the same share of work from every wave.
+constexpr int FAST_SUB = 128;
+
 template <bool ORTHO, bool CULL>
 __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
@@ -422,18 +413,20 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
     uint4 *tq = reinterpret_cast<uint4 *>(lds_raw);                 // [FAST_TILE]
     unsigned *hist = reinterpret_cast<unsigned *>(tq + FAST_TILE);   // [nbins]
 
-    const int tid = threadIdx.x;
-    const int2 pr = a.pairs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int2 pr = a.pairs[blockIdx.x >> 2];
+    const int sub = blockIdx.x & 3;
     const Tile ti = a.tiles[pr.x];
     const Tile tj = a.tiles[pr.y];
     const bool diag = pr.x == pr.y;
+    if (sub * FAST_SUB >= ti.count) return;   // empty sub-tile (uniform for the workgroup)
     const int nbins = a.nbins;
     for (int k = tid; k < nbins; k += FAST_THREADS) hist[k] = 0u;
 
     const int f0 = blockIdx.y * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
-    // two adjacent centre atoms of tile I per thread (adjacent = close in slab order)
-    const int ia = 2 * tid, ib = 2 * tid + 1;
+    // two adjacent centre atoms per lane (adjacent = close in slab order); same in every wave
+    const int ia = sub * FAST_SUB + 2 * lane, ib = ia + 1;
     const bool has_a = ia < ti.count, has_b = ib < ti.count;
     const float half_m_guard = 0.5f - fa.guard;
     const float nb_hi = fa.nbins_f + fa.guard;
@@ -442,6 +435,7 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
     for (int k = 0; k < 9; k++) sc[k] = fa.scale[k];
     const int cntj = tj.count;
     const int cntj4 = (cntj + 3) & ~3;
+    const int full = cntj & ~3;
 
     for (int fl = f0; fl < f1; fl++) {
         const int f = fa.f_base + fl;
@@ -466,31 +460,72 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
             ubx = qb.ux; uby = qb.uy; ubz = qb.uz; idb = qb.idx;
         }
         __syncthreads();
-        uint32_t wlo = 0u, whi = 0xffffffffu;
+        // Partner index range(s) to visit.  Tile J is slab-sorted along the stored .z axis, so
+        // the partners within reach of the centre atoms (slab distance <= cull_gap, circular)
+        // form at most two contiguous index ranges, found once per frame.
+        int rb0 = diag ? (sub * FAST_SUB) : 0, re0 = cntj, rb1 = 0, re1 = 0;
         if (CULL) {
-            // key range of this wave's centre atoms along the slab axis (wave reduction -> SGPRs)
             uint32_t lo = has_a ? uaz : 0xffffffffu, hi = has_a ? uaz : 0u;
             if (has_b) { lo = min(lo, ubz); hi = max(hi, ubz); }
             for (int off = 32; off > 0; off >>= 1) {
                 lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
                 hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
             }
-            wlo = __builtin_amdgcn_readfirstlane(lo);
-            whi = __builtin_amdgcn_readfirstlane(hi);
+            const uint32_t wlo = __builtin_amdgcn_readfirstlane(lo), whi = __builtin_amdgcn_readfirstlane(hi);
+            const uint32_t G = fa.cull_gap;
+            // reachable keys: [wlo - G, whi + G] (mod 2^32), widened to whole slabs (2^24 each)
+            const unsigned long long span = (unsigned long long)(whi - wlo) + 2ull * G + (2ull << 24);
+            if (span < (1ull << 32)) {
+                const uint32_t klo = wlo - G, khi = whi + G;
+                const uint32_t slo = klo >> 24, shi = khi >> 24;
+                // first partner with slab >= s: every lane samples two quads, ballots give the quad
+                auto first_quad_ge = [&](uint32_t s) {
+                    const int q0 = lane, q1 = lane + 64;     // FAST_TILE / 4 = 128 quads
+                    const bool g0 = 4 * q0 < cntj4 ? ((tq[min(4 * q0 + 3, cntj - 1)].z >> 24) >= s) : true;
+                    const bool g1 = 4 * q1 < cntj4 ? ((tq[min(4 * q1 + 3, cntj - 1)].z >> 24) >= s) : true;
+                    const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
+                    const int fq = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
+                    return min(4 * fq, cntj);     // conservative: start of the first quad whose last slab >= s
+                };
+                // first quad whose FIRST partner has slab > s (everything before may be <= s)
+                auto end_quad_gt = [&](uint32_t s) {
+                    const int q0 = lane, q1 = lane + 64;
+                    const bool g0 = 4 * q0 < cntj ? ((tq[4 * q0].z >> 24) > s) : true;
+                    const bool g1 = 4 * q1 < cntj ? ((tq[4 * q1].z >> 24) > s) : true;
+                    const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
+                    const int fq = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
+                    return min(4 * fq, cntj);
+                };
+                const int a_ = first_quad_ge(slo), b_ = end_quad_gt(shi);
+                if (klo <= khi) {
+                    rb0 = max(rb0, a_); re0 = b_;
+                } else if (b_ < a_) {      // wrapped reach: keys <= khi or >= klo
+                    re0 = b_;
+                    rb1 = max(rb0, a_); re1 = cntj;
+                }                          // else the two pieces touch: whole tile
+            }
         }
-        const int full = cntj & ~3;
-        if (wlo <= whi) {      // (a wave without centre atoms has nothing to do)
+#pragma unroll 1
+        for (int r = 0; r < 2; r++) {
+            const int rb = r == 0 ? rb0 : rb1, re = r == 0 ? re0 : re1;
+            if (re <= rb) continue;
+            int qb = rb & ~3;
+            const int qe = (re + 3) & ~3;
+            if (r == 1) qb = max(qb, (max(re0, rb0) + 3) & ~3);   // never visit a quad twice
+            const int qe_full = min(qe, full);
+            // quads are dealt round-robin to the four waves
             if (diag) {
-                for (int j0 = 0; j0 < cntj4; j0 += 4)
-                    fast_quad<ORTHO, true, true, CULL>(hist, fa, sc, tq, wlo, whi, j0, cntj, has_a, has_b, ia, ib,
-                                                       half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+                for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
+                    fast_quad<ORTHO, true, true>(hist, fa, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
+                                                 uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
             } else {
-                for (int j0 = 0; j0 < full; j0 += 4)
-                    fast_quad<ORTHO, false, false, CULL>(hist, fa, sc, tq, wlo, whi, j0, cntj, has_a, has_b, ia, ib,
-                                                         half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
-                if (full < cntj)
-                    fast_quad<ORTHO, false, true, CULL>(hist, fa, sc, tq, wlo, whi, full, cntj, has_a, has_b, ia, ib,
-                                                        half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+                int j0 = qb + 4 * wave;
+                for (; j0 < qe_full; j0 += 16)
+                    fast_quad<ORTHO, false, false>(hist, fa, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                                                   nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+                if (j0 == full && j0 < qe && full < cntj)
+                    fast_quad<ORTHO, false, true>(hist, fa, sc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard,
+                                                  nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
             }
         }
     }
@@ -690,12 +725,12 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 AMOF_HIP_TRY(ctx, hipGetLastError());
                 fa.f_base = (int32_t)fb;
                 fa.nf = (int32_t)nf;
-                int64_t want_chunks = (8 * 2048 + (int64_t)fpairs.size() - 1) / (int64_t)fpairs.size();
+                int64_t want_chunks = (8 * 2048 + 4 * (int64_t)fpairs.size() - 1) / (4 * (int64_t)fpairs.size());
                 int64_t fpc = std::max<int64_t>(1, nf / std::max<int64_t>(1, want_chunks));
                 fpc = std::min<int64_t>(fpc, 32);
                 int64_t chunks = (nf + fpc - 1) / fpc;
                 fa.a.frames_per_chunk = (int32_t)fpc;
-                dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
+                dim3 grid((unsigned)(4 * fpairs.size()), (unsigned)chunks);
                 if (launches == 0) timing_dom_begin(ctx);
                 auto launch = [&](auto kern) -> hipError_t {
                     hipError_t e2 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
