@@ -405,13 +405,25 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
 // centre atoms' slab range -- removes the same share of work from every wave.
 constexpr int FAST_SUB = 128;
 
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// One wave copies 64 x 16 B from per-lane global addresses to 1 KiB of LDS at `dst`
+// (wave-uniform), without passing through registers (LDS-DMA, global_load_lds_dwordx4).
+__device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
+{
+    __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst_wave, 16, 0, 0);
+}
+
 template <bool ORTHO, bool CULL>
 __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
     const RdfArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    uint4 *tq = reinterpret_cast<uint4 *>(lds_raw);                 // [FAST_TILE]
-    unsigned *hist = reinterpret_cast<unsigned *>(tq + FAST_TILE);   // [nbins]
+    // double-buffered tiles: J (512 entries) and the centre sub-tile (128 entries)
+    uint4 *tqb = reinterpret_cast<uint4 *>(lds_raw);                         // [2][FAST_TILE]
+    uint4 *tcb = tqb + 2 * FAST_TILE;                                        // [2][FAST_SUB]
+    unsigned *hist = reinterpret_cast<unsigned *>(tcb + 2 * FAST_SUB);       // [nbins]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int2 pr = a.pairs[blockIdx.x >> 2];
@@ -426,8 +438,10 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
     const int f0 = blockIdx.y * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
     // two adjacent centre atoms per lane (adjacent = close in slab order); same in every wave
-    const int ia = sub * FAST_SUB + 2 * lane, ib = ia + 1;
-    const bool has_a = ia < ti.count, has_b = ib < ti.count;
+    const int cnti = min(FAST_SUB, ti.count - sub * FAST_SUB);     // centre atoms of this sub-tile
+    const int la = 2 * lane, lb = la + 1;                          // local indices in the sub-tile
+    const int ia = sub * FAST_SUB + la, ib = ia + 1;               // indices in tile I
+    const bool has_a = la < cnti, has_b = lb < cnti;
     const float half_m_guard = 0.5f - fa.guard;
     const float nb_hi = fa.nbins_f + fa.guard;
     float sc[9];
@@ -437,66 +451,60 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
     const int cntj4 = (cntj + 3) & ~3;
     const int full = cntj & ~3;
 
+    // LDS-DMA of one frame's tiles into buffer b: wave w moves J entries [64w, 64w+64) and
+    // [256+64w, ...), waves 0/1 also move the centre sub-tile; indices are clamped (slots
+    // beyond the counts are never used unmasked)
+    auto stage = [&](int fl, int b) {
+        const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
+        uint4 *tq = tqb + b * FAST_TILE, *tc = tcb + b * FAST_SUB;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int k = r * 256 + wave * 64 + lane;
+            if (r * 256 + wave * 64 < cntj4) dma_1k(Qf + tj.start + min(k, cntj - 1), tq + r * 256 + wave * 64);
+        }
+        if (wave < 2 && wave * 64 < cnti)
+            dma_1k(Qf + ti.start + sub * FAST_SUB + min(wave * 64 + lane, cnti - 1), tc + wave * 64);
+    };
+
+    if (f0 < f1) stage(f0, 0);
     for (int fl = f0; fl < f1; fl++) {
+        const int b = (fl - f0) & 1;
         const int f = fa.f_base + fl;
         const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
-        const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
-        __syncthreads();
-        for (int k = tid; k < cntj4; k += FAST_THREADS) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (k < cntj) {
-                const QAtom qa = Qf[tj.start + k];
-                v = make_uint4(qa.ux, qa.uy, qa.uz, qa.idx);
-            }
-            tq[k] = v;
-        }
-        uint32_t uax = 0, uay = 0, uaz = 0, ida = 0, ubx = 0, uby = 0, ubz = 0, idb = 0;
-        if (has_a) {
-            const QAtom qa = Qf[ti.start + ia];
-            uax = qa.ux; uay = qa.uy; uaz = qa.uz; ida = qa.idx;
-        }
-        if (has_b) {
-            const QAtom qb = Qf[ti.start + ib];
-            ubx = qb.ux; uby = qb.uy; ubz = qb.uz; idb = qb.idx;
-        }
-        __syncthreads();
+        const uint4 *tq = tqb + b * FAST_TILE, *tc = tcb + b * FAST_SUB;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for frame fl has landed
+        __syncthreads();                                    // everyone's has; frame fl-1 is fully consumed
+        if (fl + 1 < f1) stage(fl + 1, b ^ 1);              // next frame streams in behind the arithmetic
+        const uint4 ca = tc[min(la, cnti - 1)], cb = tc[min(lb, cnti - 1)];
+        const uint32_t uax = ca.x, uay = ca.y, uaz = ca.z, ida = ca.w;
+        const uint32_t ubx = cb.x, uby = cb.y, ubz = cb.z, idb = cb.w;
         // Partner index range(s) to visit.  Tile J is slab-sorted along the stored .z axis, so
         // the partners within reach of the centre atoms (slab distance <= cull_gap, circular)
         // form at most two contiguous index ranges, found once per frame.
         int rb0 = diag ? (sub * FAST_SUB) : 0, re0 = cntj, rb1 = 0, re1 = 0;
         if (CULL) {
-            uint32_t lo = has_a ? uaz : 0xffffffffu, hi = has_a ? uaz : 0u;
-            if (has_b) { lo = min(lo, ubz); hi = max(hi, ubz); }
-            for (int off = 32; off > 0; off >>= 1) {
-                lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
-                hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
-            }
-            const uint32_t wlo = __builtin_amdgcn_readfirstlane(lo), whi = __builtin_amdgcn_readfirstlane(hi);
+            // the sub-tile is slab-sorted: its first / last atoms give its slab range
+            const uint32_t s_first = tc[0].z >> 24, s_last = tc[cnti - 1].z >> 24;
+            const uint32_t wlo = s_first << 24, whi = (s_last << 24) | 0xffffffu;
             const uint32_t G = fa.cull_gap;
             // reachable keys: [wlo - G, whi + G] (mod 2^32), widened to whole slabs (2^24 each)
             const unsigned long long span = (unsigned long long)(whi - wlo) + 2ull * G + (2ull << 24);
             if (span < (1ull << 32)) {
                 const uint32_t klo = wlo - G, khi = whi + G;
                 const uint32_t slo = klo >> 24, shi = khi >> 24;
-                // first partner with slab >= s: every lane samples two quads, ballots give the quad
-                auto first_quad_ge = [&](uint32_t s) {
-                    const int q0 = lane, q1 = lane + 64;     // FAST_TILE / 4 = 128 quads
-                    const bool g0 = 4 * q0 < cntj4 ? ((tq[min(4 * q0 + 3, cntj - 1)].z >> 24) >= s) : true;
-                    const bool g1 = 4 * q1 < cntj4 ? ((tq[min(4 * q1 + 3, cntj - 1)].z >> 24) >= s) : true;
-                    const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
-                    const int fq = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
-                    return min(4 * fq, cntj);     // conservative: start of the first quad whose last slab >= s
-                };
-                // first quad whose FIRST partner has slab > s (everything before may be <= s)
-                auto end_quad_gt = [&](uint32_t s) {
-                    const int q0 = lane, q1 = lane + 64;
-                    const bool g0 = 4 * q0 < cntj ? ((tq[4 * q0].z >> 24) > s) : true;
-                    const bool g1 = 4 * q1 < cntj ? ((tq[4 * q1].z >> 24) > s) : true;
+                // every lane samples two quads of tile J; ballots give the boundary quads
+                const int q0 = lane, q1 = lane + 64;     // FAST_TILE / 4 = 128 quads
+                const uint32_t l0 = tq[min(4 * q0 + 3, cntj - 1)].z >> 24, l1 = tq[min(4 * q1 + 3, cntj - 1)].z >> 24;
+                const uint32_t h0 = tq[min(4 * q0, cntj - 1)].z >> 24, h1 = tq[min(4 * q1, cntj - 1)].z >> 24;
+                auto first_set = [&](bool g0, bool g1) {
                     const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
                     const int fq = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
                     return min(4 * fq, cntj);
                 };
-                const int a_ = first_quad_ge(slo), b_ = end_quad_gt(shi);
+                // a_: start of the first quad whose LAST partner has slab >= slo
+                // b_: start of the first quad whose FIRST partner has slab > shi
+                const int a_ = first_set(4 * q0 >= cntj || l0 >= slo, 4 * q1 >= cntj || l1 >= slo);
+                const int b_ = first_set(4 * q0 >= cntj || h0 > shi, 4 * q1 >= cntj || h1 > shi);
                 if (klo <= khi) {
                     rb0 = max(rb0, a_); re0 = b_;
                 } else if (b_ < a_) {      // wrapped reach: keys <= khi or >= klo
@@ -656,7 +664,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         const double guard_f = (double)nbins * 5.5e-7 + guard_m;
         const char *force = getenv("AMOF_RDF_KERNEL");
         // (a changing cell would need per-frame scale factors: handled by the exact kernel for now)
-        bool fast = !extra && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS &&
+        bool fast = !extra && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS - 5120 &&
                     guard_f < 0.25 && t->n_cells == 1 && !(force && strcmp(force, "v1") == 0);
         bool done = false;
         if (fast) {
@@ -713,7 +721,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             fa.nbins_f = (float)nbins;
             fa.guard64 = guard_m;
             for (int k = 0; k < GEOM_STRIDE; k++) fa.geom[k] = geom.rec[k];
-            size_t lds = FAST_TILE * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
+            size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
             int64_t launches = 0;
             for (int64_t fb = 0; fb < t->n_frames; fb += FB) {
                 const int64_t nf = std::min<int64_t>(FB, t->n_frames - fb);
