@@ -163,7 +163,11 @@ struct MsdGroup {
     int32_t _pad;
 };
 
-// one workgroup = one group of <= MSD_GROUP atoms of one species
+// one workgroup = one group of <= MSD_GROUP atoms of one species.
+// WREG > 0: at most WREG windows, per-thread partial sums stay in registers across all the
+// columns of the group and are reduced over the workgroup once per window;
+// WREG == 0: any number of windows, one workgroup reduction per (column, window).
+template <int WREG>
 __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__restrict__ DT, int64_t Fp, int F,
                                                                 const int32_t *__restrict__ perm,
                                                                 const MsdGroup *__restrict__ groups,
@@ -176,7 +180,11 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__
     __shared__ double red[MSD_THREADS / 64];
     const int tid = threadIdx.x;
     const MsdGroup gr = groups[blockIdx.x];
-    for (int w = tid; w < W; w += MSD_THREADS) wsum[w] = 0.0;
+    double acc[WREG > 0 ? WREG : 1];
+#pragma unroll
+    for (int w = 0; w < (WREG > 0 ? WREG : 1); w++) acc[w] = 0.0;
+    if (WREG == 0)
+        for (int w = tid; w < W; w += MSD_THREADS) wsum[w] = 0.0;
     for (int c = 0; c < 3 * gr.count; c++) {
         const int64_t atom = perm[gr.start + c / 3];
         const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
@@ -184,32 +192,59 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__
         for (int k = tid; k < F; k += MSD_THREADS) u[k] = col[k];
         __syncthreads();
         lds_scan(u, F, red, 0.0);
-        for (int w = 0; w < W; w++) {
-            const int m = windows[w];
-            double acc = 0.0;
-            for (int k = 1 + tid; k + m < F; k += MSD_THREADS) {
-                double d = u[k + m] - u[k];
-                acc = fma(d, d, acc);
+        if (WREG > 0) {
+#pragma unroll
+            for (int w = 0; w < WREG; w++) {
+                if (w < W) {
+                    const int m = windows[w];
+                    double a = acc[w];
+                    for (int k = 1 + tid; k + m < F; k += MSD_THREADS) {
+                        double d = u[k + m] - u[k];
+                        a = fma(d, d, a);
+                    }
+                    acc[w] = a;
+                }
             }
-            acc = block_sum(acc, red);
-            if (tid == 0) wsum[w] += acc;
+        } else {
+            for (int w = 0; w < W; w++) {
+                const int m = windows[w];
+                double a = 0.0;
+                for (int k = 1 + tid; k + m < F; k += MSD_THREADS) {
+                    double d = u[k + m] - u[k];
+                    a = fma(d, d, a);
+                }
+                a = block_sum(a, red);
+                if (tid == 0) wsum[w] += a;
+            }
         }
     }
-    __syncthreads();
-    for (int w = tid; w < W; w += MSD_THREADS) partial[(size_t)blockIdx.x * W + w] = wsum[w];
+    if (WREG > 0) {
+#pragma unroll
+        for (int w = 0; w < WREG; w++) {
+            if (w < W) {
+                const double tot = block_sum(acc[w], red);
+                if (tid == 0) partial[(size_t)blockIdx.x * W + w] = tot;
+            }
+        }
+    } else {
+        __syncthreads();
+        for (int w = tid; w < W; w += MSD_THREADS) partial[(size_t)blockIdx.x * W + w] = wsum[w];
+    }
 }
 
-// sumsq[s][w] = sum over the groups of species s, in group order
-__global__ void msd_reduce_kernel(const double *__restrict__ partial, const MsdGroup *__restrict__ groups,
-                                  int n_groups, int W, int S, double *__restrict__ sumsq)
+// sumsq[s][w] = sum over the groups of species s, in a fixed order (deterministic):
+// one workgroup per (s, w); groups are species-sorted, so species s owns [g0, g1)
+__global__ __launch_bounds__(MSD_THREADS) void msd_reduce_kernel(const double *__restrict__ partial,
+                                                                 const int32_t *__restrict__ sp_group_first, int W,
+                                                                 double *__restrict__ sumsq)
 {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * W) return;
-    int s = idx / W, w = idx % W;
+    __shared__ double red[MSD_THREADS / 64];
+    const int s = blockIdx.x / W, w = blockIdx.x % W;
+    const int g0 = sp_group_first[s], g1 = sp_group_first[s + 1];
     double acc = 0.0;
-    for (int g = 0; g < n_groups; g++)
-        if (groups[g].species == s) acc += partial[(size_t)g * W + w];
-    sumsq[idx] = acc;
+    for (int g = g0 + threadIdx.x; g < g1; g += MSD_THREADS) acc += partial[(size_t)g * W + w];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) sumsq[blockIdx.x] = acc;
 }
 
 // ---- unwrap path (amof/msd.py:222-230) in atom-major layout ----
@@ -303,7 +338,9 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     // species-sorted groups of the selected atoms
     std::vector<int32_t> perm;
     std::vector<MsdGroup> groups;
+    std::vector<int32_t> sp_group_first(S + 1, 0);
     for (int s = 0; s < S; s++) {
+        sp_group_first[s] = (int32_t)groups.size();
         size_t first = perm.size();
         for (int64_t i = atom_begin; i < atom_end; i++)
             if (t->species[i] == s) perm.push_back((int32_t)i);
@@ -316,6 +353,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
             groups.push_back(g);
         }
     }
+    sp_group_first[S] = (int32_t)groups.size();
     double total_mass = 0.0;
     if (remove_com)
         for (int64_t i = 0; i < N; i++) total_mass += t->masses[i];
@@ -331,6 +369,8 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     AMOF_TRY(upload(ctx, SLOT_PERM, perm.data(), perm.size() * sizeof(int32_t), &d_perm));
     AMOF_TRY(upload(ctx, SLOT_TILES, groups.data(), groups.size() * sizeof(MsdGroup), &d_groups));
     AMOF_TRY(upload(ctx, SLOT_AUX0, windows, (size_t)W * sizeof(int32_t), &d_win));
+    void *d_sgf;
+    AMOF_TRY(upload(ctx, SLOT_PAIRS, sp_group_first.data(), sp_group_first.size() * sizeof(int32_t), &d_sgf));
     if (remove_com) {
         AMOF_TRY(upload(ctx, SLOT_AUX1, t->masses, (size_t)N * sizeof(double), &d_mass));
         AMOF_TRY(ensure(ctx, SLOT_AUX2, (size_t)F * 3 * sizeof(double), &d_com));
@@ -367,17 +407,25 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
                            (const double *)d_geom, (int)t->n_cells, N, Fp, (int)F, (double *)d_DT);
     }
     AMOF_HIP_TRY(ctx, hipGetLastError());
-    AMOF_HIP_TRY(ctx, hipFuncSetAttribute((const void *)msd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds_need));
     timing_dom_begin(ctx);
-    hipLaunchKernelGGL(msd_group_kernel, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds_need, ctx->stream,
-                       (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
-                       (const int32_t *)d_win, (int)W, (double *)d_part);
+    {
+        auto launch = [&](auto kern) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds_need, ctx->stream,
+                               (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
+                               (const int32_t *)d_win, (int)W, (double *)d_part);
+            return hipGetLastError();
+        };
+        hipError_t e;
+        if (W <= 8) e = launch(msd_group_kernel<8>);
+        else if (W <= 32) e = launch(msd_group_kernel<32>);
+        else e = launch(msd_group_kernel<0>);
+        AMOF_HIP_TRY(ctx, e);
+    }
     timing_dom_end(ctx, 1);
-    AMOF_HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(msd_reduce_kernel, dim3((unsigned)((S * W + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const double *)d_part, (const MsdGroup *)d_groups, (int)groups.size(), (int)W, S,
-                       (double *)d_out);
+    hipLaunchKernelGGL(msd_reduce_kernel, dim3((unsigned)(S * W)), dim3(MSD_THREADS), 0, ctx->stream,
+                       (const double *)d_part, (const int32_t *)d_sgf, (int)W, (double *)d_out);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_end(ctx);
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(sumsq, d_out, (size_t)S * W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

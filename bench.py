@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--reps", type=str, default="3,3,4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rdf-frames", type=int, default=24)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
+    ap.add_argument("--all-on-device", type=int, default=None, help="rehearsal: put every rank on this GPU")
     args = ap.parse_args()
 
     import torch
@@ -131,10 +133,15 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.all_on_device is not None:
+        local_rank = args.all_on_device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     reps = tuple(int(x) for x in args.reps.split(","))
     F = args.frames
@@ -169,7 +176,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
