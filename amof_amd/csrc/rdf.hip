@@ -266,19 +266,22 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
     }
 }
 
+// per-cell record of the fast path (one per frame when the cell changes)
+struct FrameScale {
+    float sc[9];        // ORTHO: sc[0..2] = L_k * 2^-32 / dr ; else cell[k][c] * 2^-32 / dr (rows in stored order)
+    uint32_t cull_gap;  // slab-gap threshold of this cell (0 = culling off)
+    double sc64[9];     // the same factors in f64 (level-2 refinement)
+};
+
 struct RdfFastArgs {
     RdfArgs a;
-    const QAtom *Q;     // [nf][N] species-sorted
-    int32_t f_base;     // first frame of this batch
-    int32_t nf;         // frames in this batch
-    float scale[9];     // ORTHO: scale[0..2] = L_k * 2^-32 / dr ; else cell[k][c] * 2^-32 / dr (row-major)
-    float guard;        // g_f (bins): f32 candidate
+    const QAtom *Q;          // [nf][N] species-sorted, slab-sorted
+    const FrameScale *fs;    // [n_cells]
+    int32_t f_base;          // first frame of this batch
+    int32_t nf;              // frames in this batch
+    float guard;             // g_f (bins): f32 candidate
     float nbins_f;
-    double scale64[9];  // the same factors in f64 (medium path)
-    double guard64;     // g_m (bins): f64-from-fixed-point candidate
-    uint32_t cull_gap;  // skip a (wave, partner quad) block when its slab gap exceeds this (0 = off)
-    int32_t cull_axis;
-    double geom[GEOM_STRIDE];  // the (constant) cell record: canonical path reads it from SGPRs
+    double guard64;          // g_m (bins): f64-from-fixed-point candidate
 };
 
 constexpr int FAST_THREADS = 256;
@@ -325,12 +328,13 @@ __device__ __forceinline__ double medium_t(const double *sc, int ix, int iy, int
 // range).  Level 3 (|q - e| <= g_m, or coincident atoms): canonical arithmetic
 // on the original float64 positions with exact sqrt and divide.
 template <bool ORTHO>
-__device__ __forceinline__ void rdf_pair_refine(unsigned *hist, const RdfFastArgs &fa, float q, uint32_t uix,
-                                                uint32_t uiy, uint32_t uiz, uint4 qj,
+__device__ __forceinline__ void rdf_pair_refine(unsigned *hist, const RdfFastArgs &fa,
+                                                const FrameScale *__restrict__ fs, const double *__restrict__ g,
+                                                float q, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj,
                                                 const double *__restrict__ p, uint32_t idx_i)
 {
     const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
-    const double T = medium_t<ORTHO>(fa.scale64, ix, iy, iz);
+    const double T = medium_t<ORTHO>(fs->sc64, ix, iy, iz);
     const float ef = rintf(q);
     const double e = (double)ef, gm = fa.guard64;
     const double hi = (e + gm) * (e + gm), lo = (e - gm) * (e - gm);
@@ -344,7 +348,7 @@ __device__ __forceinline__ void rdf_pair_refine(unsigned *hist, const RdfFastArg
     }
     const double *pi = p + (size_t)idx_i * 3, *pj = p + (size_t)qj.w * 3;
     double dx, dy, dz;
-    pair_base<ORTHO>(fa.geom, pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2], dx, dy, dz);
+    pair_base<ORTHO>(g, pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2], dx, dy, dz);
     rdf_count(hist, norm2(dx, dy, dz), fa.a.rmax2, fa.a.dr, fa.a.nbins);
 }
 
@@ -370,7 +374,8 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
 }
 
 template <bool ORTHO, bool DIAG, bool TAIL>
-__device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const float *sc, const uint4 *tq,
+__device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const FrameScale *__restrict__ fs,
+                                          const double *__restrict__ g, const float *sc, const uint4 *tq,
                                           int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
                                           float half_m_guard, float nb_hi, uint32_t uax, uint32_t uay,
                                           uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
@@ -393,8 +398,8 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
     if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {   // a few % of the pairs
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (na[u]) rdf_pair_refine<ORTHO>(hist, fa, qa[u], uax, uay, uaz, qj[u], p, ida);
-            if (nb[u]) rdf_pair_refine<ORTHO>(hist, fa, qb[u], ubx, uby, ubz, qj[u], p, idb);
+            if (na[u]) rdf_pair_refine<ORTHO>(hist, fa, fs, g, qa[u], uax, uay, uaz, qj[u], p, ida);
+            if (nb[u]) rdf_pair_refine<ORTHO>(hist, fa, fs, g, qb[u], ubx, uby, ubz, qj[u], p, idb);
         }
     }
 }
@@ -416,7 +421,7 @@ __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
 }
 
 template <bool ORTHO, bool CULL>
-__global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs fa)
+__global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
     const RdfArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -444,9 +449,6 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
     const bool has_a = la < cnti, has_b = lb < cnti;
     const float half_m_guard = 0.5f - fa.guard;
     const float nb_hi = fa.nbins_f + fa.guard;
-    float sc[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) sc[k] = fa.scale[k];
     const int cntj = tj.count;
     const int cntj4 = (cntj + 3) & ~3;
     const int full = cntj & ~3;
@@ -472,6 +474,13 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
         const int f = fa.f_base + fl;
         const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
         const uint4 *tq = tqb + b * FAST_TILE, *tc = tcb + b * FAST_SUB;
+        const int gi = a.n_cells == 1 ? 0 : f;
+        const FrameScale *__restrict__ fs = fa.fs + gi;
+        const double *__restrict__ g = a.geom + (size_t)gi * GEOM_STRIDE;
+        float sc[9];      // wave-uniform: keep them in scalar registers
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for frame fl has landed
         __syncthreads();                                    // everyone's has; frame fl-1 is fully consumed
         if (fl + 1 < f1) stage(fl + 1, b ^ 1);              // next frame streams in behind the arithmetic
@@ -486,10 +495,10 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
             // the sub-tile is slab-sorted: its first / last atoms give its slab range
             const uint32_t s_first = tc[0].z >> 24, s_last = tc[cnti - 1].z >> 24;
             const uint32_t wlo = s_first << 24, whi = (s_last << 24) | 0xffffffu;
-            const uint32_t G = fa.cull_gap;
+            const uint32_t G = __builtin_amdgcn_readfirstlane(fs->cull_gap);
             // reachable keys: [wlo - G, whi + G] (mod 2^32), widened to whole slabs (2^24 each)
             const unsigned long long span = (unsigned long long)(whi - wlo) + 2ull * G + (2ull << 24);
-            if (span < (1ull << 32)) {
+            if (G != 0u && span < (1ull << 32)) {
                 const uint32_t klo = wlo - G, khi = whi + G;
                 const uint32_t slo = klo >> 24, shi = khi >> 24;
                 // every lane samples two quads of tile J; ballots give the boundary quads
@@ -524,15 +533,15 @@ __global__ __launch_bounds__(FAST_THREADS) void rdf_tile_kernel_fast(RdfFastArgs
             // quads are dealt round-robin to the four waves
             if (diag) {
                 for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
-                    fast_quad<ORTHO, true, true>(hist, fa, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
+                    fast_quad<ORTHO, true, true>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
                                                  uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
             } else {
                 int j0 = qb + 4 * wave;
                 for (; j0 < qe_full; j0 += 16)
-                    fast_quad<ORTHO, false, false>(hist, fa, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                    fast_quad<ORTHO, false, false>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
                                                    nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
                 if (j0 == full && j0 < qe && full < cntj)
-                    fast_quad<ORTHO, false, true>(hist, fa, sc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard,
+                    fast_quad<ORTHO, false, true>(hist, fa, fs, g, sc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard,
                                                   nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
             }
         }
@@ -648,11 +657,13 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         };
 
         // ---- fast path: fixed-point minimum image + guarded candidate bins ----
-        double csum = 0.0;   // sum of cell-vector lengths: bounds the fixed-point grid error
-        {
-            const double *c = t->cell;
-            csum = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + sqrt(c[3] * c[3] + c[4] * c[4] + c[5] * c[5]) +
-                   sqrt(c[6] * c[6] + c[7] * c[7] + c[8] * c[8]);
+        const int64_t nc = t->n_cells;
+        double csum = 0.0;   // largest sum of cell-vector lengths: bounds the fixed-point grid error
+        for (int64_t k = 0; k < nc; k++) {
+            const double *c = t->cell + 9 * k;
+            csum = std::max(csum, sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) +
+                                      sqrt(c[3] * c[3] + c[4] * c[4] + c[5] * c[5]) +
+                                      sqrt(c[6] * c[6] + c[7] * c[7] + c[8] * c[8]));
         }
         // fractional coordinates are truncated to 2^-32: a pair vector moves by < csum * 2^-32;
         // quant carries a factor 2 of margin (it also covers the f64 rounding of the fold, |s| < 1e4)
@@ -663,9 +674,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         // 5.5e-7 also covers a 2-ulp root
         const double guard_f = (double)nbins * 5.5e-7 + guard_m;
         const char *force = getenv("AMOF_RDF_KERNEL");
-        // (a changing cell would need per-frame scale factors: handled by the exact kernel for now)
         bool fast = !extra && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS - 5120 &&
-                    guard_f < 0.25 && t->n_cells == 1 && !(force && strcmp(force, "v1") == 0);
+                    guard_f < 0.25 && !(force && strcmp(force, "v1") == 0);
         bool done = false;
         if (fast) {
             HostTiles ftiles;
@@ -676,51 +686,58 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             void *d_ftiles, *d_fpairs;
             AMOF_TRY(upload(ctx, SLOT_AUX2, ftiles.tiles.data(), ftiles.tiles.size() * sizeof(Tile), &d_ftiles));
             AMOF_TRY(upload(ctx, SLOT_AUX3, fpairs.data(), fpairs.size() * sizeof(int2), &d_fpairs));
+            // slab axis = the axis whose smallest perpendicular height over the trajectory is largest;
+            // culling only pays when 2 rmax < h
+            int axis = 0;
+            double hmin[3] = {1e300, 1e300, 1e300};
+            for (int64_t k = 0; k < nc; k++)
+                for (int x = 0; x < 3; x++) hmin[x] = std::min(hmin[x], geom.rec[(size_t)k * GEOM_STRIDE + 18 + x]);
+            for (int x = 1; x < 3; x++)
+                if (hmin[x] > hmin[axis]) axis = x;
+            const char *nocull = getenv("AMOF_RDF_NOCULL");
+            const bool cull = !(nocull && nocull[0] == '1') && 2.0 * rmax * 1.05 < hmin[axis];
+            std::vector<int64_t> sp_first(S + 1, 0);
+            for (int sidx = 0; sidx < S; sidx++) sp_first[sidx + 1] = sp_first[sidx] + ftiles.nsp[sidx];
+            void *d_spfirst;
+            AMOF_TRY(upload(ctx, SLOT_AUX4, sp_first.data(), sp_first.size() * sizeof(int64_t), &d_spfirst));
+            // per-cell records; fixed-point components are stored in the order (ax0, ax1, axis)
+            std::vector<FrameScale> fsv((size_t)nc);
+            const int ord[3] = {(axis + 1) % 3, (axis + 2) % 3, axis};
+            const double two32 = 1.0 / 4294967296.0;
+            const char *dbg = getenv("AMOF_RDF_CULLGAP_DEBUG");   // timing experiments only (breaks results)
+            for (int64_t k = 0; k < nc; k++) {
+                const double *c = t->cell + 9 * k;
+                FrameScale &r = fsv[(size_t)k];
+                for (int q = 0; q < 9; q++) r.sc64[q] = 0.0;
+                if (ortho) {
+                    for (int q = 0; q < 3; q++) r.sc64[q] = c[4 * ord[q]] * two32 / dr;
+                } else {
+                    for (int q = 0; q < 3; q++)
+                        for (int x = 0; x < 3; x++) r.sc64[3 * q + x] = c[3 * ord[q] + x] * two32 / dr;
+                }
+                for (int q = 0; q < 9; q++) r.sc[q] = (float)r.sc64[q];
+                // a block is skipped when the slab gap alone exceeds rmax (1e-6 relative and 4 grid units of slack)
+                const double hax = geom.rec[(size_t)k * GEOM_STRIDE + 18 + axis];
+                r.cull_gap = cull ? (uint32_t)std::min(4294967295.0, ceil(rmax / hax * 4294967296.0 * (1.0 + 1e-6)) + 4.0) : 0u;
+                if (dbg && cull) r.cull_gap = (uint32_t)strtoul(dbg, nullptr, 10);
+            }
+            void *d_fs;
+            AMOF_TRY(upload(ctx, SLOT_AUX5, fsv.data(), fsv.size() * sizeof(FrameScale), &d_fs));
+            RdfFastArgs fa;
+            fa.a = a;
+            fa.a.tiles = (const Tile *)d_ftiles;
+            fa.a.pairs = (const int2 *)d_fpairs;
+            fa.fs = (const FrameScale *)d_fs;
+            fa.guard = (float)guard_f;
+            fa.nbins_f = (float)nbins;
+            fa.guard64 = guard_m;
             int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
             FB = std::min<int64_t>(std::min<int64_t>(FB, 65535), t->n_frames);
             void *d_Q, *d_flag;
             AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB * t->n_atoms * sizeof(QAtom), &d_Q));
             AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag));
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int32_t), ctx->stream));
-            // slab axis = largest perpendicular height; culling only pays when 2 rmax < h
-            int axis = 0;
-            for (int k = 1; k < 3; k++)
-                if (geom.rec[18 + k] > geom.rec[18 + axis]) axis = k;
-            const double hax = geom.rec[18 + axis];
-            const char *nocull = getenv("AMOF_RDF_NOCULL");
-            const bool cull = !(nocull && nocull[0] == '1') && 2.0 * rmax * 1.05 < hax;
-            std::vector<int64_t> sp_first(S + 1, 0);
-            for (int sidx = 0; sidx < S; sidx++) sp_first[sidx + 1] = sp_first[sidx] + ftiles.nsp[sidx];
-            void *d_spfirst;
-            AMOF_TRY(upload(ctx, SLOT_AUX4, sp_first.data(), sp_first.size() * sizeof(int64_t), &d_spfirst));
-            RdfFastArgs fa;
-            fa.cull_axis = axis;
-            // a block is skipped when the slab gap alone exceeds rmax (1e-6 relative and 4 grid units of slack)
-            fa.cull_gap = cull ? (uint32_t)std::min(4294967295.0, ceil(rmax / hax * 4294967296.0 * (1.0 + 1e-6)) + 4.0) : 0u;
-            {
-                const char *dbg = getenv("AMOF_RDF_CULLGAP_DEBUG");   // timing experiments only (breaks results)
-                if (dbg && cull) fa.cull_gap = (uint32_t)strtoul(dbg, nullptr, 10);
-            }
-            fa.a = a;
-            fa.a.tiles = (const Tile *)d_ftiles;
-            fa.a.pairs = (const int2 *)d_fpairs;
             fa.Q = (const QAtom *)d_Q;
-            const double *c = t->cell;
-            const double two32 = 1.0 / 4294967296.0;
-            // fixed-point components are stored in the order (ax0, ax1, axis): permute the cell rows alike
-            const int ord[3] = {(axis + 1) % 3, (axis + 2) % 3, axis};
-            for (int k = 0; k < 9; k++) fa.scale64[k] = 0.0;
-            if (ortho) {
-                for (int k = 0; k < 3; k++) fa.scale64[k] = c[4 * ord[k]] * two32 / dr;
-            } else {
-                for (int k = 0; k < 3; k++)
-                    for (int x = 0; x < 3; x++) fa.scale64[3 * k + x] = c[3 * ord[k] + x] * two32 / dr;
-            }
-            for (int k = 0; k < 9; k++) fa.scale[k] = (float)fa.scale64[k];
-            fa.guard = (float)guard_f;
-            fa.nbins_f = (float)nbins;
-            fa.guard64 = guard_m;
-            for (int k = 0; k < GEOM_STRIDE; k++) fa.geom[k] = geom.rec[k];
             size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
             int64_t launches = 0;
             for (int64_t fb = 0; fb < t->n_frames; fb += FB) {
