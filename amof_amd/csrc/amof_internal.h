@@ -36,6 +36,8 @@ enum Slot {
     SLOT_AUX3,
     SLOT_AUX4,
     SLOT_AUX5,
+    SLOT_AUX6,
+    SLOT_AUX7,
     SLOT_OUT0,
     SLOT_OUT1,
     SLOT_FLAGS,
@@ -112,6 +114,16 @@ void build_tiles(const amof_traj *t, int tile, HostTiles &out);
 // staging of the position array (host -> device) or pass-through
 int stage_positions(amof_ctx *ctx, const amof_traj *t, const double **pos_dev);
 int upload(amof_ctx *ctx, Slot s, const void *src, size_t bytes, void **out);
+
+// fixed-point atom record of the fast paths: fractional coordinates * 2^32 in the stored
+// axis order (slab axis last), original atom index
+struct QAtom {
+    uint32_t ux, uy, uz, idx;
+};
+constexpr int QSLABS = 256;
+int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
+                    const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis, QAtom *d_Q,
+                    uint32_t *d_slab_start, int32_t *d_flag);
 
 void timing_begin(amof_ctx *ctx);
 void timing_end(amof_ctx *ctx);

@@ -10,6 +10,8 @@
 // with the tiles of its partner species only, staged through LDS and read by
 // broadcast.  All results are integer counts (exact, order independent).
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -255,6 +257,273 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
     if (tid == 0 && nang) atomicAdd(&a.n_angles[trip], nang);
 }
 
+// --------------------------------------------------------------------------
+// Fast neighbour path (fully periodic cells, cutoffs that need no extra image).
+//
+// Shares the RDF fast path's preparation: per frame every species segment is
+// folded into the cell, stored as 32-bit fixed-point fractional coordinates and
+// counting-sorted into 256 slabs along the longest cell axis, with a slab offset
+// table.  A centre tile only visits the partners whose slab lies within the
+// cutoff of its own slab range (a 1-D cell list: 2 rc / h of the partners), the
+// pair test is an f32 distance from the wrapped integer differences, and only
+// pairs within 1e-6 rc of the cutoff are re-decided by the canonical float64
+// arithmetic -- so every neighbour decision equals the oracle's.
+struct NbrCell {
+    float sc[9];         // cell rows * 2^-32 in stored axis order (ORTHO: sc[0..2])
+    float _pad;
+    double gap_per_len;  // 2^32 / h_axis * (1 + 1e-6): slab-key units per Angstrom of cutoff
+};
+
+struct NbrFastArgs {
+    NbrArgs a;
+    const QAtom *Q;               // [nf][N] species-sorted, slab-sorted
+    const uint32_t *slab_start;   // [nf][S][QSLABS+1]
+    const NbrCell *cells;         // [n_cells]
+    const int64_t *sp_first;      // [S+1] species segment offsets
+    int32_t f_base, nf;
+    float guard_rel;              // relative half-width of the "re-decide exactly" band
+    float guard_abs;              // absolute part (fixed-point grid), Angstrom
+};
+
+template <bool ORTHO>
+__device__ __forceinline__ float nbr_fast_dist(const float *sc, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj)
+{
+    const float fx = (float)(int)(qj.x - uix), fy = (float)(int)(qj.y - uiy), fz = (float)(int)(qj.z - uiz);
+    float t;
+    if (ORTHO) {
+        const float dx = fx * sc[0], dy = fy * sc[1], dz = fz * sc[2];
+        t = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    } else {
+        const float dx = fmaf(fz, sc[6], fmaf(fy, sc[3], fx * sc[0]));
+        const float dy = fmaf(fz, sc[7], fmaf(fy, sc[4], fx * sc[1]));
+        const float dz = fmaf(fz, sc[8], fmaf(fy, sc[5], fx * sc[2]));
+        t = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    }
+    return __builtin_amdgcn_sqrtf(t);
+}
+
+// exact decision (canonical arithmetic) for a pair in the guard band
+template <bool ORTHO>
+__device__ __forceinline__ bool nbr_exact(const double *__restrict__ g, const double *__restrict__ p,
+                                          uint32_t idx_i, uint32_t idx_j, double rc)
+{
+    const double *pi = p + (size_t)idx_i * 3, *pj = p + (size_t)idx_j * 3;
+    double dx, dy, dz;
+    pair_base<ORTHO>(g, pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2], dx, dy, dz);
+    return sqrt(norm2(dx, dy, dz)) < rc;
+}
+
+// partner index range(s), relative to species B's segment, within slab reach of a centre tile
+__device__ __forceinline__ void nbr_ranges(const uint32_t *__restrict__ st /* [QSLABS+1] */, uint32_t s_first,
+                                           uint32_t s_last, double rc, double gap_per_len, int nB, int &b0, int &e0,
+                                           int &b1, int &e1)
+{
+    b0 = 0; e0 = nB; b1 = 0; e1 = 0;
+    const double gd = ceil(rc * gap_per_len) + 4.0;
+    if (gd >= 4294967295.0) return;
+    const uint32_t G = (uint32_t)gd;
+    const uint32_t wlo = s_first << 24, whi = (s_last << 24) | 0xffffffu;
+    const unsigned long long span = (unsigned long long)(whi - wlo) + 2ull * G + (2ull << 24);
+    if (span >= (1ull << 32)) return;
+    const uint32_t slo = (wlo - G) >> 24, shi = (whi + G) >> 24;
+    if (slo <= shi) {
+        b0 = (int)st[slo]; e0 = (int)st[shi + 1];
+    } else {            // wrapped: slabs >= slo or <= shi
+        b0 = 0; e0 = (int)st[shi + 1];
+        b1 = (int)st[slo]; e1 = nB;
+        if (b1 < e0) { e0 = nB; b1 = e1 = 0; }
+    }
+}
+
+constexpr int NBRF_TILE = 256;
+
+template <bool ORTHO>
+__global__ __launch_bounds__(NBRF_TILE) void cn_fast_kernel(NbrFastArgs fa)
+{
+    const NbrArgs &a = fa.a;
+    __shared__ uint4 tq[NBRF_TILE];
+    __shared__ unsigned long long wsum[NBRF_TILE / 64];
+    const int tid = threadIdx.x;
+    const int4 w = a.work[blockIdx.x];          // (set, first centre (species-relative), A, B)
+    const int set = w.x, c0 = w.y, A = w.z, B = w.w;
+    const double rc = a.cutoff[A * a.S + B];
+    const int64_t segA = fa.sp_first[A], segB = fa.sp_first[B];
+    const int nA = (int)(fa.sp_first[A + 1] - segA), nB = (int)(fa.sp_first[B + 1] - segB);
+    const int cnt_c = min(NBRF_TILE, nA - c0);
+    const bool has = tid < cnt_c;
+    const float rcf = (float)rc;
+    const float g = rcf * fa.guard_rel + fa.guard_abs;
+    const float r_in = rcf - g, r_out = rcf + g;
+    const int f0 = blockIdx.y * a.frames_per_chunk;
+    const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
+    for (int fl = f0; fl < f1; fl++) {
+        const int f = fa.f_base + fl;
+        const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+        const int gi = a.n_cells == 1 ? 0 : f;
+        const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
+        const NbrCell *__restrict__ cell = fa.cells + gi;
+        const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
+        float sc[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) sc[k] = cell->sc[k];
+        const QAtom qc = Qf[segA + c0 + min(tid, cnt_c - 1)];
+        const uint32_t s_first = Qf[segA + c0].uz >> 24, s_last = Qf[segA + c0 + cnt_c - 1].uz >> 24;
+        int rb[2], re[2];
+        nbr_ranges(fa.slab_start + ((size_t)fl * a.S + B) * (QSLABS + 1), s_first, s_last, rc, cell->gap_per_len, nB,
+                   rb[0], re[0], rb[1], re[1]);
+        int cnt = 0;
+        if (rc > 0.0) {
+            for (int r = 0; r < 2; r++) {
+                for (int j0 = rb[r]; j0 < re[r]; j0 += NBRF_TILE) {
+                    const int nj = min(NBRF_TILE, re[r] - j0);
+                    __syncthreads();
+                    if (tid < nj) {
+                        const QAtom q = Qf[segB + j0 + tid];
+                        tq[tid] = make_uint4(q.ux, q.uy, q.uz, q.idx);
+                    }
+                    __syncthreads();
+                    if (has) {
+                        for (int j = 0; j < nj; j++) {
+                            const uint4 qj = tq[j];
+                            if (qj.w == qc.idx) continue;                       // no zero-shift self pair
+                            const float d = nbr_fast_dist<ORTHO>(sc, qc.ux, qc.uy, qc.uz, qj);
+                            if (d < r_in) cnt++;
+                            else if (d < r_out && nbr_exact<ORTHO>(geo, p, qc.idx, qj.w, rc)) cnt++;
+                        }
+                    }
+                }
+            }
+        }
+        if (a.per_atom && has) a.per_atom[((size_t)f * a.n_sets + set) * (size_t)a.N + qc.idx] = cnt;
+        unsigned long long v = has ? (unsigned long long)cnt : 0ull;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) wsum[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long s = 0;
+            for (int k = 0; k < NBRF_TILE / 64; k++) s += wsum[k];
+            if (s) atomicAdd(&a.sums[(size_t)f * a.n_sets + set], s);
+        }
+    }
+}
+
+// ase.geometry.get_angles on two canonical minimum-image vectors (normalise, dot, clip, acos)
+__device__ __forceinline__ bool unit_vec(double x, double y, double z, double &ux, double &uy, double &uz)
+{
+    const double nv = sqrt(x * x + y * y + z * z);
+    if (!(nv > 0.0)) return false;
+    ux = x / nv; uy = y / nv; uz = z / nv;
+    return true;
+}
+
+template <bool ORTHO>
+__global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
+{
+    const NbrArgs &a = fa.a;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    uint4 *tq = reinterpret_cast<uint4 *>(lds_raw);                       // [NBRF_TILE]
+    uint32_t *nlist = reinterpret_cast<uint32_t *>(tq + NBRF_TILE);       // [AMOF_MAX_NEIGHBOURS][NBRF_TILE]
+    unsigned *hist = nlist + AMOF_MAX_NEIGHBOURS * NBRF_TILE;             // [nb]
+    const int tid = threadIdx.x;
+    const int4 w = a.work[blockIdx.x];          // (triple, first centre (species-relative), centre species, B)
+    const int trip = w.x, c0 = w.y, sa = w.z, B = w.w;
+    const int64_t segA = fa.sp_first[sa];
+    const int nA = (int)(fa.sp_first[sa + 1] - segA);
+    const int cnt_c = min(NBRF_TILE, nA - c0);
+    const bool has = tid < cnt_c;
+    const int nb = a.nb;
+    for (int k = tid; k < nb; k += NBRF_TILE) hist[k] = 0u;
+    unsigned long long nang = 0;
+    const int f0 = blockIdx.y * a.frames_per_chunk;
+    const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
+    for (int fl = f0; fl < f1; fl++) {
+        const int f = fa.f_base + fl;
+        const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+        const int gi = a.n_cells == 1 ? 0 : f;
+        const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
+        const NbrCell *__restrict__ cell = fa.cells + gi;
+        const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
+        float sc[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) sc[k] = cell->sc[k];
+        const QAtom qc = Qf[segA + c0 + min(tid, cnt_c - 1)];
+        const uint32_t s_first = Qf[segA + c0].uz >> 24, s_last = Qf[segA + c0 + cnt_c - 1].uz >> 24;
+        int n = 0;
+        for (int sb = 0; sb < a.S; sb++) {
+            if (!(B < 0 || sb == B)) continue;
+            const double rc = a.cutoff[sa * a.S + sb];
+            if (!(rc > 0.0)) continue;
+            const int64_t segB = fa.sp_first[sb];
+            const int nB = (int)(fa.sp_first[sb + 1] - segB);
+            const float rcf = (float)rc;
+            const float g = rcf * fa.guard_rel + fa.guard_abs;
+            const float r_in = rcf - g, r_out = rcf + g;
+            int rb[2], re[2];
+            nbr_ranges(fa.slab_start + ((size_t)fl * a.S + sb) * (QSLABS + 1), s_first, s_last, rc, cell->gap_per_len,
+                       nB, rb[0], re[0], rb[1], re[1]);
+            for (int r = 0; r < 2; r++) {
+                for (int j0 = rb[r]; j0 < re[r]; j0 += NBRF_TILE) {
+                    const int nj = min(NBRF_TILE, re[r] - j0);
+                    __syncthreads();
+                    if (tid < nj) {
+                        const QAtom q = Qf[segB + j0 + tid];
+                        tq[tid] = make_uint4(q.ux, q.uy, q.uz, q.idx);
+                    }
+                    __syncthreads();
+                    if (!has) continue;
+                    for (int j = 0; j < nj; j++) {
+                        const uint4 qj = tq[j];
+                        if (qj.w == qc.idx) continue;
+                        const float d = nbr_fast_dist<ORTHO>(sc, qc.ux, qc.uy, qc.uz, qj);
+                        bool nbr = d < r_in;
+                        if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, qc.idx, qj.w, rc);
+                        if (nbr) {
+                            if (n < AMOF_MAX_NEIGHBOURS) nlist[n * NBRF_TILE + tid] = qj.w;
+                            else a.flags[1] = 1;
+                            n++;
+                        }
+                    }
+                }
+            }
+        }
+        n = min(n, AMOF_MAX_NEIGHBOURS);
+        // every unordered pair of neighbours of this centre -> one angle, from the canonical
+        // minimum-image vectors of the original float64 positions
+        if (has && n >= 2) {
+            const double *pc = p + (size_t)qc.idx * 3;
+            const double cx = pc[0], cy = pc[1], cz = pc[2];
+            for (int u = 0; u < n - 1; u++) {
+                const double *pu = p + (size_t)nlist[u * NBRF_TILE + tid] * 3;
+                double vx, vy, vz, ax, ay, az;
+                pair_base<ORTHO>(geo, pu[0] - cx, pu[1] - cy, pu[2] - cz, vx, vy, vz);
+                if (!unit_vec(vx, vy, vz, ax, ay, az)) { a.flags[0] = 1; continue; }
+                for (int v = u + 1; v < n; v++) {
+                    const double *pv = p + (size_t)nlist[v * NBRF_TILE + tid] * 3;
+                    double wx, wy, wz, bx, by, bz;
+                    pair_base<ORTHO>(geo, pv[0] - cx, pv[1] - cy, pv[2] - cz, wx, wy, wz);
+                    if (!unit_vec(wx, wy, wz, bx, by, bz)) { a.flags[0] = 1; continue; }
+                    double dot = ax * bx + ay * by + az * bz;
+                    if (dot > 1.0) dot = 1.0;
+                    if (dot < -1.0) dot = -1.0;
+                    const double ang = (180.0 / M_PI) * acos(dot);
+                    nang++;
+                    const int k = hist_bin(a.edges, nb, ang);
+                    if (k >= 0) atomicAdd(&hist[k], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long *H = a.hist + (size_t)trip * nb;
+    for (int k = tid; k < nb; k += NBRF_TILE) {
+        unsigned v = hist[k];
+        if (v) atomicAdd(&H[k], (unsigned long long)v);
+    }
+    for (int off = 32; off > 0; off >>= 1) nang += __shfl_down(nang, off, 64);
+    if ((tid & 63) == 0 && nang) atomicAdd(&a.n_angles[trip], nang);
+}
+
 // ------------------------------------------------------------ host side ----
 struct NbrSetup {
     HostGeom geom;
@@ -325,6 +594,84 @@ static void pick_chunks(int64_t F, size_t nwork, int32_t &fpc, unsigned &chunks)
     chunks = (unsigned)c;
 }
 
+__global__ void add_u64_kernel(unsigned long long *dst, const unsigned long long *src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] += src[i];
+}
+
+// ---- fast-path preparation shared by CN and BAD ----
+struct NbrFast {
+    bool ok = false;
+    int axis = 0;
+    bool ortho = false;
+    int64_t FB = 0;              // frames per batch
+    void *d_Q = nullptr, *d_slab = nullptr, *d_cells = nullptr, *d_spfirst = nullptr, *d_qflag = nullptr;
+    std::vector<int64_t> sp_first;
+    NbrFastArgs fa;
+};
+
+static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cutoff, NbrSetup &st, NbrFast &nf)
+{
+    const int S = t->n_species;
+    const int64_t nc = t->n_cells;
+    const char *force = getenv("AMOF_NBR_KERNEL");
+    double R = 0.0;
+    for (int k = 0; k < S * S; k++) R = std::max(R, cutoff[k]);
+    nf.ok = st.max_img == 0 && t->pbc[0] && t->pbc[1] && t->pbc[2] && R > 0.0 && t->n_atoms > 0 &&
+            !(force && strcmp(force, "v1") == 0);
+    if (!nf.ok) return AMOF_OK;
+    nf.ortho = st.geom.all_ortho;
+    double hmin[3] = {1e300, 1e300, 1e300}, csum = 0.0;
+    for (int64_t k = 0; k < nc; k++) {
+        const double *c = t->cell + 9 * k;
+        for (int x = 0; x < 3; x++) hmin[x] = std::min(hmin[x], st.geom.rec[(size_t)k * GEOM_STRIDE + 18 + x]);
+        csum = std::max(csum, sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) +
+                                  sqrt(c[3] * c[3] + c[4] * c[4] + c[5] * c[5]) +
+                                  sqrt(c[6] * c[6] + c[7] * c[7] + c[8] * c[8]));
+    }
+    nf.axis = 0;
+    for (int x = 1; x < 3; x++)
+        if (hmin[x] > hmin[nf.axis]) nf.axis = x;
+    const int ord[3] = {(nf.axis + 1) % 3, (nf.axis + 2) % 3, nf.axis};
+    const double two32 = 1.0 / 4294967296.0;
+    std::vector<NbrCell> cells((size_t)nc);
+    for (int64_t k = 0; k < nc; k++) {
+        const double *c = t->cell + 9 * k;
+        NbrCell &r = cells[(size_t)k];
+        for (int q = 0; q < 9; q++) r.sc[q] = 0.f;
+        if (nf.ortho) {
+            for (int q = 0; q < 3; q++) r.sc[q] = (float)(c[4 * ord[q]] * two32);
+        } else {
+            for (int q = 0; q < 3; q++)
+                for (int x = 0; x < 3; x++) r.sc[3 * q + x] = (float)(c[3 * ord[q] + x] * two32);
+        }
+        r._pad = 0.f;
+        r.gap_per_len = 4294967296.0 / st.geom.rec[(size_t)k * GEOM_STRIDE + 18 + nf.axis] * (1.0 + 1e-6);
+    }
+    nf.sp_first.assign(S + 1, 0);
+    for (int x = 0; x < S; x++) nf.sp_first[x + 1] = nf.sp_first[x] + st.tiles.nsp[x];
+    int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
+    nf.FB = std::min<int64_t>(std::min<int64_t>(FB, 65535), std::max<int64_t>(1, t->n_frames));
+    AMOF_TRY(upload(ctx, SLOT_AUX4, cells.data(), cells.size() * sizeof(NbrCell), &nf.d_cells));
+    AMOF_TRY(upload(ctx, SLOT_AUX5, nf.sp_first.data(), nf.sp_first.size() * sizeof(int64_t), &nf.d_spfirst));
+    AMOF_TRY(ensure(ctx, SLOT_HISTU, (size_t)nf.FB * t->n_atoms * sizeof(QAtom), &nf.d_Q));
+    AMOF_TRY(ensure(ctx, SLOT_SELF, (size_t)nf.FB * S * (QSLABS + 1) * sizeof(uint32_t), &nf.d_slab));
+    AMOF_TRY(ensure(ctx, SLOT_SPEC, sizeof(int32_t), &nf.d_qflag));
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(nf.d_qflag, 0, sizeof(int32_t), ctx->stream));
+    NbrFastArgs &fa = nf.fa;
+    fa.a = st.a;
+    fa.Q = (const QAtom *)nf.d_Q;
+    fa.slab_start = (const uint32_t *)nf.d_slab;
+    fa.cells = (const NbrCell *)nf.d_cells;
+    fa.sp_first = (const int64_t *)nf.d_spfirst;
+    // f32 chain error <= 3.9e-7 relative (see rdf.hip) + image-choice slack 2e-7 near h/2: 1e-6;
+    // the fixed-point grid moves a distance by < csum * 2^-32 (x2 margin)
+    fa.guard_rel = 1e-6f;
+    fa.guard_abs = (float)(csum * (1.0 / 2147483648.0));
+    return AMOF_OK;
+}
+
 }  // namespace amof
 
 using namespace amof;
@@ -362,7 +709,47 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
     a.n_sets = n_sets;
     a.sums = (unsigned long long *)d_sums;
     a.per_atom = (int32_t *)d_pa;
-    if (!work.empty()) {
+    NbrFast nf;
+    AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf));
+    bool done = false;
+    if (nf.ok) {
+        std::vector<int4> fwork;
+        for (int s2 = 0; s2 < n_sets; s2++) {
+            int A = sets[2 * s2], B = sets[2 * s2 + 1];
+            for (int64_t c0 = 0; c0 < st.tiles.nsp[A]; c0 += NBRF_TILE) fwork.push_back(make_int4(s2, (int)c0, A, B));
+        }
+        void *d_fwork;
+        AMOF_TRY(upload(ctx, SLOT_AUX3, fwork.data(), fwork.size() * sizeof(int4), &d_fwork));
+        nf.fa.a = a;
+        nf.fa.a.work = (const int4 *)d_fwork;
+        int64_t launches = 0;
+        for (int64_t fb = 0; fb < t->n_frames && !fwork.empty(); fb += nf.FB) {
+            const int64_t nfr = std::min<int64_t>(nf.FB, t->n_frames - fb);
+            AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, S,
+                                     t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
+                                     (int32_t *)nf.d_qflag));
+            nf.fa.f_base = (int32_t)fb;
+            nf.fa.nf = (int32_t)nfr;
+            unsigned chunks;
+            pick_chunks(nfr, fwork.size(), nf.fa.a.frames_per_chunk, chunks);
+            dim3 grid((unsigned)fwork.size(), chunks);
+            if (launches == 0) timing_dom_begin(ctx);
+            if (nf.ortho) hipLaunchKernelGGL(cn_fast_kernel<true>, grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
+            else hipLaunchKernelGGL(cn_fast_kernel<false>, grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
+            AMOF_HIP_TRY(ctx, hipGetLastError());
+            launches++;
+        }
+        timing_dom_end(ctx, launches);
+        int32_t qflag = 0;
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nf.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (qflag) {   // atoms absurdly far from the cell: redo with the exact kernel
+            AMOF_HIP_TRY(ctx, hipMemsetAsync(d_sums, 0, F * n_sets * sizeof(int64_t), ctx->stream));
+        } else {
+            done = true;
+        }
+    }
+    if (!done && !work.empty()) {
         unsigned chunks;
         pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
         dim3 grid((unsigned)work.size(), chunks);
@@ -407,7 +794,72 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
     a.hist = hist_dev;
     a.n_angles = nang_dev;
     a.flags = (int32_t *)d_flags;
-    if (!work.empty() && t->n_frames > 0) {
+    NbrFast nf;
+    AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf));
+    bool done = false;
+    if (nf.ok && t->n_frames > 0) {
+        const int S = t->n_species;
+        std::vector<int4> fwork;
+        for (int k = 0; k < T; k++) {
+            int A = triples[2 * k], B = triples[2 * k + 1];
+            for (int sa = 0; sa < S; sa++) {
+                if (!(A < 0 || sa == A)) continue;
+                for (int64_t c0 = 0; c0 < st.tiles.nsp[sa]; c0 += NBRF_TILE) fwork.push_back(make_int4(k, (int)c0, sa, B));
+            }
+        }
+        void *d_fwork;
+        AMOF_TRY(upload(ctx, SLOT_AUX6, fwork.data(), fwork.size() * sizeof(int4), &d_fwork));
+        // the fast kernels accumulate into scratch so that a fallback can start from a clean slate
+        void *d_hs, *d_ns;
+        AMOF_TRY(ensure(ctx, SLOT_AUX7, ((size_t)T * nb + (size_t)T) * sizeof(unsigned long long), &d_hs));
+        AMOF_HIP_TRY(ctx, hipMemsetAsync(d_hs, 0, ((size_t)T * nb + (size_t)T) * sizeof(unsigned long long), ctx->stream));
+        d_ns = (unsigned long long *)d_hs + (size_t)T * nb;
+        nf.fa.a = a;
+        nf.fa.a.work = (const int4 *)d_fwork;
+        nf.fa.a.hist = (unsigned long long *)d_hs;
+        nf.fa.a.n_angles = (unsigned long long *)d_ns;
+        size_t lds = NBRF_TILE * sizeof(uint4) + (size_t)AMOF_MAX_NEIGHBOURS * NBRF_TILE * sizeof(uint32_t) +
+                     (size_t)nb * sizeof(unsigned);
+        int64_t launches = 0;
+        for (int64_t fb = 0; fb < t->n_frames && !fwork.empty(); fb += nf.FB) {
+            const int64_t nfr = std::min<int64_t>(nf.FB, t->n_frames - fb);
+            AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, S,
+                                     t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
+                                     (int32_t *)nf.d_qflag));
+            nf.fa.f_base = (int32_t)fb;
+            nf.fa.nf = (int32_t)nfr;
+            unsigned chunks;
+            pick_chunks(nfr, fwork.size(), nf.fa.a.frames_per_chunk, chunks);
+            dim3 grid((unsigned)fwork.size(), chunks);
+            if (launches == 0) timing_dom_begin(ctx);
+            hipError_t e;
+            if (nf.ortho) {
+                e = hipFuncSetAttribute((const void *)bad_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) hipLaunchKernelGGL(bad_fast_kernel<true>, grid, dim3(NBRF_TILE), lds, ctx->stream, nf.fa);
+            } else {
+                e = hipFuncSetAttribute((const void *)bad_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) hipLaunchKernelGGL(bad_fast_kernel<false>, grid, dim3(NBRF_TILE), lds, ctx->stream, nf.fa);
+            }
+            AMOF_HIP_TRY(ctx, e);
+            AMOF_HIP_TRY(ctx, hipGetLastError());
+            launches++;
+        }
+        timing_dom_end(ctx, launches);
+        int32_t qflag = 0;
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nf.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!qflag) {
+            hipLaunchKernelGGL(add_u64_kernel, dim3(64), dim3(256), 0, ctx->stream, hist_dev,
+                               (const unsigned long long *)d_hs, (size_t)T * nb);
+            hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, nang_dev,
+                               (const unsigned long long *)d_ns, (size_t)T);
+            AMOF_HIP_TRY(ctx, hipGetLastError());
+            done = true;
+        } else {   // atoms absurdly far from the cell: redo with the exact kernel
+            AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 2 * sizeof(int32_t), ctx->stream));
+        }
+    }
+    if (!done && !work.empty() && t->n_frames > 0) {
         unsigned chunks;
         pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
         dim3 grid((unsigned)work.size(), chunks);

@@ -1,0 +1,96 @@
+// Fixed-point folding + slab counting sort shared by the RDF and neighbour fast paths.
+#include <math.h>
+
+#include "amof_internal.h"
+
+namespace amof {
+
+__device__ __forceinline__ QAtom quantize_atom(const double *__restrict__ pos, const double *__restrict__ g,
+                                                int64_t N, int f, int64_t a, int ax0, int ax1, int ax2,
+                                                int32_t *flag)
+{
+    const double *__restrict__ p = pos + ((size_t)f * N + a) * 3;
+    const double x = p[0], y = p[1], z = p[2];
+    uint32_t u[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double s = fma(z, g[15 + c], fma(y, g[12 + c], x * g[9 + c]));
+        if (!(fabs(s) < 1.0e4)) *flag = 1;   // absurdly far from the cell (or NaN): caller falls back
+        s = s - floor(s);
+        double t = s * 4294967296.0;
+        u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    }
+    // components are stored in the order (ax0, ax1, ax2): the host puts the slab axis last
+    QAtom q;
+    q.ux = u[ax0]; q.uy = u[ax1]; q.uz = u[ax2]; q.idx = (uint32_t)a;
+    return q;
+}
+
+// One workgroup per (species, frame): fold the atoms into the cell, quantise to 2^-32 of
+// the cell vectors, and counting-sort the species segment into 256 slabs along cell axis
+// `axis` (order inside a slab is arbitrary -- every result downstream is an integer count,
+// independent of the order).  slab_start (optional) [nf][S][SLABS+1]: offset, relative to
+// the species segment, of the first atom of every slab.
+__global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict__ pos,
+                                                       const double *__restrict__ geom, int n_cells,
+                                                       const int32_t *__restrict__ perm,
+                                                       const int64_t *__restrict__ sp_first, int S, int64_t N,
+                                                       int f0, int axis, QAtom *__restrict__ Q,
+                                                       uint32_t *__restrict__ slab_start, int32_t *flag)
+{
+    __shared__ unsigned cnt[QSLABS];
+    __shared__ unsigned wsum[4];
+    const int sp = blockIdx.x, fl = blockIdx.y, tid = threadIdx.x;
+    const int f = f0 + fl;
+    const int ax0 = (axis + 1) % 3, ax1 = (axis + 2) % 3;   // stored order: (ax0, ax1, axis)
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const int64_t k0 = sp_first[sp], k1 = sp_first[sp + 1];
+    cnt[tid] = 0u;
+    __syncthreads();
+    for (int64_t k = k0 + tid; k < k1; k += 256) {
+        const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        atomicAdd(&cnt[q.uz >> 24], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 256 counters (one per thread)
+    unsigned v = cnt[tid], incl = v;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wv; w++) base += wsum[w];
+    __syncthreads();
+    const unsigned excl = base + incl - v;
+    cnt[tid] = excl;
+    if (slab_start) {
+        uint32_t *st = slab_start + ((size_t)fl * S + sp) * (QSLABS + 1);
+        st[tid] = excl;
+        if (tid == 255) st[QSLABS] = excl + v;
+    }
+    __syncthreads();
+    QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
+    for (int64_t k = k0 + tid; k < k1; k += 256) {
+        const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        const unsigned slot = atomicAdd(&cnt[q.uz >> 24], 1u);
+        Qf[slot] = q;
+    }
+}
+
+int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
+                    const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis, QAtom *d_Q,
+                    uint32_t *d_slab_start, int32_t *d_flag)
+{
+    if (nf <= 0 || S <= 0) return AMOF_OK;
+    if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
+    dim3 qgrid((unsigned)S, (unsigned)nf);
+    hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(256), 0, ctx->stream, pos_dev, d_geom, n_cells, d_perm, d_spfirst,
+                       S, N, f0, axis, d_Q, d_slab_start, d_flag);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    return AMOF_OK;
+}
+
+}  // namespace amof

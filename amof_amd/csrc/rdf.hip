@@ -194,78 +194,6 @@ __global__ __launch_bounds__(RDF_TILE) void rdf_tile_kernel_global(RdfArgs a)
 // with the canonical f64 arithmetic and exact sqrt/divide.  Where the two
 // disagree on the periodic image (|s_k| ~ 1/2) both distances are >= rmax(1-2e-7),
 // i.e. inside the guard of nbins, so the slow path decides those too.
-struct QAtom {
-    uint32_t ux, uy, uz, idx;
-};
-
-__device__ __forceinline__ QAtom quantize_atom(const double *__restrict__ pos, const double *__restrict__ g,
-                                                int64_t N, int f, int64_t a, int ax0, int ax1, int ax2,
-                                                int32_t *flag)
-{
-    const double *__restrict__ p = pos + ((size_t)f * N + a) * 3;
-    const double x = p[0], y = p[1], z = p[2];
-    uint32_t u[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        double s = fma(z, g[15 + c], fma(y, g[12 + c], x * g[9 + c]));
-        if (!(fabs(s) < 1.0e4)) *flag = 1;   // absurdly far from the cell (or NaN): caller falls back
-        s = s - floor(s);
-        double t = s * 4294967296.0;
-        u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
-    }
-    // components are stored in the order (ax0, ax1, ax2): the host puts the slab axis last
-    QAtom q;
-    q.ux = u[ax0]; q.uy = u[ax1]; q.uz = u[ax2]; q.idx = (uint32_t)a;
-    return q;
-}
-
-// One workgroup per (species, frame): fold the atoms into the cell, quantise, and
-// counting-sort the species segment into 256 slabs along cell axis `axis`
-// (order inside a slab is arbitrary -- every result downstream is an integer
-// count, independent of the order).
-constexpr int SLABS = 256;
-__global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict__ pos,
-                                                       const double *__restrict__ geom, int n_cells,
-                                                       const int32_t *__restrict__ perm,
-                                                       const int64_t *__restrict__ sp_first, int64_t N, int f0,
-                                                       int axis, QAtom *__restrict__ Q, int32_t *flag)
-{
-    __shared__ unsigned cnt[SLABS];
-    __shared__ unsigned wsum[4];
-    const int sp = blockIdx.x, fl = blockIdx.y, tid = threadIdx.x;
-    const int f = f0 + fl;
-    const int ax0 = (axis + 1) % 3, ax1 = (axis + 2) % 3;   // stored order: (ax0, ax1, axis)
-    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
-    const int64_t k0 = sp_first[sp], k1 = sp_first[sp + 1];
-    cnt[tid] = 0u;
-    __syncthreads();
-    for (int64_t k = k0 + tid; k < k1; k += 256) {
-        const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
-        atomicAdd(&cnt[q.uz >> 24], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the 256 counters (one per thread)
-    unsigned v = cnt[tid], incl = v;
-    const int lane = tid & 63, wv = tid >> 6;
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned n = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += n;
-    }
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    unsigned base = 0;
-    for (int w = 0; w < wv; w++) base += wsum[w];
-    __syncthreads();
-    cnt[tid] = base + incl - v;
-    __syncthreads();
-    QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
-    for (int64_t k = k0 + tid; k < k1; k += 256) {
-        const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
-        const unsigned slot = atomicAdd(&cnt[q.uz >> 24], 1u);
-        Qf[slot] = q;
-    }
-}
-
 // per-cell record of the fast path (one per frame when the cell changes)
 struct FrameScale {
     float sc[9];        // ORTHO: sc[0..2] = L_k * 2^-32 / dr ; else cell[k][c] * 2^-32 / dr (rows in stored order)
@@ -742,12 +670,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             int64_t launches = 0;
             for (int64_t fb = 0; fb < t->n_frames; fb += FB) {
                 const int64_t nf = std::min<int64_t>(FB, t->n_frames - fb);
-                dim3 qgrid((unsigned)S, (unsigned)nf);
-                hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(256), 0, ctx->stream, pos_dev,
-                                   (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm,
-                                   (const int64_t *)d_spfirst, t->n_atoms, (int)fb, axis, (QAtom *)d_Q,
-                                   (int32_t *)d_flag);
-                AMOF_HIP_TRY(ctx, hipGetLastError());
+                AMOF_TRY(launch_quantize(ctx, pos_dev, (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm,
+                                         (const int64_t *)d_spfirst, S, t->n_atoms, (int)fb, (int)nf, axis, (QAtom *)d_Q,
+                                         nullptr, (int32_t *)d_flag));
                 fa.f_base = (int32_t)fb;
                 fa.nf = (int32_t)nf;
                 int64_t want_chunks = (8 * 2048 + 4 * (int64_t)fpairs.size() - 1) / (4 * (int64_t)fpairs.size());

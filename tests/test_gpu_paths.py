@@ -1,0 +1,127 @@
+"""Every kernel family has an exact (brute-force, canonical float64) path and a fast path
+(fixed-point minimum image, slab culling, f32 prefilter with exact refinement).  Both must
+give identical integers; the exact one is also what partially periodic / tiny cells use."""
+
+import os
+
+import numpy as np
+import pytest
+
+from amof_amd.frames import PackedTrajectory
+from oracle import clib
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+class _env(object):
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _traj(kind):
+    z = H.zif4_frame()
+    if kind == "elongated":       # 2x1x4 supercell: slab culling along z is active (2 rmax < Lz)
+        return H.random_walk(H.replicate(z, (2, 1, 4)), 3, 0.05, 31, ortho=True), 6.0, 600
+    if kind == "elongated_tri":
+        return H.random_walk(H.replicate(z, (1, 1, 3)), 3, 0.05, 32), 5.0, 417
+    if kind == "npt":
+        return H.random_walk(H.replicate(z, (1, 1, 2)), 6, 0.05, 33, cell_jitter=0.01), 7.0, 700
+    return H.random_walk(z, 4, 0.05, 34), 7.7, 770
+
+
+@pytest.mark.parametrize("kind", ["elongated", "elongated_tri", "npt", "cubicish"])
+def test_rdf_fast_equals_exact_equals_oracle(hip_ctx, kind):
+    packed, rmax, nb = _traj(kind)
+    fast, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+    with _env(AMOF_RDF_NOCULL="1"):
+        nocull, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+    with _env(AMOF_RDF_KERNEL="v1"):
+        exact, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+    kinds, sp = H.species_of(packed.numbers)
+    ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
+    assert np.array_equal(fast, ref) and np.array_equal(nocull, ref) and np.array_equal(exact, ref)
+
+
+def test_rdf_lattice_pairs_on_bin_edges(hip_ctx):
+    # every distance of a perfect lattice sits on (or within rounding of) a bin edge: the
+    # fast path must push all of them through the exact refinement and still agree
+    a, n = 2.0, 8
+    g = np.arange(n) * a
+    pos = np.array([[x, y, z] for x in g for y in g for z in g], dtype=float)
+    packed = PackedTrajectory(np.stack([pos, pos + 0.25]), np.diag([n * a] * 3), np.ones(len(pos), int))
+    for rmax, nb in [(7.9, 79), (8.0, 800), (6.0, 6)]:
+        h, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, np.zeros(len(pos), np.int32), 1, rmax, nb)
+        assert np.array_equal(h, ref)
+
+
+@pytest.mark.parametrize("kind", ["elongated", "elongated_tri", "npt"])
+def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
+    packed, _, _ = _traj(kind)
+    kinds, sp = H.species_of(packed.numbers)
+    S = len(kinds)
+    zn, n, c, h = kinds.index(30), kinds.index(7), kinds.index(6), kinds.index(1)
+    rcm = np.zeros((S, S))
+    rcm[zn, n] = rcm[n, zn] = 2.5
+    rcm[c, n] = rcm[n, c] = 1.6
+    rcm[c, h] = rcm[h, c] = 1.3
+    rcm[c, c] = 1.7
+    sets = [(zn, n), (n, zn), (c, n), (c, c), (h, c)]
+    triples = [(zn, n), (n, -1), (-1, -1), (c, c), (c, -1)]
+    edges = np.arange(int(180 // 0.5) + 2) * 0.5
+    s_fast, pa_fast = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+    h_fast, a_fast = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    with _env(AMOF_NBR_KERNEL="v1"):
+        s_ex, pa_ex = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+        h_ex, a_ex = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
+    h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
+    assert np.array_equal(s_fast, s_ref) and np.array_equal(pa_fast, pa_ref)
+    assert np.array_equal(s_ex, s_ref) and np.array_equal(pa_ex, pa_ref)
+    assert np.array_equal(a_fast, a_ref) and np.array_equal(h_fast, h_ref)
+    assert np.array_equal(a_ex, a_ref) and np.array_equal(h_ex, h_ref)
+    assert a_ref.sum() > 0
+
+
+def test_pairs_exactly_at_the_cutoff(hip_ctx):
+    # simple cubic lattice, cutoff exactly the lattice constant: strict '<' excludes the shell;
+    # one ulp more includes it.  The f32 prefilter cannot tell: the exact re-decision must.
+    a, n = 2.0, 8
+    g = np.arange(n) * a
+    pos = np.array([[x, y, z] for x in g for y in g for z in g], dtype=float)
+    packed = PackedTrajectory(pos[None] + 0.125, np.diag([n * a] * 3), np.ones(len(pos), int))
+    for rc, want in [(a, 0), (np.nextafter(a, 10.0), 6), (a * np.sqrt(2.0), 6), (1.5 * a, 18)]:
+        sums = hip_ctx.cn_count(packed, [[rc]], [(0, 0)])
+        ref = clib.cn_counts(packed.pos, packed.cell, np.zeros(len(pos), np.int32), 1, [[rc]], [(0, 0)])
+        assert sums[0, 0] == ref[0, 0]
+        if want is not None and rc != a * np.sqrt(2.0):
+            assert sums[0, 0] == want * len(pos)
+
+
+def test_far_away_atoms_fall_back(hip_ctx):
+    # coordinates > 1e4 cells from the origin defeat the fixed-point fold: the library must
+    # notice and answer through the exact kernels
+    packed = H.random_walk(H.zif4_frame(), 2, 0.05, 35)
+    far = PackedTrajectory(packed.pos + np.array([2.0e5 * packed.cell[0, 0, 0], 0, 0]), packed.cell, packed.numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    h, _, _ = hip_ctx.rdf_accumulate(far, 6.0, 60)
+    ref, _ = clib.rdf_hist(far.pos, far.cell, sp, len(kinds), 6.0, 60)
+    assert np.array_equal(h, ref)
+    rcm = np.zeros((4, 4)); rcm[2, 3] = rcm[3, 2] = 2.5
+    assert np.array_equal(hip_ctx.cn_count(far, rcm, [(3, 2)]), clib.cn_counts(far.pos, far.cell, sp, 4, rcm, [(3, 2)]))
+    edges = np.arange(181.0)
+    hb, ab = hip_ctx.bad_hist(far, rcm, [(3, 2)], edges)
+    hr, ar = clib.bad_hist(far.pos, far.cell, sp, 4, rcm, [(3, 2)], edges)
+    assert np.array_equal(ab, ar) and np.array_equal(hb, hr)
