@@ -359,8 +359,16 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     unsigned *hist = reinterpret_cast<unsigned *>(tcb + 2 * FAST_SUB);       // [nbins]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int2 pr = a.pairs[blockIdx.x >> 2];
-    const int sub = blockIdx.x & 3;
+    // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8), each
+    // with its own 4 MiB L2.  All work items of one frame chunk go to the same XCD so that the
+    // chunk's quantised frames (16 frames x 16 B x N) are re-read from that L2, not from the
+    // fabric.  Pure bijection of the grid: correctness does not depend on the placement.
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = lin & 7u, kk = lin >> 3;
+    const unsigned chunk = (kk / gridDim.x) * 8u + xcd, bx = kk % gridDim.x;
+    if ((int)(chunk * a.frames_per_chunk) >= fa.nf) return;
+    const int2 pr = a.pairs[bx >> 2];
+    const int sub = bx & 3;
     const Tile ti = a.tiles[pr.x];
     const Tile tj = a.tiles[pr.y];
     const bool diag = pr.x == pr.y;
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const int nbins = a.nbins;
     for (int k = tid; k < nbins; k += FAST_THREADS) hist[k] = 0u;
 
-    const int f0 = blockIdx.y * a.frames_per_chunk;
+    const int f0 = chunk * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
     // two adjacent centre atoms per lane (adjacent = close in slab order); same in every wave
     const int cnti = min(FAST_SUB, ti.count - sub * FAST_SUB);     // centre atoms of this sub-tile
@@ -677,8 +685,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.nf = (int32_t)nf;
                 int64_t want_chunks = (8 * 2048 + 4 * (int64_t)fpairs.size() - 1) / (4 * (int64_t)fpairs.size());
                 int64_t fpc = std::max<int64_t>(1, nf / std::max<int64_t>(1, want_chunks));
-                fpc = std::min<int64_t>(fpc, 32);
+                fpc = std::min<int64_t>(fpc, 16);
                 int64_t chunks = (nf + fpc - 1) / fpc;
+                chunks = (chunks + 7) / 8 * 8;      // the XCD mapping deals chunks in groups of 8
                 fa.a.frames_per_chunk = (int32_t)fpc;
                 dim3 grid((unsigned)(4 * fpairs.size()), (unsigned)chunks);
                 if (launches == 0) timing_dom_begin(ctx);
