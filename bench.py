@@ -153,10 +153,11 @@ def main():
     def step():
         rdf = Rdf.from_trajectory(packed, device=local_rank, distributed=mode)
         t_rdf = ctx.last_kernel_seconds(dominant=True)
+        t_rdf_all = ctx.last_kernel_seconds(dominant=False)
         msd = WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=local_rank, distributed=mode)
         t_msd_dom = ctx.last_kernel_seconds(dominant=True)
         t_msd_all = ctx.last_kernel_seconds(dominant=False)
-        return rdf, msd, t_rdf, t_msd_dom, t_msd_all
+        return rdf, msd, t_rdf, t_msd_dom, t_msd_all, t_rdf_all
 
     for _ in range(args.warmup):
         step()
@@ -169,10 +170,10 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    k_rdf, k_msd_dom, k_msd_all = [], [], []
+    k_rdf, k_msd_dom, k_msd_all, k_rdf_all = [], [], [], []
     for _ in range(args.steps):
-        rdf, msd, a, b, c = step()
-        k_rdf.append(a); k_msd_dom.append(b); k_msd_all.append(c)
+        rdf, msd, a, b, c, d = step()
+        k_rdf.append(a); k_msd_dom.append(b); k_msd_all.append(c); k_rdf_all.append(d)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -188,6 +189,13 @@ def main():
         alg_bytes = F * (24 * N + 72)                      # 24N+72 bytes per frame per pass
         pairs = F * N * (N - 1) / 2.0                      # unordered pair evaluations per launch
         in_range = float(rdf.hist.sum()) / 2.0 / world if world > 1 else float(rdf.hist.sum()) / 2.0
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied),
+        # recorded under profiles/ for this exact workload; null for any other size
+        traffic = {}
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile) and (N, F) == (9792, 5000):
+            with open(tfile) as fh:
+                traffic = json.load(fh).get("cfg3", {})
         out = {
             "metric": "frames/s (RDF+MSD, 10k-atom ZIF-4)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,18 +206,21 @@ def main():
                                    % (N, reps[0], reps[1], reps[2], F, rmax, nbins, len(msd.data)),
                        "n_atoms": N, "frames_per_gpu": F, "rdf_bins": nbins, "msd_windows": len(msd.data),
                        "parallelism": "frames x%d, RCCL all-reduce of u64 histograms" % world},
-            "roofline": {"kernel": "rdf_tile_kernel", "bound": "hbm", "achieved": alg_bytes / t_rdf / 1e9,
+            "roofline": {"kernel": "rdf_tile_kernel_fast", "bound": "hbm", "achieved": alg_bytes / t_rdf / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / t_rdf / 1e9 / HBM_PEAK_GBPS,
-                         "traffic": None, "launch_seconds": t_rdf, "algorithmic_bytes": alg_bytes,
-                         "note": "all-pairs RDF at half-cell rmax is pair-evaluation bound, not HBM bound "
-                                 "(SURVEY 8d); see pair_evals_per_s"},
+                         "traffic": traffic.get("rdf_tile_kernel_fast"), "launch_seconds": t_rdf,
+                         "algorithmic_bytes": alg_bytes,
+                         "note": "all-pairs RDF at half-cell rmax does N(N-1)/2 = 4.8e7 pair evaluations per 235 kB "
+                                 "frame: VALU-issue bound, not HBM bound (SURVEY 8d, DESIGN 4.1); the honest HBM "
+                                 "fraction is tiny by construction -- see pair_evals_per_s"},
             "pair_evals_per_s": pairs / t_rdf, "pairs_in_range_per_s": in_range / t_rdf,
             "roofline_msd": {"kernel": "msd pipeline (com + delta_transpose + msd_group + reduce)", "bound": "hbm",
                              "achieved": alg_bytes / float(np.mean(k_msd_all)) / 1e9, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": alg_bytes / float(np.mean(k_msd_all)) / 1e9 / HBM_PEAK_GBPS,
-                             "traffic": None, "pipeline_seconds": float(np.mean(k_msd_all)),
+                             "traffic": traffic.get("msd_pipeline"), "pipeline_seconds": float(np.mean(k_msd_all)),
                              "msd_group_kernel_seconds": float(np.mean(k_msd_dom))},
-            "kernel_seconds_per_step": {"rdf_tile": t_rdf, "msd_all": float(np.mean(k_msd_all))},
+            "kernel_seconds_per_step": {"rdf_tile": t_rdf, "rdf_all_incl_quantize": float(np.mean(k_rdf_all)),
+                                        "msd_all": float(np.mean(k_msd_all))},
         }
         if world == 1 and not args.no_cpu_baseline:
             window = np.arange(0, (F // 2), 100)
