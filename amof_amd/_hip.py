@@ -31,6 +31,7 @@ EXPORTS = [
     "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_last_kernel_seconds", "amof_last_kernel_launches",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_msd_window",
+    "amof_xyz_scan", "amof_xyz_read", "amof_cp2k_cell_read", "amof_ingest_last_error",
 ]
 
 
@@ -94,6 +95,11 @@ def load_library():
         lib.amof_bad_hist_dev.argtypes = lib.amof_bad_hist.argtypes
         lib.amof_msd_window.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int64, ctypes.c_int64, P]
+        lib.amof_xyz_scan.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        lib.amof_xyz_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, P, P, P,
+                                      ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]
+        lib.amof_cp2k_cell_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, P, ctypes.POINTER(ctypes.c_int64)]
+        lib.amof_ingest_last_error.restype = ctypes.c_char_p
         if lib.amof_abi_version() != ABI_VERSION:
             raise RuntimeError("libamofhip.so ABI version %d, expected %d" % (lib.amof_abi_version(), ABI_VERSION))
         _lib = lib

@@ -1,13 +1,172 @@
 """Trajectory helpers on the hot path (mirror of reference amof/trajectory.py).
 
-Only ``construct_step`` (amof/trajectory.py:244-283) is host logic here;
-``get_delta_pos`` (amof/trajectory.py:285-303) runs inside the MSD kernels."""
+``construct_step`` (amof/trajectory.py:244-283) is host logic;
+``get_delta_pos`` (amof/trajectory.py:285-303) runs inside the MSD kernels.
 
+Ingest: ``read_lammps_traj`` / ``read_cp2k_traj`` keep the
+reference's signatures (amof/trajectory.py:193-228) but return a
+:class:`amof_amd.frames.PackedTrajectory` -- the arrays the kernels consume --
+parsed by the native reader in ``libamofhip.so`` instead of a Python list of
+``ase.Atoms`` built by ``ase.io.read``.  ``.to_frames()`` gives ``Frame`` objects
+when a list is wanted."""
+
+import ctypes
 import logging
 
 import numpy as np
 
+from . import data as _data
+from .frames import PackedTrajectory
+
 logger = logging.getLogger(__name__)
+
+
+def string2index(string):
+    """ase.io.formats.string2index: 'a:b:c' -> slice, '3' -> 3"""
+    if ':' not in string:
+        return int(string)
+    i = []
+    for s in string.split(':'):
+        i.append(None if s == '' else int(s))
+    i += (3 - len(i)) * [None]
+    return slice(*i)
+
+
+def _ingest_error(lib, rc):
+    msg = lib.amof_ingest_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    raise RuntimeError("libamofhip ingest error %d: %s" % (rc, msg))
+
+
+def read_xyz(path, index=None, n_threads=0):
+    """Read an XYZ / extended-XYZ trajectory into packed arrays.
+
+    Args:
+        index: like ``ase.io.read``: None or int -> that single frame (None = the
+            last one, ASE's default), slice or 'first:last:step' -> those frames
+    Returns:
+        (pos[F][N][3] f64, numbers[N] int64, lattice[F][3][3] or None)
+    """
+    from . import _hip
+    lib = _hip.load_library()
+    bpath = str(path).encode()
+    nf, na = ctypes.c_int64(0), ctypes.c_int64(0)
+    rc = lib.amof_xyz_scan(bpath, ctypes.byref(nf), ctypes.byref(na))
+    if rc:
+        _ingest_error(lib, rc)
+    F, N = nf.value, na.value
+    if isinstance(index, str):
+        index = string2index(index)
+    if index is None:
+        index = -1
+    if isinstance(index, slice):
+        first, stop, step = index.indices(F)
+        count = len(range(first, stop, step))
+    else:
+        first = index + F if index < 0 else index
+        if not 0 <= first < F:
+            raise IndexError("frame %d out of range (%d frames)" % (index, F))
+        count, step = 1, 1
+    pos = np.empty((count, N, 3), dtype=np.float64)
+    symbols = np.zeros((N, 4), dtype=np.uint8)
+    lattice = np.zeros((count, 9), dtype=np.float64)
+    has = ctypes.c_int32(0)
+    if count:
+        rc = lib.amof_xyz_read(bpath, first, count, step, ctypes.c_void_p(pos.ctypes.data),
+                               ctypes.c_void_p(symbols.ctypes.data), ctypes.c_void_p(lattice.ctypes.data),
+                               ctypes.byref(has), int(n_threads))
+        if rc:
+            _ingest_error(lib, rc)
+    names = [bytes(row).split(b"\0")[0].decode() for row in symbols]
+    numbers = np.array([_data.atomic_numbers[s.capitalize()] for s in names], dtype=np.int64)
+    return pos, numbers, (lattice.reshape(count, 3, 3) if has.value else None)
+
+
+def read_cp2k_cell(path_to_cell):
+    """CP2K cell log -> cell[rows][3][3] (columns [2:-1], amof/trajectory.py:217-224)"""
+    from . import _hip
+    lib = _hip.load_library()
+    bpath = str(path_to_cell).encode()
+    n = ctypes.c_int64(0)
+    rc = lib.amof_cp2k_cell_read(bpath, 0, None, ctypes.byref(n))
+    if rc:
+        _ingest_error(lib, rc)
+    cell = np.empty((n.value, 9), dtype=np.float64)
+    rc = lib.amof_cp2k_cell_read(bpath, n.value, ctypes.c_void_p(cell.ctypes.data), ctypes.byref(n))
+    if rc:
+        _ingest_error(lib, rc)
+    return cell.reshape(-1, 3, 3)
+
+
+def _fit(pos, cell):
+    """Trajectory.set_cell(fit_size=True): trim to the shorter of the two (amof/trajectory.py:104-113)"""
+    if len(pos) != len(cell):
+        logger.warning("Mismatch in file sizes; traj: %s vs cell: %s", len(pos), len(cell))
+        n = min(len(pos), len(cell))
+        pos, cell = pos[:n], cell[:n]
+    return pos, cell
+
+
+def read_lammps_traj(path_to_xyz, index=None, cell=None, unzip_xyz=False):
+    """
+    Args:
+        index: 'first_frame:last_frame:step' or slice(first_frame, last_frame, step)
+        cell: cell vectors, one per frame read (or a single 3x3); if None the extended-XYZ
+            Lattice is used when present
+    Returns:
+        PackedTrajectory (pbc = True, as Trajectory.set_cell does)
+    """
+    if unzip_xyz:
+        raise NotImplementedError("gunzip the file first; the native reader maps the file")
+    pos, numbers, lattice = read_xyz(path_to_xyz, index)
+    if cell is None:
+        if lattice is None:
+            raise ValueError("no cell given and the file carries no Lattice")
+        cell = lattice
+    cell = np.asarray(cell, dtype=np.float64)
+    if cell.ndim == 3:
+        pos, cell = _fit(pos, cell)
+    return PackedTrajectory(pos, cell, numbers, pbc=(True, True, True))
+
+
+def read_cp2k_traj(path_to_xyz, path_to_cell, index=None, unzip_xyz=False):
+    """
+    Args:
+        index: slice(first_frame, last_frame, step) (or an int / None like the reference)
+    Returns:
+        PackedTrajectory with one cell per frame (pbc = True)
+    """
+    if unzip_xyz:
+        raise NotImplementedError("gunzip the file first; the native reader maps the file")
+    pos, numbers, _ = read_xyz(path_to_xyz, index)
+    cell = read_cp2k_cell(path_to_cell)
+    if isinstance(index, str):
+        index = string2index(index)
+    if isinstance(index, slice):
+        cell = cell[index]
+    elif index is None:
+        cell = cell[-1:] if len(pos) == 1 else cell
+    else:
+        cell = cell[index:index + 1] if index != -1 else cell[-1:]
+    pos, cell = _fit(pos, cell)
+    return PackedTrajectory(pos, cell, numbers, pbc=(True, True, True))
+
+
+def write_xyz(path, packed, comment_lattice=True, fmt="%.10f"):
+    """Write a PackedTrajectory as (extended) XYZ -- test / example helper."""
+    pos = packed.pos_host()
+    syms = [_data.chemical_symbols[int(z)] for z in packed.numbers]
+    with open(path, "w") as fh:
+        for k in range(packed.n_frames):
+            fh.write("%d\n" % packed.n_atoms)
+            if comment_lattice:
+                c = packed.cell_of(k).reshape(-1)
+                fh.write('Lattice="%s" Properties=species:S:1:pos:R:3\n' % " ".join(repr(float(x)) for x in c))
+            else:
+                fh.write("frame %d\n" % k)
+            for s, p in zip(syms, pos[k]):
+                fh.write(("%s " + fmt + " " + fmt + " " + fmt + "\n") % (s, p[0], p[1], p[2]))
 
 
 def construct_step(**kwargs):

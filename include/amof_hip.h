@@ -161,6 +161,26 @@ int amof_msd_window(amof_ctx *ctx, const amof_traj *traj, const int32_t *windows
                     int32_t unwrap, int32_t remove_com, int64_t atom_begin, int64_t atom_end,
                     double *sumsq /* host [S][W] */);
 
+/*
+ * Trajectory ingest (host only).
+ * Replaces, for the packed path, ase.io.read(filename, index, format='xyz') as driven by
+ * Trajectory.from_traj / read_lammps_traj / read_cp2k_traj (amof/trajectory.py:37-60,193-228)
+ * and np.genfromtxt on the CP2K cell log (amof/trajectory.py:217).
+ *   amof_xyz_scan: number of frames and atoms per frame (all frames must agree).
+ *   amof_xyz_read: frames first, first+step, ... (count of them) into pos[count][N][3];
+ *       symbols[N][4] (NUL padded) from the first frame read; lattice[count][9] (may be NULL)
+ *       receives extended-XYZ Lattice="..." when every frame carries one (*has_lattice = 1).
+ *       n_threads <= 0: all hardware threads.  Numbers are parsed correctly rounded.
+ *   amof_cp2k_cell_read: columns [2:-1] (Ax..Cz) of every data row into cell[rows][9];
+ *       cell == NULL only counts rows.
+ * Errors: negative code, message via amof_ingest_last_error() (thread local).
+ */
+int amof_xyz_scan(const char *path, int64_t *n_frames, int64_t *n_atoms);
+int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, double *pos,
+                  char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads);
+int amof_cp2k_cell_read(const char *path, int64_t max_rows, double *cell, int64_t *n_rows);
+const char *amof_ingest_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ from tests.conftest import ROOT
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _hip.load_library()
     header = open(os.path.join(ROOT, "include", "amof_hip.h")).read()
-    declared = set(re.findall(r"\b(amof_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(amof_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name

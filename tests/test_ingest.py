@@ -1,0 +1,90 @@
+"""Native trajectory ingest: host-only entry points of libamofhip.so."""
+
+import os
+
+import numpy as np
+import pytest
+
+from amof_amd import trajectory as T
+from amof_amd.frames import PackedTrajectory
+from tests import helpers as H
+from tests.conftest import GOLDEN
+
+
+def test_cp2k_cell_equals_genfromtxt():
+    path = os.path.join(GOLDEN, "toy_trajectory_200.cell")       # first 200 rows of the reference's example file
+    cell = T.read_cp2k_cell(path)
+    ref = np.genfromtxt(path)[:, 2:-1].reshape(-1, 3, 3)         # what the reference does (amof/trajectory.py:217-224)
+    assert cell.shape == (200, 3, 3) and np.array_equal(cell, ref)
+
+
+def test_xyz_fixture_bitwise():
+    z = H.zif4_frame()                                           # parsed by the pure-Python reader (float())
+    pos, numbers, lattice = T.read_xyz(os.path.join(GOLDEN, "ZIF-4.xyz"), 0)
+    assert np.array_equal(pos[0], z.positions) and np.array_equal(numbers, z.numbers)
+    assert np.array_equal(lattice[0], z.cell)
+
+
+@pytest.mark.parametrize("fmt", ["%.17g", "%.8f", "%15.8E", "%g"])
+def test_xyz_round_trip_is_correctly_rounded(tmp_path, fmt):
+    rng = np.random.default_rng(3)
+    z = H.zif4_frame()
+    pos = rng.normal(scale=[1e-3, 30.0, 5e4], size=(7, 272, 3))
+    packed = PackedTrajectory(pos, z.cell, z.numbers)
+    path = str(tmp_path / "t.xyz")
+    T.write_xyz(path, packed, fmt=fmt)
+    got = T.read_lammps_traj(path, ":")
+    want = np.array([[[float(fmt % v) for v in atom] for atom in frame] for frame in pos])
+    assert np.array_equal(got.pos, want)                         # same doubles as Python's float()
+    assert np.array_equal(got.cell, packed.cell) and np.array_equal(got.numbers, z.numbers)
+    assert got.pbc.all()
+
+
+def test_index_semantics_like_ase(tmp_path):
+    packed = H.random_walk(H.zif4_frame(), 23, 0.1, 4, cell_jitter=0.01)
+    path = str(tmp_path / "t.xyz")
+    T.write_xyz(path, packed, fmt="%.17g")
+    assert np.array_equal(T.read_lammps_traj(path, "3:20:4").pos, packed.pos[3:20:4])
+    assert np.array_equal(T.read_lammps_traj(path, slice(None, None, -5)).pos, packed.pos[::-5])
+    assert np.array_equal(T.read_lammps_traj(path, slice(5, 9)).cell, packed.cell[5:9])
+    last = T.read_lammps_traj(path)                              # ase.io.read default: the last frame
+    assert last.n_frames == 1 and np.array_equal(last.pos[0], packed.pos[-1])
+    assert np.array_equal(T.read_lammps_traj(path, 2).pos[0], packed.pos[2])
+    assert T.string2index("4") == 4 and T.string2index("1::2") == slice(1, None, 2)
+    with pytest.raises(IndexError):
+        T.read_xyz(path, 99)
+
+
+def test_read_cp2k_traj(tmp_path):
+    packed = H.random_walk(H.zif4_frame(), 12, 0.1, 5)
+    xyz = str(tmp_path / "pos.xyz")
+    T.write_xyz(xyz, packed, comment_lattice=False, fmt="%.12f")
+    cellfile = os.path.join(GOLDEN, "toy_trajectory_200.cell")
+    traj = T.read_cp2k_traj(xyz, cellfile, slice(2, 10, 3))
+    ref = np.genfromtxt(cellfile)[:, 2:-1].reshape(-1, 3, 3)
+    assert traj.n_frames == 3 and np.array_equal(traj.cell, ref[2:10:3])
+    full = T.read_cp2k_traj(xyz, cellfile, ":")                  # 12 frames vs 200 cell rows: trimmed like set_cell
+    assert full.n_frames == 12 and np.array_equal(full.cell, ref[:12])
+    frames = full.to_frames()
+    assert len(frames) == 12 and frames[3].get_volume() == pytest.approx(abs(np.linalg.det(ref[3])))
+
+
+def test_errors(tmp_path):
+    with pytest.raises(ValueError):
+        T.read_xyz(str(tmp_path / "missing.xyz"))
+    bad = tmp_path / "bad.xyz"
+    bad.write_text("2\ncomment\nH 0 0 0\nH 1 1 1\n3\ncomment\nH 0 0 0\nH 1 1 1\nH 2 2 2\n")
+    with pytest.raises(ValueError, match="atoms"):
+        T.read_xyz(str(bad), ":")
+    trunc = tmp_path / "trunc.xyz"
+    trunc.write_text("2\ncomment\nH 0 0 0\n")
+    with pytest.raises(ValueError):
+        T.read_xyz(str(trunc), ":")
+    garbage = tmp_path / "g.xyz"
+    garbage.write_text("1\ncomment\nH 0 zero 0\n")
+    with pytest.raises(ValueError):
+        T.read_xyz(str(garbage), ":")
+    nolat = tmp_path / "n.xyz"
+    nolat.write_text("1\ncomment\nH 0 0 0\n")
+    with pytest.raises(ValueError, match="Lattice"):
+        T.read_lammps_traj(str(nolat), ":")
