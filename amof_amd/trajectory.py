@@ -127,6 +127,8 @@ def read_lammps_traj(path_to_xyz, index=None, cell=None, unzip_xyz=False):
     cell = np.asarray(cell, dtype=np.float64)
     if cell.ndim == 3:
         pos, cell = _fit(pos, cell)
+        if len(cell) > 1 and (cell == cell[0]).all():
+            cell = cell[:1]                     # constant cell: one record serves every frame
     return PackedTrajectory(pos, cell, numbers, pbc=(True, True, True))
 
 

@@ -36,7 +36,7 @@ def test_xyz_round_trip_is_correctly_rounded(tmp_path, fmt):
     got = T.read_lammps_traj(path, ":")
     want = np.array([[[float(fmt % v) for v in atom] for atom in frame] for frame in pos])
     assert np.array_equal(got.pos, want)                         # same doubles as Python's float()
-    assert np.array_equal(got.cell, packed.cell) and np.array_equal(got.numbers, z.numbers)
+    assert np.array_equal(got.cells_full(), packed.cells_full()) and np.array_equal(got.numbers, z.numbers)
     assert got.pbc.all()
 
 
