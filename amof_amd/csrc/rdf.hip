@@ -210,6 +210,7 @@ struct RdfFastArgs {
     float guard;             // g_f (bins): f32 candidate
     float nbins_f;
     double guard64;          // g_m (bins): f64-from-fixed-point candidate
+    int32_t xcd_map;         // 1: chunk -> XCD affinity mapping of the grid
 };
 
 constexpr int FAST_THREADS = 256;
@@ -363,9 +364,13 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     // with its own 4 MiB L2.  All work items of one frame chunk go to the same XCD so that the
     // chunk's quantised frames (16 frames x 16 B x N) are re-read from that L2, not from the
     // fabric.  Pure bijection of the grid: correctness does not depend on the placement.
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned xcd = lin & 7u, kk = lin >> 3;
-    const unsigned chunk = (kk / gridDim.x) * 8u + xcd, bx = kk % gridDim.x;
+    unsigned chunk = blockIdx.y, bx = blockIdx.x;
+    if (fa.xcd_map) {      // (off when there are too few chunks to give every XCD its share)
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned xcd = lin & 7u, kk = lin >> 3;
+        chunk = (kk / gridDim.x) * 8u + xcd;
+        bx = kk % gridDim.x;
+    }
     if ((int)(chunk * a.frames_per_chunk) >= fa.nf) return;
     const int2 pr = a.pairs[bx >> 2];
     const int sub = bx & 3;
@@ -686,8 +691,10 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 int64_t want_chunks = (8 * 2048 + 4 * (int64_t)fpairs.size() - 1) / (4 * (int64_t)fpairs.size());
                 int64_t fpc = std::max<int64_t>(1, nf / std::max<int64_t>(1, want_chunks));
                 fpc = std::min<int64_t>(fpc, 16);
+                if (nf >= 64) fpc = std::min<int64_t>(fpc, nf / 32);   // >= 32 chunks: every XCD gets >= 4
                 int64_t chunks = (nf + fpc - 1) / fpc;
-                chunks = (chunks + 7) / 8 * 8;      // the XCD mapping deals chunks in groups of 8
+                fa.xcd_map = chunks >= 32 ? 1 : 0;
+                if (fa.xcd_map) chunks = (chunks + 7) / 8 * 8;         // the XCD mapping deals chunks in groups of 8
                 fa.a.frames_per_chunk = (int32_t)fpc;
                 dim3 grid((unsigned)(4 * fpairs.size()), (unsigned)chunks);
                 if (launches == 0) timing_dom_begin(ctx);

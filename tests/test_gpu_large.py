@@ -1,0 +1,36 @@
+"""BASELINE configs[4]-shaped case: ~100k atoms, sheared (triclinic) cell, rmax = 10 A."""
+
+import time
+
+import numpy as np
+import pytest
+
+from amof_amd.frames import Frame, PackedTrajectory
+from amof_amd.rdf import Rdf
+from oracle import clib
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg5_100k_triclinic_rdf(hip_ctx):
+    base = H.replicate(H.zif4_frame(), (7, 7, 8))
+    assert len(base) == 106624
+    shear = np.eye(3) + np.array([[0, 0.15, 0.10], [0, 0, 0.20], [0, 0, 0]])     # upper-triangular affine shear
+    cell = base.cell @ shear
+    pos = base.positions @ shear
+    sheared = Frame(base.numbers, pos, cell)
+    packed = H.random_walk(sheared, 3, 0.05, 51)
+    rdf = Rdf.from_trajectory(packed, dr=0.01, rmax=10.0)
+    assert len(rdf.data) == 999 and rdf.rmax == 10.0                 # int(10 // 0.01) == 999
+    kinds, sp = H.species_of(packed.numbers)
+    ref, vol = clib.rdf_hist(packed.pos[:1], packed.cell, sp, 4, 10.0, 999, cell_list=True)
+    one, _, _ = hip_ctx.rdf_accumulate(packed, 10.0, 999, frame_range=(0, 1))
+    assert np.array_equal(one, ref)
+    t0 = time.perf_counter()
+    hip_ctx.rdf_accumulate(packed, 10.0, 999)
+    dt = time.perf_counter() - t0
+    print("cfg5-shaped RDF: %.1f ms per frame (3 frames, incl. H2D of %d MB)" % (1e3 * dt / 3, packed.pos.nbytes >> 20))
+    # g(r) -> N_b / N at large r for partials normalised with the total density
+    tail = rdf.data["X-X"].values[-50:].mean()
+    assert 0.9 < tail < 1.1
