@@ -30,6 +30,7 @@ EXPORTS = [
     "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_destroy", "amof_last_error",
     "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_last_kernel_seconds", "amof_last_kernel_launches",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
+    "amof_bad_hist_by_cn",
     "amof_msd_window",
     "amof_xyz_scan", "amof_xyz_read", "amof_cp2k_cell_read", "amof_ingest_last_error",
 ]
@@ -93,6 +94,7 @@ def load_library():
         lib.amof_cn_count.argtypes = [P, TP, P, P, ctypes.c_int32, P, P]
         lib.amof_bad_hist.argtypes = [P, TP, P, P, ctypes.c_int32, P, ctypes.c_int32, P, P]
         lib.amof_bad_hist_dev.argtypes = lib.amof_bad_hist.argtypes
+        lib.amof_bad_hist_by_cn.argtypes = [P, TP, P, P, ctypes.c_int32, P, ctypes.c_int32, ctypes.c_int32, P, P]
         lib.amof_msd_window.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int64, ctypes.c_int64, P]
         lib.amof_xyz_scan.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
@@ -275,6 +277,22 @@ class Context(object):
                                      ctypes.c_void_p(triples.ctypes.data), len(triples),
                                      ctypes.c_void_p(edges.ctypes.data), nb,
                                      ctypes.c_void_p(hist.ctypes.data), ctypes.c_void_p(nang.ctypes.data))
+        self._check(rc)
+        return hist, nang
+
+    def bad_hist_by_cn(self, packed, cutoff, triples, edges, cn_max=16, frame_range=None):
+        """``(hist u64 [T][cn_max+1][nb], n_angles u64 [T][cn_max+1])`` keyed by neighbour count."""
+        th = _TrajHandle(packed, frame_range)
+        cutoff = np.ascontiguousarray(cutoff, dtype=np.float64).reshape(th.S, th.S)
+        triples = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 2)
+        edges = np.ascontiguousarray(edges, dtype=np.float64)
+        nb = len(edges) - 1
+        hist = np.zeros((len(triples), cn_max + 1, nb), dtype=np.uint64)
+        nang = np.zeros((len(triples), cn_max + 1), dtype=np.uint64)
+        rc = self._lib.amof_bad_hist_by_cn(self._h, ctypes.byref(th.c), ctypes.c_void_p(cutoff.ctypes.data),
+                                           ctypes.c_void_p(triples.ctypes.data), len(triples),
+                                           ctypes.c_void_p(edges.ctypes.data), nb, int(cn_max),
+                                           ctypes.c_void_p(hist.ctypes.data), ctypes.c_void_p(nang.ctypes.data))
         self._check(rc)
         return hist, nang
 

@@ -140,3 +140,103 @@ class Bad(CoreBad):
     def read_bad_file(self, path_to_data):
         path_to_data = _path.append_suffix(path_to_data, 'bad')
         self.data = pd.read_feather(path_to_data)
+
+
+class BadByCn(CoreBad):
+    """
+    Bond-angle distributions split by coordination number (mirror of reference
+    amof/bad.py:172-309): BAD for A bonded to 2 B, 3 B, ...  With
+    ``normalization='partial'`` each cn is weighted by its share of the angles, so
+    that the partial BADs of a triple add up to the ``Bad`` result.
+
+    The reference stores the result as an ``xarray.Dataset`` (variable 'bad',
+    dims atom_triple x cn x theta).  ``.data`` is that Dataset when xarray is
+    importable; the same numbers are always available as ``.bad``
+    (``{triple: {cn: density[theta]}}``), ``.theta`` and the integer counts ``.hist``.
+    """
+
+    CN_MAX = 16
+
+    def __init__(self):
+        """default constructor"""
+        self.data = None
+        self.bad = {}
+        self.theta = np.empty([0])
+
+    def compute_bad(self, trajectory, nb_set_and_cutoff, dtheta, normalisation='total', parallel=False,
+                    device=None, distributed=None):
+        """compute bond-angle distributions by cn (reference amof/bad.py:240-301)"""
+        packed = pack_trajectory(trajectory)
+        atomic_numbers_unique = list(set(packed.numbers))
+        cutoff_dict = amatom.format_cutoff(nb_set_and_cutoff)
+        elements_present_unique = list(set([_data.atomic_numbers[i] for nb_set in nb_set_and_cutoff.keys()
+                                            for i in nb_set.split('-')]))
+        if len(elements_present_unique) == len(atomic_numbers_unique):
+            elements_present_unique.append("X")
+        elements = [(a, b) for b in elements_present_unique for a in elements_present_unique
+                    if (a not in [b, "X"] or ((a, b) == ("X", "X")))]
+        logger.info("Start computing bad for %s frames with dtheta = %s", len(packed), dtheta)
+        bins = int(180 // dtheta)
+        theta_bins = np.arange(bins + 2) * dtheta
+        theta = np.arange(bins + 1) * dtheta + dtheta / 2
+        kinds, _ = _hip.species_index(packed.numbers)
+        lut = {z: k for k, z in enumerate(kinds)}
+        rcm = amatom.cutoff_matrix(cutoff_dict, kinds)
+        names, triples = [], []
+        for A, B in elements:
+            ia = -1 if isinstance(A, str) else lut.get(A, None)
+            ib = -1 if isinstance(B, str) else lut.get(B, None)
+            if ia is None or ib is None:
+                continue
+            names.append("-".join([_symbol(C) for C in [B, A, B]]))
+            triples.append((ia, ib))
+        rank, world = (0, 1) if distributed is False else _dist.world()
+        F = len(packed)
+        frame_range = _dist.shard_range(F, rank, world) if (world > 1 and distributed != 'local') else (0, F)
+        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        ctx = _hip.get_context(dev)
+        if triples:
+            hist, nang = ctx.bad_hist_by_cn(packed, rcm, triples, theta_bins, cn_max=self.CN_MAX, frame_range=frame_range)
+        else:
+            hist = np.zeros((0, self.CN_MAX + 1, bins + 1), dtype=np.uint64)
+            nang = np.zeros((0, self.CN_MAX + 1), dtype=np.uint64)
+        if world > 1:
+            hist = _dist.all_reduce_sum(hist)
+            nang = _dist.all_reduce_sum(nang)
+        if nang.size and nang[:, self.CN_MAX].any():
+            raise _hip.AmofError(_hip.AMOF_ECAPACITY, "a centre has %d or more neighbours; BadByCn.CN_MAX is %d"
+                                 % (self.CN_MAX, self.CN_MAX))
+        self.hist, self.n_angles, self.columns, self.theta = hist, nang, names, theta
+        db = np.array(np.diff(theta_bins), float)
+        self.bad = {}
+        for k, aba_str in enumerate(names):
+            cns = [c for c in range(2, self.CN_MAX) if nang[k, c] != 0]
+            if not cns:
+                continue                          # no angle at all: triple omitted (amof/bad.py:282)
+            num_angles_all = int(nang[k].sum())
+            per_cn = {}
+            for c in cns:
+                n = hist[k, c].astype(np.int64)
+                ratio = float(nang[k, c]) / num_angles_all if normalisation == 'partial' else 1
+                per_cn[c] = ratio * (n / db / n.sum())
+            self.bad[aba_str] = per_cn
+        try:
+            import xarray as xr
+        except ImportError:
+            self.data = None
+            return
+        dic_of_xarray = {aba: xr.DataArray([v[c] for c in v], coords={"cn": list(v), "theta": theta}, dims=("cn", "theta"))
+                         for aba, v in self.bad.items()}
+        xa = xr.Dataset(dic_of_xarray).to_array("atom_triple")
+        self.data = xr.Dataset({'bad': xa})
+
+    def write_to_file(self, filename):
+        if self.data is None:
+            raise ImportError("xarray (netCDF) is needed to write a BadByCn file, as in the reference")
+        filename = _path.append_suffix(filename, 'bad')
+        self.data.to_netcdf(filename)
+
+    def read_bad_file(self, filename):
+        import xarray as xr
+        filename = _path.append_suffix(filename, 'bad')
+        self.data = xr.open_dataset(filename)

@@ -50,6 +50,7 @@ struct NbrArgs {
     unsigned long long *hist;  // [T][nb]
     unsigned long long *n_angles;
     int32_t *flags;            // [0] zero-length vector, [1] neighbour overflow
+    int32_t cn_max;            // > 0: histograms keyed by the centre's neighbour count (BadByCn)
 };
 
 // ------------------------------------------------------------------- CN ----
@@ -241,15 +242,21 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
                 if (dot > 1.0) dot = 1.0;
                 if (dot < -1.0) dot = -1.0;
                 double ang = (180.0 / M_PI) * acos(dot);
-                nang++;
                 int k = hist_bin(a.edges, nb, ang);
-                if (k >= 0) atomicAdd(&hist[k], 1u);
+                if (a.cn_max > 0) {     // keyed by the number of B-neighbours of this centre
+                    const size_t slot = (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max);
+                    atomicAdd(&a.n_angles[slot], 1ull);
+                    if (k >= 0) atomicAdd(&a.hist[slot * nb + k], 1ull);
+                } else {
+                    nang++;
+                    if (k >= 0) atomicAdd(&hist[k], 1u);
+                }
             }
         }
     }
     __syncthreads();
     unsigned long long *H = a.hist + (size_t)trip * nb;
-    for (int k = tid; k < nb; k += BAD_TILE) {
+    for (int k = tid; k < nb && a.cn_max == 0; k += BAD_TILE) {
         unsigned v = hist[k];
         if (v) atomicAdd(&H[k], (unsigned long long)v);
     }
@@ -507,16 +514,22 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
                     if (dot > 1.0) dot = 1.0;
                     if (dot < -1.0) dot = -1.0;
                     const double ang = (180.0 / M_PI) * acos(dot);
-                    nang++;
                     const int k = hist_bin(a.edges, nb, ang);
-                    if (k >= 0) atomicAdd(&hist[k], 1u);
+                    if (a.cn_max > 0) {     // keyed by the number of B-neighbours of this centre
+                        const size_t slot = (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max);
+                        atomicAdd(&a.n_angles[slot], 1ull);
+                        if (k >= 0) atomicAdd(&a.hist[slot * nb + k], 1ull);
+                    } else {
+                        nang++;
+                        if (k >= 0) atomicAdd(&hist[k], 1u);
+                    }
                 }
             }
         }
     }
     __syncthreads();
     unsigned long long *H = a.hist + (size_t)trip * nb;
-    for (int k = tid; k < nb; k += NBRF_TILE) {
+    for (int k = tid; k < nb && a.cn_max == 0; k += NBRF_TILE) {
         unsigned v = hist[k];
         if (v) atomicAdd(&H[k], (unsigned long long)v);
     }
@@ -772,7 +785,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
 
 static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, const int32_t *triples,
                    int32_t T, const double *edges, int32_t nb, unsigned long long *hist_dev,
-                   unsigned long long *nang_dev)
+                   unsigned long long *nang_dev, int32_t cn_max = 0)
 {
     NbrSetup st;
     AMOF_TRY(nbr_setup(ctx, t, cutoff, BAD_TILE, st));
@@ -794,6 +807,8 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
     a.hist = hist_dev;
     a.n_angles = nang_dev;
     a.flags = (int32_t *)d_flags;
+    a.cn_max = cn_max;
+    const size_t KC = (size_t)(cn_max > 0 ? cn_max + 1 : 1);   // histogram slots per triple
     NbrFast nf;
     AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf));
     bool done = false;
@@ -811,9 +826,9 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         AMOF_TRY(upload(ctx, SLOT_AUX6, fwork.data(), fwork.size() * sizeof(int4), &d_fwork));
         // the fast kernels accumulate into scratch so that a fallback can start from a clean slate
         void *d_hs, *d_ns;
-        AMOF_TRY(ensure(ctx, SLOT_AUX7, ((size_t)T * nb + (size_t)T) * sizeof(unsigned long long), &d_hs));
-        AMOF_HIP_TRY(ctx, hipMemsetAsync(d_hs, 0, ((size_t)T * nb + (size_t)T) * sizeof(unsigned long long), ctx->stream));
-        d_ns = (unsigned long long *)d_hs + (size_t)T * nb;
+        AMOF_TRY(ensure(ctx, SLOT_AUX7, ((size_t)T * KC * nb + (size_t)T * KC) * sizeof(unsigned long long), &d_hs));
+        AMOF_HIP_TRY(ctx, hipMemsetAsync(d_hs, 0, ((size_t)T * KC * nb + (size_t)T * KC) * sizeof(unsigned long long), ctx->stream));
+        d_ns = (unsigned long long *)d_hs + (size_t)T * KC * nb;
         nf.fa.a = a;
         nf.fa.a.work = (const int4 *)d_fwork;
         nf.fa.a.hist = (unsigned long long *)d_hs;
@@ -850,9 +865,9 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (!qflag) {
             hipLaunchKernelGGL(add_u64_kernel, dim3(64), dim3(256), 0, ctx->stream, hist_dev,
-                               (const unsigned long long *)d_hs, (size_t)T * nb);
+                               (const unsigned long long *)d_hs, (size_t)T * KC * nb);
             hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, nang_dev,
-                               (const unsigned long long *)d_ns, (size_t)T);
+                               (const unsigned long long *)d_ns, (size_t)T * KC);
             AMOF_HIP_TRY(ctx, hipGetLastError());
             done = true;
         } else {   // atoms absurdly far from the cell: redo with the exact kernel
@@ -929,6 +944,28 @@ extern "C" int amof_bad_hist(amof_ctx *ctx, const amof_traj *t, const double *cu
     AMOF_TRY(upload(ctx, SLOT_OUT0, hist, hb, &d_hist));
     AMOF_TRY(upload(ctx, SLOT_OUT1, n_angles, nbts, &d_nang));
     int rc = bad_run(ctx, t, cutoff, triples, T, edges, nb, (unsigned long long *)d_hist, (unsigned long long *)d_nang);
+    if (rc) return rc;
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, hb, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(n_angles, d_nang, nbts, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMOF_OK;
+}
+
+extern "C" int amof_bad_hist_by_cn(amof_ctx *ctx, const amof_traj *t, const double *cutoff, const int32_t *triples,
+                                   int32_t T, const double *edges, int32_t nb, int32_t cn_max, uint64_t *hist,
+                                   uint64_t *n_angles)
+{
+    if (!ctx) return AMOF_EINVAL;
+    AMOF_TRY(bad_check(ctx, t, cutoff, triples, T, edges, nb, hist, n_angles));
+    if (cn_max < 1 || cn_max > AMOF_MAX_NEIGHBOURS) return fail(ctx, AMOF_EINVAL, "cn_max must be 1..%d", AMOF_MAX_NEIGHBOURS);
+    if (T == 0) return AMOF_OK;
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d_hist, *d_nang;
+    const size_t KC = (size_t)cn_max + 1;
+    size_t hb = (size_t)T * KC * nb * sizeof(uint64_t), nbts = (size_t)T * KC * sizeof(uint64_t);
+    AMOF_TRY(upload(ctx, SLOT_OUT0, hist, hb, &d_hist));
+    AMOF_TRY(upload(ctx, SLOT_OUT1, n_angles, nbts, &d_nang));
+    int rc = bad_run(ctx, t, cutoff, triples, T, edges, nb, (unsigned long long *)d_hist, (unsigned long long *)d_nang, cn_max);
     if (rc) return rc;
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, hb, hipMemcpyDeviceToHost, ctx->stream));
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(n_angles, d_nang, nbts, hipMemcpyDeviceToHost, ctx->stream));

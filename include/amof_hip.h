@@ -140,6 +140,16 @@ int amof_bad_hist_dev(amof_ctx *ctx, const amof_traj *traj, const double *cutoff
                       uint64_t *hist_dev /* device [T][nb] */, uint64_t *n_angles_dev /* device [T] */);
 
 /*
+ * Bond-angle histograms split by the centre atom's number of B-neighbours.
+ * Replaces BadByCn.bad_BAB (amof/bad.py:190-224): slot c (0..cn_max) of triple t holds the
+ * angles of centres with exactly c B-neighbours (c = cn_max also collects any larger count;
+ * cn_max <= AMOF_MAX_NEIGHBOURS).  hist[(t*(cn_max+1) + c)*nb + k], n_angles[t*(cn_max+1) + c].
+ */
+int amof_bad_hist_by_cn(amof_ctx *ctx, const amof_traj *traj, const double *cutoff,
+                        const int32_t *triples, int32_t n_triples, const double *edges, int32_t nb,
+                        int32_t cn_max, uint64_t *hist, uint64_t *n_angles);
+
+/*
  * Window-averaged MSD partial sums.
  * Replaces amof.trajectory.get_delta_pos (amof/trajectory.py:285-303, i.e.
  * ase.geometry.wrap_positions(d, cell[k], center=0)) + the per-window loop

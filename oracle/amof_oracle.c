@@ -551,6 +551,59 @@ int amof_oracle_bad(const double *pos, const double *cell, int64_t n_cells, cons
     return rc;
 }
 
+/*
+ * Bond-angle histograms keyed by the centre's number of B-neighbours.
+ * Restates BadByCn.bad_BAB (amof/bad.py:190-224): slot c of triple t collects the angles of
+ * centres that have exactly c neighbours of kind B (c = cn_max also takes larger counts).
+ */
+int amof_oracle_bad_by_cn(const double *pos, const double *cell, int64_t n_cells, const unsigned char *pbc,
+                          int64_t F, int64_t N, const int *species, int S, const double *rcm,
+                          const int *triples, int T, const double *edges, int nb, int cn_max,
+                          uint64_t *hist, uint64_t *n_angles)
+{
+    if (F < 0 || N < 0 || S <= 0 || T < 0 || nb <= 0 || cn_max < 1) return AMOF_EINVAL;
+    if (n_cells != 1 && n_cells != F) return AMOF_EINVAL;
+    double R = max_cutoff(rcm, S);
+    double *E = (double *)malloc(sizeof(double) * 3 * MAX_IMG);
+    if (!E) return AMOF_ENOMEM;
+    nblist_t l = {0, 0, 0};
+    int rc = AMOF_OK;
+    for (int64_t f = 0; f < F && rc == AMOF_OK; f++) {
+        geom_t g;
+        int nE = 0;
+        rc = geom_make(cell + 9 * (n_cells == 1 ? 0 : f), pbc, &g);
+        if (rc) break;
+        if (R > 0.0) rc = images_make(&g, pbc, R, E, &nE);
+        if (rc) break;
+        const double *p = pos + (size_t)f * N * 3;
+        for (int64_t a = 0; a < N && rc == AMOF_OK; a++) {
+            rc = neighbours_of(&g, E, nE, p, N, species, S, rcm, (int)a, &l);
+            if (rc) break;
+            for (int t = 0; t < T && rc == AMOF_OK; t++) {
+                int A = triples[2 * t], B = triples[2 * t + 1];
+                if (!(A < 0 || A == species[a])) continue;
+                int cn = 0;
+                for (int u = 0; u < l.n; u++) if (B < 0 || species[l.e[u].j] == B) cn++;
+                size_t slot = (size_t)t * (cn_max + 1) + (cn < cn_max ? cn : cn_max);
+                for (int u = 0; u < l.n && rc == AMOF_OK; u++) {
+                    if (!(B < 0 || species[l.e[u].j] == B)) continue;
+                    for (int w = u + 1; w < l.n; w++) {
+                        if (!(B < 0 || species[l.e[w].j] == B)) continue;
+                        double ang;
+                        rc = angle_deg(l.e[u].v, l.e[w].v, &ang);
+                        if (rc) break;
+                        n_angles[slot]++;
+                        int k = hist_bin(edges, nb, ang);
+                        if (k >= 0) hist[slot * nb + k]++;
+                    }
+                }
+            }
+        }
+    }
+    free(l.e); free(E);
+    return rc;
+}
+
 /* test hook: all angles of one triple in one frame, in centre-major order */
 int amof_oracle_angles(const double *pos, const double *cell, const unsigned char *pbc, int64_t N,
                        const int *species, int S, const double *rcm, int A, int B,

@@ -126,6 +126,24 @@ def bad_hist(pos, cell, species, S, rcm, triples, edges, pbc=(True, True, True))
     return hist, nang
 
 
+def bad_hist_by_cn(pos, cell, species, S, rcm, triples, edges, cn_max, pbc=(True, True, True)):
+    """``(hist u64 [T][cn_max+1][nb], n_angles u64 [T][cn_max+1])``."""
+    pos, cell, pbc, species, F, N = _prep(pos, cell, pbc, species)
+    rcm = np.ascontiguousarray(rcm, dtype=np.float64).reshape(S, S)
+    triples = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 2)
+    edges = np.ascontiguousarray(edges, dtype=np.float64)
+    nb = len(edges) - 1
+    hist = np.zeros((len(triples), cn_max + 1, nb), dtype=np.uint64)
+    nang = np.zeros((len(triples), cn_max + 1), dtype=np.uint64)
+    rc = lib().amof_oracle_bad_by_cn(_p(pos, ctypes.c_double), _p(cell, ctypes.c_double), ctypes.c_int64(cell.shape[0]),
+                                     _p(pbc, ctypes.c_ubyte), ctypes.c_int64(F), ctypes.c_int64(N),
+                                     _p(species, ctypes.c_int), int(S), _p(rcm, ctypes.c_double),
+                                     _p(triples, ctypes.c_int), len(triples), _p(edges, ctypes.c_double), nb,
+                                     int(cn_max), _p(hist, ctypes.c_uint64), _p(nang, ctypes.c_uint64))
+    _check(rc, "bad_by_cn")
+    return hist, nang
+
+
 def angles(pos, cell, species, S, rcm, A, B, pbc=(True, True, True)):
     """All B-A-B angles (degrees) of one frame."""
     pos, cell, pbc, species, F, N = _prep(pos, cell, pbc, species)

@@ -125,3 +125,36 @@ def test_far_away_atoms_fall_back(hip_ctx):
     hb, ab = hip_ctx.bad_hist(far, rcm, [(3, 2)], edges)
     hr, ar = clib.bad_hist(far.pos, far.cell, sp, 4, rcm, [(3, 2)], edges)
     assert np.array_equal(ab, ar) and np.array_equal(hb, hr)
+
+
+def test_bad_by_cn(hip_ctx):
+    from amof_amd.bad import Bad, BadByCn
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (1, 1, 2)), 6, 0.25, 41)     # hot: mixed coordination numbers
+    kinds, sp = H.species_of(packed.numbers)
+    S = len(kinds)
+    zn, n, c = kinds.index(30), kinds.index(7), kinds.index(6)
+    rcm = np.zeros((S, S))
+    rcm[zn, n] = rcm[n, zn] = 2.6
+    rcm[c, n] = rcm[n, c] = 1.7
+    triples = [(zn, n), (n, -1), (-1, -1)]
+    edges = np.arange(int(180 // 1.0) + 2) * 1.0
+    for env in ({}, {"AMOF_NBR_KERNEL": "v1"}):
+        with _env(**env):
+            h, a = hip_ctx.bad_hist_by_cn(packed, rcm, triples, edges, cn_max=8)
+        hr, ar = clib.bad_hist_by_cn(packed.pos, packed.cell, sp, S, rcm, triples, edges, 8)
+        assert np.array_equal(a, ar) and np.array_equal(h, hr)
+        assert (ar[:, 2:] > 0).sum() >= 4 and ar[:, :2].sum() == 0          # several cn values populated, none below 2
+    # summing over cn gives the plain histogram
+    h0, a0 = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert np.array_equal(h.sum(axis=1), h0) and np.array_equal(a.sum(axis=1), a0)
+    # class level: 'partial' weights make the per-cn BADs add up to Bad's column
+    cut = {'Zn-N': 2.6, 'C-N': 1.7}
+    by = BadByCn.from_trajectory(packed, cut, dtheta=1.0, normalization='partial')
+    plain = Bad.from_trajectory(packed, cut, dtheta=1.0)
+    assert set(by.bad) == set(plain.data.columns) - {"theta"}
+    for col, per_cn in by.bad.items():
+        np.testing.assert_allclose(sum(per_cn.values()), plain.data[col].values, rtol=1e-12, atol=1e-15)
+    tot = BadByCn.from_trajectory(packed, cut, dtheta=1.0)
+    for col, per_cn in tot.bad.items():
+        for cn, dens in per_cn.items():
+            assert (dens * np.diff(np.arange(182) * 1.0)).sum() == pytest.approx(1.0, rel=1e-12)
