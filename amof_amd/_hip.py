@@ -31,7 +31,7 @@ EXPORTS = [
     "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_last_kernel_seconds", "amof_last_kernel_launches",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_bad_hist_by_cn",
-    "amof_msd_window",
+    "amof_msd_window", "amof_msd_direct",
     "amof_xyz_scan", "amof_xyz_read", "amof_cp2k_cell_read", "amof_ingest_last_error",
 ]
 
@@ -97,6 +97,7 @@ def load_library():
         lib.amof_bad_hist_by_cn.argtypes = [P, TP, P, P, ctypes.c_int32, P, ctypes.c_int32, ctypes.c_int32, P, P]
         lib.amof_msd_window.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int64, ctypes.c_int64, P]
+        lib.amof_msd_direct.argtypes = [P, TP, P]
         lib.amof_xyz_scan.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         lib.amof_xyz_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, P, P, P,
                                       ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]
@@ -306,6 +307,14 @@ class Context(object):
                                        len(windows), 1 if unwrap else 0, 1 if remove_com else 0,
                                        int(a0), int(a1), ctypes.c_void_p(out.ctypes.data))
         self._check(rc)
+        return out, th.kinds
+
+
+    def msd_direct(self, packed):
+        """``(msd [F][S+1] f64, kinds)``: column 0 = all atoms, then one per species."""
+        th = _TrajHandle(packed)
+        out = np.zeros((th.n_frames, th.S + 1), dtype=np.float64)
+        self._check(self._lib.amof_msd_direct(self._h, ctypes.byref(th.c), ctypes.c_void_p(out.ctypes.data)))
         return out, th.kinds
 
 

@@ -302,6 +302,56 @@ __global__ __launch_bounds__(MSD_THREADS) void delta_T_kernel(const double *__re
     DT[(3 * a + 2) * Fp + k] = dz;
 }
 
+// ---- DirectMsd (deprecated in the reference, orthogonal cells only; amof/msd.py:83-107) ----
+// One thread per coordinate column walks the frames: r_t = r_{t-1} + wrap(pos_t - (r_{t-1} % a)),
+// with Python's float modulo (result in [0, a)) and the reference's +-a/2 fold.
+__global__ __launch_bounds__(256) void direct_walk_kernel(const double *__restrict__ pos,
+                                                          const double *__restrict__ cell, int n_cells, int64_t N,
+                                                          int F, double *__restrict__ sq)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= 3 * N) return;
+    const int j = (int)(c % 3);
+    const double r0 = pos[c];
+    double r = r0;
+    sq[c] = 0.0;
+    for (int t = 1; t < F; t++) {
+        const double a = cell[(size_t)(n_cells == 1 ? 0 : t) * 9 + 4 * j];
+        double m = fmod(r, a);
+        if (m != 0.0 && ((a < 0.0) != (m < 0.0))) m += a;      // numpy's % on floats
+        double dr = pos[(size_t)t * 3 * N + c] - m;
+        if (dr > a / 2) dr -= a;
+        else if (dr < -a / 2) dr += a;
+        r = dr + r;
+        const double d = r - r0;
+        sq[(size_t)t * 3 * N + c] = d * d;
+    }
+}
+
+// msd[t][0] = sum over all atoms / N ; msd[t][1+s] = sum over species s / N_s  (fixed order)
+__global__ __launch_bounds__(MSD_THREADS) void direct_reduce_kernel(const double *__restrict__ sq,
+                                                                    const int32_t *__restrict__ perm,
+                                                                    const int64_t *__restrict__ sp_first, int S,
+                                                                    int64_t N, double *__restrict__ msd)
+{
+    __shared__ double red[MSD_THREADS / 64];
+    const int t = blockIdx.x;
+    const double *__restrict__ row = sq + (size_t)t * 3 * N;
+    double total = 0.0;
+    for (int s = 0; s < S; s++) {
+        const int64_t k0 = sp_first[s], k1 = sp_first[s + 1];
+        double acc = 0.0;
+        for (int64_t k = k0 + threadIdx.x; k < k1; k += MSD_THREADS) {
+            const int64_t a = perm[k];
+            acc += row[3 * a] + row[3 * a + 1] + row[3 * a + 2];
+        }
+        acc = block_sum(acc, red);
+        total += acc;
+        if (threadIdx.x == 0) msd[(size_t)t * (S + 1) + 1 + s] = k1 > k0 ? acc / (double)(k1 - k0) : 0.0;
+    }
+    if (threadIdx.x == 0) msd[(size_t)t * (S + 1)] = N > 0 ? total / (double)N : 0.0;
+}
+
 }  // namespace amof
 
 using namespace amof;
@@ -429,6 +479,48 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_end(ctx);
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(sumsq, d_out, (size_t)S * W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMOF_OK;
+}
+
+extern "C" int amof_msd_direct(amof_ctx *ctx, const amof_traj *t, double *msd)
+{
+    if (!ctx) return AMOF_EINVAL;
+    AMOF_TRY(validate_traj(ctx, t, false));
+    if (!msd) return fail(ctx, AMOF_EINVAL, "msd is NULL");
+    const int S = t->n_species;
+    const int64_t N = t->n_atoms, F = t->n_frames;
+    if (F == 0) return AMOF_OK;
+    if (F > 0x7fffffffLL) return fail(ctx, AMOF_EINVAL, "too many frames");
+    for (int64_t k = 0; k < t->n_cells; k++)
+        for (int j = 0; j < 3; j++)
+            if (!(t->cell[9 * k + 4 * j] > 0.0)) return fail(ctx, AMOF_EINVAL, "DirectMsd needs positive cell diagonals");
+    HostTiles tiles;
+    build_tiles(t, 256, tiles);
+    std::vector<int64_t> sp_first(S + 1, 0);
+    for (int x = 0; x < S; x++) sp_first[x + 1] = sp_first[x] + tiles.nsp[x];
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    timing_begin(ctx);
+    const double *pos_dev = nullptr;
+    AMOF_TRY(stage_positions(ctx, t, &pos_dev));
+    void *d_cell, *d_perm, *d_spf, *d_sq, *d_out;
+    AMOF_TRY(upload(ctx, SLOT_GEOM, t->cell, (size_t)t->n_cells * 9 * sizeof(double), &d_cell));
+    AMOF_TRY(upload(ctx, SLOT_PERM, tiles.perm.data(), tiles.perm.size() * sizeof(int32_t), &d_perm));
+    AMOF_TRY(upload(ctx, SLOT_AUX0, sp_first.data(), sp_first.size() * sizeof(int64_t), &d_spf));
+    AMOF_TRY(ensure(ctx, SLOT_AUX3, (size_t)F * 3 * N * sizeof(double), &d_sq));
+    AMOF_TRY(ensure(ctx, SLOT_OUT0, (size_t)F * (S + 1) * sizeof(double), &d_out));
+    if (N > 0) {
+        timing_dom_begin(ctx);
+        hipLaunchKernelGGL(direct_walk_kernel, dim3((unsigned)((3 * N + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
+                           (const double *)d_cell, (int)t->n_cells, N, (int)F, (double *)d_sq);
+        timing_dom_end(ctx, 1);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(direct_reduce_kernel, dim3((unsigned)F), dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_sq,
+                       (const int32_t *)d_perm, (const int64_t *)d_spf, S, N, (double *)d_out);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    timing_end(ctx);
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(msd, d_out, (size_t)F * (S + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return AMOF_OK;
 }

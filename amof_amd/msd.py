@@ -52,6 +52,45 @@ class Msd(object):
         self.data = pd.read_feather(path_to_data)
 
 
+class DirectMsd(Msd):
+    """
+    Direct MSD (mirror of reference amof/msd.py:54-137; deprecated there)
+
+    MSD(t) = 1/N sum_i (r_i(t) - r_i(0))^2 with a running unwrap that only works
+    for orthogonal cells.  Better to use WindowMsd.
+    """
+
+    def __init__(self):
+        """default constructor"""
+        self.data = pd.DataFrame({"Step": np.empty([0])})
+        logger.warning('DirectMsd is deprecated and not suitable for non-orthogonal cells, use WindowMsd instead')
+
+    @classmethod
+    def from_trajectory(cls, trajectory, delta_Step=1, first_frame=0, parallel=False, device=None):
+        """
+        Args:
+            trajectory: list of ase.Atoms-like frames, or a PackedTrajectory
+            delta_Step: number of simulation steps between two frames
+            parallel: accepted for compatibility
+        """
+        from . import trajectory as amtraj
+        msd_class = cls()
+        step = amtraj.construct_step(delta_Step=delta_Step, first_frame=first_frame, number_of_frames=len(trajectory))
+        msd_class.compute_msd(trajectory, step, parallel, device=device)
+        return msd_class
+
+    def compute_msd(self, trajectory, step, parallel=False, device=None):
+        packed = pack_trajectory(trajectory)
+        logger.info("Start computing msd for %s frames", len(packed))
+        elements = list(set(packed.numbers))
+        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        msd, kinds = _hip.get_context(dev).msd_direct(packed)
+        self.data = pd.DataFrame({"Step": step})
+        self.data["X"] = msd[:, 0]
+        for x in elements:
+            self.data[_data.chemical_symbols[int(x)]] = msd[:, 1 + kinds.index(int(x))]
+
+
 class WindowMsd(Msd):
     """
     Window MSD

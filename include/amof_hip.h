@@ -172,6 +172,15 @@ int amof_msd_window(amof_ctx *ctx, const amof_traj *traj, const int32_t *windows
                     double *sumsq /* host [S][W] */);
 
 /*
+ * Direct MSD with running unwrap, orthogonal cells only (deprecated in the reference).
+ * Replaces DirectMsd.compute_species_msd (amof/msd.py:83-107) for every species at once:
+ *   msd[t*(S+1) + 0]     = sum over all atoms  |r_i(t) - r_i(0)|^2 / N     (column 'X')
+ *   msd[t*(S+1) + 1 + s] = the same over the atoms of species s / N_s
+ * with r_i(t) = r_i(t-1) + fold(pos_i(t) - (r_i(t-1) % a_t)) per axis, a_t = cell_t[j][j].
+ */
+int amof_msd_direct(amof_ctx *ctx, const amof_traj *traj, double *msd /* host [F][S+1] */);
+
+/*
  * Trajectory ingest (host only).
  * Replaces, for the packed path, ase.io.read(filename, index, format='xyz') as driven by
  * Trajectory.from_traj / read_lammps_traj / read_cp2k_traj (amof/trajectory.py:37-60,193-228)

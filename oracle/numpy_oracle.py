@@ -281,3 +281,31 @@ def construct_step(**kwargs):
         if first_frame is not None and last_frame is not None:
             return np.linspace(first_frame, last_frame, number_of_frames)
     return None
+
+
+def direct_msd(pos, cell, numbers):
+    """reference amof/msd.py:83-107 (DirectMsd.compute_species_msd) for 'X' and every element,
+    vectorised over atoms (the reference loops over atoms in Python); orthogonal cells only.
+    Returns (elements, {None or Z: msd[F]})."""
+    pos = np.asarray(pos, dtype=np.float64)
+    F = len(pos)
+    cell = np.asarray(cell, dtype=np.float64).reshape(-1, 3, 3)
+    numbers = np.asarray(numbers)
+    elements = list(set(numbers))
+    out = {}
+    for x in [None] + elements:
+        sel = slice(None) if x is None else (numbers == x)
+        r_0 = pos[0][sel]
+        r_t = r_0
+        msd = np.zeros(F)
+        for t in range(1, F):
+            r_prev = r_t
+            dr = np.zeros((len(r_0), 3))
+            for j in range(3):
+                a = cell[t if len(cell) > 1 else 0][j, j]
+                dr[:, j] = (pos[t][sel] - r_prev % a)[:, j]
+                dr[:, j] = np.where(dr[:, j] > a / 2, dr[:, j] - a, np.where(dr[:, j] < -a / 2, dr[:, j] + a, dr[:, j]))
+            r_t = dr + r_prev
+            msd[t] = np.linalg.norm(r_t - r_0) ** 2 / len(r_0)
+        out[x] = msd
+    return elements, out
