@@ -313,7 +313,21 @@ def gold_e2e():
                         dr=0.05, rmax=6.0, **_df_to_npz(rdf.data))
 
 
+def gold_direct_msd():
+    """DirectMsd is pure reference numpy on Atoms.get_cell()/get_positions(): no stub in the numbers."""
+    rng = np.random.default_rng(7)
+    numbers = np.array([30] * 2 + [7] * 5 + [6] * 4 + [1] * 6)
+    cell = np.diag([6.0, 7.0, 8.0])
+    base = GoldenFrame(numbers, rng.uniform(0, 1, size=(len(numbers), 3)) @ cell, cell)
+    frames = random_walk_frames(base, 14, 0.6, rng, wrap=True, cell_jitter=0.004)
+    pos, cells, Z = pack(frames)
+    d = amof.msd.DirectMsd.from_trajectory([f.copy() for f in frames], delta_Step=2, first_frame=4)
+    np.savez_compressed(os.path.join(OUT, "reference_e2e_directmsd_ortho.npz"), pos=pos, cell=cells, numbers=Z,
+                        delta_Step=2, first_frame=4, **_df_to_npz(d.data))
+
+
 if __name__ == "__main__":
+    gold_direct_msd()
     gold_msd_of_m()
     gold_construct_step()
     gold_e2e()

@@ -128,3 +128,10 @@ def test_torch_resident_trajectory_matches_host(zif4):
     m1 = WindowMsd.from_trajectory(packed, delta_time=1, timestep=1).data.values
     m2 = WindowMsd.from_trajectory(dev, delta_time=1, timestep=1).data.values
     assert np.array_equal(m1, m2)                 # same kernels, same order: bitwise
+
+
+def test_direct_msd_matches_reference_dataframe():
+    from amof_amd.msd import DirectMsd
+    g = np.load(os.path.join(GOLDEN, "reference_e2e_directmsd_ortho.npz"))
+    d = DirectMsd.from_trajectory(_frames(g), delta_Step=int(g["delta_Step"]), first_frame=int(g["first_frame"]))
+    _check_df(d.data, g, rtol=1e-9)

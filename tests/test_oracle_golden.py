@@ -73,3 +73,15 @@ def test_window_msd_pipeline_matches_reference_e2e(name):
         for e, col in zip(elements, out):
             want = g["values"][:, cols.index(eldata.chemical_symbols[int(e)])]
             np.testing.assert_allclose(col, want, rtol=1e-10, atol=1e-13)
+
+
+def test_direct_msd_matches_reference_e2e():
+    # DirectMsd is pure reference numpy on get_cell()/get_positions(): this golden carries no stub
+    g = np.load(os.path.join(GOLDEN, "reference_e2e_directmsd_ortho.npz"))
+    from amof_amd import data as eldata
+    elements, out = no.direct_msd(g["pos"], g["cell"], g["numbers"])
+    cols = [str(c) for c in g["columns"]]
+    np.testing.assert_allclose(out[None], g["values"][:, cols.index("X")], rtol=1e-12, atol=1e-14)
+    for e in elements:
+        np.testing.assert_allclose(out[e], g["values"][:, cols.index(eldata.chemical_symbols[int(e)])],
+                                   rtol=1e-12, atol=1e-14)
