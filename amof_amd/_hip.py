@@ -119,9 +119,8 @@ def species_index(numbers):
     Returns ``(kinds, species)``: ``kinds`` = sorted unique atomic numbers,
     ``species[i]`` = index of atom i's number in ``kinds`` (int32)."""
     numbers = np.asarray(numbers)
-    kinds = sorted(set(int(z) for z in numbers))
-    lut = {z: k for k, z in enumerate(kinds)}
-    return kinds, np.array([lut[int(z)] for z in numbers], dtype=np.int32)
+    uniq, inverse = np.unique(numbers, return_inverse=True)
+    return [int(z) for z in uniq], inverse.astype(np.int32).reshape(-1)
 
 
 class _TrajHandle(object):

@@ -213,6 +213,15 @@ class PackedTrajectory(object):
             return self.pos.detach().cpu().numpy()
         return self.pos
 
+    def to_device(self, device=0):
+        """Copy the positions to HBM once (torch CUDA tensor); every later analysis call on the
+        returned trajectory reads them in place instead of staging 24*N*F bytes over PCIe."""
+        import torch
+        if self.on_device:
+            return self
+        pos = torch.as_tensor(self.pos_host()).to(torch.device("cuda", device))
+        return PackedTrajectory(pos, self.cell, self.numbers, self.masses, self.pbc)
+
     def formula_count(self):
         return _Formula([_data.chemical_symbols[z] for z in self.numbers])._count
 

@@ -135,3 +135,13 @@ def test_direct_msd_matches_reference_dataframe():
     g = np.load(os.path.join(GOLDEN, "reference_e2e_directmsd_ortho.npz"))
     d = DirectMsd.from_trajectory(_frames(g), delta_Step=int(g["delta_Step"]), first_frame=int(g["first_frame"]))
     _check_df(d.data, g, rtol=1e-9)
+
+
+def test_to_device_round_trip(zif4):
+    packed = H.random_walk(zif4, 5, 0.05, 9)
+    dev = packed.to_device(0)
+    assert dev.on_device and dev.to_device(0) is dev and not packed.on_device
+    assert np.array_equal(dev.pos_host(), packed.pos)
+    a = CoordinationNumber.from_trajectory(packed, {'Zn-N': 2.5}).data.values
+    b = CoordinationNumber.from_trajectory(dev, {'Zn-N': 2.5}).data.values
+    assert np.array_equal(a, b)
