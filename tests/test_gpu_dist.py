@@ -1,0 +1,61 @@
+"""The classes' N > 1 path on a real GPU: two ranks (gloo rendezvous, both on cuda:0 -- the box
+has one GPU) shard frames (RDF / BAD / CN) or atoms (MSD) of a replicated trajectory and merge;
+every rank must end with exactly the single-process DataFrames (integers: bit-identical)."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _build():
+    from tests import helpers as H
+    return H.random_walk(H.zif4_frame(), 9, 0.1, 77, cell_jitter=0.005)
+
+
+def _run_all(packed, distributed):
+    from amof_amd.rdf import Rdf
+    from amof_amd.msd import WindowMsd
+    from amof_amd.bad import Bad
+    from amof_amd.cn import CoordinationNumber
+    cut = {'Zn-N': 2.5, 'C-N': 1.6}
+    return {
+        "rdf": Rdf.from_trajectory(packed, dr=0.02, device=0, distributed=distributed).data,
+        "msd": WindowMsd.from_trajectory(packed, delta_time=1, timestep=1, device=0, distributed=distributed).data,
+        "bad": Bad.from_trajectory(packed, cut, dtheta=0.5, device=0, distributed=distributed).data,
+        "cn": CoordinationNumber.from_trajectory(packed, cut, device=0, distributed=distributed).data,
+    }
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = _run_all(_build(), None)          # None: shard over the initialised group
+    for k, df in res.items():
+        df.to_pickle(os.path.join(out_dir, "%s_rank%d.pkl" % (k, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process(tmp_path):
+    import pandas as pd
+    port = 29600 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    single = _run_all(_build(), False)
+    for k, df in single.items():
+        for rank in (0, 1):
+            got = pd.read_pickle(os.path.join(str(tmp_path), "%s_rank%d.pkl" % (k, rank)))
+            assert list(got.columns) == list(df.columns), k
+            if k == "msd":      # float sums in a different (but fixed) order
+                np.testing.assert_allclose(got.values, df.values, rtol=1e-12, atol=1e-15)
+            else:               # built from merged integer counts: identical
+                assert np.array_equal(got.values, df.values), k
