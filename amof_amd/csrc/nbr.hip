@@ -665,7 +665,7 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     nf.sp_first.assign(S + 1, 0);
     for (int x = 0; x < S; x++) nf.sp_first[x + 1] = nf.sp_first[x] + st.tiles.nsp[x];
     int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
-    nf.FB = std::min<int64_t>(std::min<int64_t>(FB, 65535), std::max<int64_t>(1, t->n_frames));
+    nf.FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), std::max<int64_t>(1, t->n_frames));
     AMOF_TRY(upload(ctx, SLOT_AUX4, cells.data(), cells.size() * sizeof(NbrCell), &nf.d_cells));
     AMOF_TRY(upload(ctx, SLOT_AUX5, nf.sp_first.data(), nf.sp_first.size() * sizeof(int64_t), &nf.d_spfirst));
     AMOF_TRY(ensure(ctx, SLOT_HISTU, (size_t)nf.FB * t->n_atoms * sizeof(QAtom), &nf.d_Q));

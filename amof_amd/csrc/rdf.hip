@@ -673,7 +673,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             fa.nbins_f = (float)nbins;
             fa.guard64 = guard_m;
             int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
-            FB = std::min<int64_t>(std::min<int64_t>(FB, 65535), t->n_frames);
+            FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), t->n_frames);
             void *d_Q, *d_flag;
             AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB * t->n_atoms * sizeof(QAtom), &d_Q));
             AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag));

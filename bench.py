@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--reps", type=str, default="3,3,4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rdf-frames", type=int, default=24)
+    ap.add_argument("--with-bad", action="store_true", help="BASELINE configs[3]: add Bad({'Zn-N': 2.5}, dtheta=0.05) to the step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--all-on-device", type=int, default=None, help="rehearsal: put every rank on this GPU")
     args = ap.parse_args()
@@ -157,10 +158,17 @@ def main():
         msd = WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=local_rank, distributed=mode)
         t_msd_dom = ctx.last_kernel_seconds(dominant=True)
         t_msd_all = ctx.last_kernel_seconds(dominant=False)
+        if args.with_bad:
+            from amof_amd.bad import Bad
+            bad = Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=local_rank, distributed=mode)
+            k_bad.append(ctx.last_kernel_seconds(dominant=False))
+            assert "N-Zn-N" in bad.data.columns
         return rdf, msd, t_rdf, t_msd_dom, t_msd_all, t_rdf_all
 
+    k_bad = []
     for _ in range(args.warmup):
         step()
+    k_bad.clear()
 
     def fence():
         torch.cuda.synchronize()
@@ -222,6 +230,11 @@ def main():
             "kernel_seconds_per_step": {"rdf_tile": t_rdf, "rdf_all_incl_quantize": float(np.mean(k_rdf_all)),
                                         "msd_all": float(np.mean(k_msd_all))},
         }
+        if args.with_bad:
+            out["metric"] = "frames/s (RDF+BAD+MSD, 10k-atom ZIF-4)"
+            out["config"]["workload"] += " + Bad({'Zn-N': 2.5}, dtheta=0.05) [configs[3]]"
+            out["kernel_seconds_per_step"]["bad_all"] = float(np.mean(k_bad))
+            args.no_cpu_baseline = True         # the CPU leg times RDF+MSD only
         if world == 1 and not args.no_cpu_baseline:
             window = np.arange(0, (F // 2), 100)
             out["cpu_baseline"] = cpu_baseline(packed, rmax, nbins, window, args.cpu_rdf_frames)
