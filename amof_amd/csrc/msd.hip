@@ -248,20 +248,56 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_reduce_kernel(const double *_
 }
 
 // ---- unwrap path (amof/msd.py:222-230) in atom-major layout ----
-// U_T[col][k] = pos[0][col] + sum_{j<=k} D_T[col][j]
-__global__ __launch_bounds__(MSD_THREADS) void unwrap_scan_kernel(const double *__restrict__ DT,
-                                                                  const double *__restrict__ pos0, int64_t Fp,
-                                                                  int F, double *__restrict__ UT)
+// OUT[col][k] = x0[col] + sum_{j<=k} IN[col][j]   (x0 == nullptr: plain prefix sum; IN may alias OUT).
+// Any F: the column is scanned in LDS segments with a running carry.
+constexpr int SCAN_SEG = 8192;
+__global__ __launch_bounds__(MSD_THREADS) void scan_column_kernel(const double *IN, const double *__restrict__ x0,
+                                                                  int64_t Fp, int F, double *OUT)
 {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    double *u = reinterpret_cast<double *>(lds_raw);
+    __shared__ double u[SCAN_SEG];
     __shared__ double red[MSD_THREADS / 64];
+    __shared__ double carry_s;
     const size_t col = blockIdx.x;
-    for (int k = threadIdx.x; k < F; k += MSD_THREADS) u[k] = DT[col * Fp + k];
-    __syncthreads();
-    lds_scan(u, F, red, 0.0);
-    const double x0 = pos0[col];
-    for (int k = threadIdx.x; k < F; k += MSD_THREADS) UT[col * Fp + k] = x0 + u[k];
+    double carry = x0 ? x0[col] : 0.0;
+    for (int base = 0; base < F; base += SCAN_SEG) {
+        const int n = min(SCAN_SEG, F - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += MSD_THREADS) u[k] = IN[col * Fp + base + k];
+        __syncthreads();
+        lds_scan(u, n, red, carry);
+        for (int k = threadIdx.x; k < n; k += MSD_THREADS) OUT[col * Fp + base + k] = u[k];
+        if (threadIdx.x == 0) carry_s = u[n - 1];
+        __syncthreads();
+        carry = carry_s;
+    }
+}
+
+// Long trajectories (F + W beyond the LDS-resident limit): window sums straight from the
+// prefix-summed columns in global memory.  Workgroup (g, c) owns the windows w = c, c + C, ...
+// of group g, so every partial[g][w] has exactly one writer (deterministic).
+__global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel_global(const double *__restrict__ UT, int64_t Fp, int F,
+                                                                       const int32_t *__restrict__ perm,
+                                                                       const MsdGroup *__restrict__ groups,
+                                                                       const int32_t *__restrict__ windows, int W,
+                                                                       double *__restrict__ partial)
+{
+    __shared__ double red[MSD_THREADS / 64];
+    const MsdGroup gr = groups[blockIdx.x];
+    for (int w = blockIdx.y; w < W; w += gridDim.y) {
+        const int m = windows[w];
+        double tot = 0.0;
+        for (int c = 0; c < 3 * gr.count; c++) {
+            const int64_t atom = perm[gr.start + c / 3];
+            const double *__restrict__ u = UT + (size_t)(3 * atom + c % 3) * Fp;
+            double a = 0.0;
+            for (int k = 1 + threadIdx.x; k + m < F; k += MSD_THREADS) {
+                const double d = u[k + m] - u[k];
+                a = fma(d, d, a);
+            }
+            tot += block_sum(a, red);
+        }
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * W + w] = tot;
+    }
 }
 
 __global__ __launch_bounds__(MSD_THREADS) void com_T_kernel(const double *__restrict__ UT,
@@ -372,9 +408,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     if (F == 0 || N == 0 || W == 0 || atom_begin == atom_end) return AMOF_OK;
     if (F > 0x7fffffffLL) return fail(ctx, AMOF_EINVAL, "too many frames");
     const size_t lds_need = ((size_t)F + (size_t)W) * sizeof(double);
-    if (lds_need > 150 * 1024)
-        return fail(ctx, AMOF_ECAPACITY, "n_frames + n_windows = %lld exceeds the LDS-resident limit of %d",
-                    (long long)(F + W), (int)(150 * 1024 / sizeof(double)));
+    const bool lds_resident = lds_need <= 150 * 1024;   // whole time series + window sums fit in LDS
 
     // geometry records with the FULL inverse (wrap_positions semantics)
     HostGeom hg;
@@ -443,10 +477,8 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         hipLaunchKernelGGL(delta_transpose_kernel, tgrid, dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
                            (const double *)nullptr, (const double *)d_geom, (int)t->n_cells, N, (int)F, Fp,
                            (double *)d_DT);
-        AMOF_HIP_TRY(ctx, hipFuncSetAttribute((const void *)unwrap_scan_kernel,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F * sizeof(double))));
-        hipLaunchKernelGGL(unwrap_scan_kernel, dim3((unsigned)(3 * N)), dim3(MSD_THREADS), (size_t)F * sizeof(double),
-                           ctx->stream, (const double *)d_DT, pos_dev, Fp, (int)F, (double *)d_UT);
+        hipLaunchKernelGGL(scan_column_kernel, dim3((unsigned)(3 * N)), dim3(MSD_THREADS), 0, ctx->stream,
+                           (const double *)d_DT, pos_dev, Fp, (int)F, (double *)d_UT);
         if (remove_com) {
             hipLaunchKernelGGL(com_T_kernel, dim3((unsigned)((F + MSD_THREADS - 1) / MSD_THREADS), 3),
                                dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_UT, (const double *)d_mass, N, Fp,
@@ -458,7 +490,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     }
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_dom_begin(ctx);
-    {
+    if (lds_resident) {
         auto launch = [&](auto kern) -> hipError_t {
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need);
             if (e != hipSuccess) return e;
@@ -472,6 +504,16 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         else if (W <= 32) e = launch(msd_group_kernel<32>);
         else e = launch(msd_group_kernel<0>);
         AMOF_HIP_TRY(ctx, e);
+    } else {
+        // long trajectory: prefix-sum every column in place, then reduce the windows from global memory
+        hipLaunchKernelGGL(scan_column_kernel, dim3((unsigned)(3 * N)), dim3(MSD_THREADS), 0, ctx->stream,
+                           (const double *)d_DT, (const double *)nullptr, Fp, (int)F, (double *)d_DT);
+        const unsigned wchunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(W, (4096 + (int64_t)groups.size() - 1) /
+                                                                                    (int64_t)groups.size()));
+        hipLaunchKernelGGL(msd_group_kernel_global, dim3((unsigned)groups.size(), std::min(wchunks, 65535u)),
+                           dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm,
+                           (const MsdGroup *)d_groups, (const int32_t *)d_win, (int)W, (double *)d_part);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
     }
     timing_dom_end(ctx, 1);
     hipLaunchKernelGGL(msd_reduce_kernel, dim3((unsigned)(S * W)), dim3(MSD_THREADS), 0, ctx->stream,

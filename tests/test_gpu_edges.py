@@ -158,12 +158,28 @@ def test_msd_changing_cell_and_long_windows(hip_ctx):
             np.testing.assert_allclose(got, r, rtol=1e-9, atol=1e-12)
 
 
-def test_msd_frame_capacity_error(hip_ctx):
-    z = H.zif4_frame()
-    big = PackedTrajectory(np.zeros((20000, 4, 3)) + 1.0, z.cell, [1, 1, 8, 8])
-    with pytest.raises(_hip.AmofError) as e:
-        hip_ctx.msd_window(big, [0, 1])
-    assert e.value.code == _hip.AMOF_ECAPACITY
+def test_msd_long_trajectory_uses_global_path(hip_ctx):
+    # F + W beyond the LDS-resident limit (19 200): scan in global memory, windows from L2
+    rng = np.random.default_rng(5)
+    F, n = 21000, 6
+    cell = np.diag([9.0, 10.0, 11.0])
+    pos = np.cumsum(rng.normal(scale=0.2, size=(F, n, 3)), axis=0) + 4.0
+    s = pos / np.diag(cell)
+    packed = PackedTrajectory((s - np.floor(s)) * np.diag(cell), cell, [1, 1, 1, 8, 8, 30])
+    window = np.array([0, 1, 7, 500, 9999, 20000, 20999], dtype=np.int32)
+    for unwrap in (False, True):
+        sumsq, kinds = hip_ctx.msd_window(packed, window, unwrap=unwrap)
+        elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window, unwrap=unwrap)
+        for e, r in zip(elements, ref):
+            got = sumsq[kinds.index(int(e))] / (packed.numbers == e).sum() / (F - window)
+            np.testing.assert_allclose(got, r, rtol=1e-9, atol=1e-12)
+    # and many windows on a shorter one (W > 32: generic LDS kernel)
+    short = PackedTrajectory(packed.pos[:600], cell, packed.numbers)
+    w2 = np.arange(0, 300, dtype=np.int32)
+    sumsq, kinds = hip_ctx.msd_window(short, w2)
+    elements, ref = no.window_msd_fast(short.pos, short.cell, short.numbers, short.masses, w2)
+    for e, r in zip(elements, ref):
+        np.testing.assert_allclose(sumsq[kinds.index(int(e))] / (short.numbers == e).sum() / (600 - w2), r, rtol=1e-9, atol=1e-12)
 
 
 def test_headline_shape_properties(hip_ctx):
