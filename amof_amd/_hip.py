@@ -73,6 +73,13 @@ def load_library():
             raise RuntimeError(
                 "amof_amd: %s not found. Build it with `make -C amof_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If torch is
+        # importable, let it load first so that this library binds to the same runtime (loading the
+        # system runtime first makes torch.cuda report "No HIP GPUs are available" later on).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         P = ctypes.c_void_p
         lib.amof_abi_version.restype = ctypes.c_int
