@@ -131,27 +131,29 @@ __global__ __launch_bounds__(MSD_THREADS) void delta_transpose_kernel(const doub
     }
 }
 
-// in-place inclusive prefix sum of u[0..F) held in LDS by the whole workgroup
+// in-place inclusive prefix sum of u[0..F) held in LDS by the whole workgroup: every thread
+// owns one contiguous chunk (serial sum, then serial rewrite), the 256 chunk totals are scanned
+// with wave shuffles -- two barriers per column instead of two per 256 elements.
 __device__ __forceinline__ void lds_scan(double *u, int F, double *wtot, double carry_init)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double carry = carry_init;
-    for (int base = 0; base < F; base += MSD_THREADS) {
-        const int k = base + tid;
-        double v = k < F ? u[k] : 0.0;
-        for (int off = 1; off < 64; off <<= 1) {
-            double n = __shfl_up(v, off, 64);
-            if (lane >= off) v += n;
-        }
-        __syncthreads();
-        if (lane == 63) wtot[wv] = v;
-        __syncthreads();
-        double pre = carry;
-        for (int q = 0; q < wv; q++) pre += wtot[q];
-        if (k < F) u[k] = v + pre;
-        double tot = 0.0;
-        for (int q = 0; q < MSD_THREADS / 64; q++) tot += wtot[q];
-        carry += tot;
+    const int chunk = (F + MSD_THREADS - 1) / MSD_THREADS;
+    const int k0 = min(tid * chunk, F), k1 = min(k0 + chunk, F);
+    double s = 0.0;
+    for (int k = k0; k < k1; k++) s += u[k];
+    double v = s;                                   // inclusive scan of the chunk totals
+    for (int off = 1; off < 64; off <<= 1) {
+        double n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    __syncthreads();
+    if (lane == 63) wtot[wv] = v;
+    __syncthreads();
+    double run = carry_init + (v - s);              // exclusive prefix of this thread's chunk
+    for (int q = 0; q < wv; q++) run += wtot[q];
+    for (int k = k0; k < k1; k++) {
+        run += u[k];
+        u[k] = run;
     }
     __syncthreads();
 }
@@ -189,7 +191,12 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__
         const int64_t atom = perm[gr.start + c / 3];
         const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
         __syncthreads();
-        for (int k = tid; k < F; k += MSD_THREADS) u[k] = col[k];
+        // columns start 256-B aligned and are padded to a multiple of 32 frames: 16-B loads
+        for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
+            const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
+            u[k] = v2.x;
+            if (k + 1 < F) u[k + 1] = v2.y;
+        }
         __syncthreads();
         lds_scan(u, F, red, 0.0);
         if (WREG > 0) {
