@@ -125,6 +125,10 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
                     const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis, QAtom *d_Q,
                     uint32_t *d_slab_start, int32_t *d_flag);
 
+int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
+                     const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis_z, int axis_y, int nz,
+                     QAtom *d_Q, uint32_t *d_start2, int32_t *d_flag);
+
 void timing_begin(amof_ctx *ctx);
 void timing_end(amof_ctx *ctx);
 void timing_dom_begin(amof_ctx *ctx);

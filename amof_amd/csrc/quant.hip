@@ -80,6 +80,80 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
     }
 }
 
+// Two-level variant for small cutoffs in big cells: nz coarse slabs along `axis_z` (each at
+// least one cutoff thick) x 256 fine bins along `axis_y`.  Key = slab * 256 + ybin; the species
+// segment is counting-sorted by key and start2[(fl*S + sp)*(nz*256+1) + key] gives the offset
+// of every (slab, ybin) cell inside the segment -- a 2-D cell list.  Stored component order:
+// (.ux, .uy, .uz) = (remaining axis, axis_y, axis_z).
+__global__ __launch_bounds__(256) void quantize2_kernel(const double *__restrict__ pos,
+                                                        const double *__restrict__ geom, int n_cells,
+                                                        const int32_t *__restrict__ perm,
+                                                        const int64_t *__restrict__ sp_first, int S, int64_t N,
+                                                        int f0, int axis_z, int axis_y, int nz,
+                                                        QAtom *__restrict__ Q, uint32_t *__restrict__ start2,
+                                                        int32_t *flag)
+{
+    extern __shared__ unsigned cnt2[];          // [nz * 256]
+    __shared__ unsigned wsum[4];
+    const int sp = blockIdx.x, fl = blockIdx.y, tid = threadIdx.x;
+    const int f = f0 + fl;
+    const int axis_x = 3 - axis_z - axis_y;
+    const int nkeys = nz * 256;
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const int64_t k0 = sp_first[sp], k1 = sp_first[sp + 1];
+    for (int k = tid; k < nkeys; k += 256) cnt2[k] = 0u;
+    __syncthreads();
+    for (int64_t k = k0 + tid; k < k1; k += 256) {
+        const QAtom q = quantize_atom(pos, g, N, f, perm[k], axis_x, axis_y, axis_z, flag);
+        const unsigned key = __umulhi(q.uz, (unsigned)nz) * 256u + (q.uy >> 24);
+        atomicAdd(&cnt2[key], 1u);
+    }
+    __syncthreads();
+    // exclusive scan: thread t owns the nz consecutive counters [t*nz, (t+1)*nz)
+    unsigned s = 0;
+    for (int k = 0; k < nz; k++) s += cnt2[tid * nz + k];
+    unsigned incl = s;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - s;
+    for (int w = 0; w < wv; w++) run += wsum[w];
+    uint32_t *st = start2 + ((size_t)fl * S + sp) * (size_t)(nkeys + 1);
+    for (int k = 0; k < nz; k++) {
+        const unsigned c = cnt2[tid * nz + k];
+        cnt2[tid * nz + k] = run;
+        st[tid * nz + k] = run;
+        run += c;
+    }
+    if (tid == 255) st[nkeys] = run;
+    __syncthreads();
+    QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
+    for (int64_t k = k0 + tid; k < k1; k += 256) {
+        const QAtom q = quantize_atom(pos, g, N, f, perm[k], axis_x, axis_y, axis_z, flag);
+        const unsigned key = __umulhi(q.uz, (unsigned)nz) * 256u + (q.uy >> 24);
+        const unsigned slot = atomicAdd(&cnt2[key], 1u);
+        Qf[slot] = q;
+    }
+}
+
+int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
+                     const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis_z, int axis_y, int nz,
+                     QAtom *d_Q, uint32_t *d_start2, int32_t *d_flag)
+{
+    if (nf <= 0 || S <= 0) return AMOF_OK;
+    if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
+    if (nz < 1 || nz > 64 || axis_z == axis_y) return fail(ctx, AMOF_EINVAL, "bad two-level grid");
+    dim3 qgrid((unsigned)S, (unsigned)nf);
+    hipLaunchKernelGGL(quantize2_kernel, qgrid, dim3(256), (size_t)nz * 256 * sizeof(unsigned), ctx->stream, pos_dev,
+                       d_geom, n_cells, d_perm, d_spfirst, S, N, f0, axis_z, axis_y, nz, d_Q, d_start2, d_flag);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    return AMOF_OK;
+}
+
 int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                     const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis, QAtom *d_Q,
                     uint32_t *d_slab_start, int32_t *d_flag)

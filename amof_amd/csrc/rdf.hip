@@ -495,6 +495,128 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     }
 }
 
+// --------------------------------------------------------------------------
+// Range kernel: small cutoffs in big cells (rmax <= a third of the slab axis).
+//
+// Frames come 2-level sorted (quantize2_kernel): nz slabs (>= rmax thick) x 256 y-bins.  One
+// workgroup = one 128-atom centre sub-tile x one partner species; instead of meeting fixed
+// partner tiles it walks the partner ranges itself: for each slab within one slab of the
+// centres, the y-bins within rmax of the centres' y range give at most two contiguous index
+// ranges (table start2), streamed through LDS 512 at a time.  Same-species pairs are counted
+// once with a per-lane rule that needs no look-back: partner slab == centre slab + 1 (mod nz):
+// every pair; same slab: partner index > centre index; anything else is the other atom's job
+// (or farther than a whole slab: out of range).  Needs nz >= 3.
+struct RdfRangeArgs {
+    RdfFastArgs f;
+    const uint32_t *start2;   // [nf][S][nz*256 + 1]
+    const int64_t *sp_first;  // [S+1]
+    const int4 *work;         // (centre species a, first centre c0, partner species b, 0)
+    int32_t nz;
+    int32_t gy_bins;          // y reach in bins (rmax / h_y * 256, rounded up, + 1)
+};
+
+template <bool ORTHO>
+__global__ __launch_bounds__(FAST_THREADS, 5) void rdf_range_kernel_fast(RdfRangeArgs ra)
+{
+    const RdfFastArgs &fa = ra.f;
+    const RdfArgs &a = fa.a;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    uint4 *tq = reinterpret_cast<uint4 *>(lds_raw);                  // [FAST_TILE] partner chunk
+    unsigned *hist = reinterpret_cast<unsigned *>(tq + FAST_TILE);    // [nbins]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int4 w = ra.work[blockIdx.x];
+    const int sa_ = w.x, c0 = w.y, sb_ = w.z;
+    const bool same = sa_ == sb_;
+    const int nz = ra.nz, nkeys = nz * 256;
+    const int nbins = a.nbins;
+    for (int k = tid; k < nbins; k += FAST_THREADS) hist[k] = 0u;
+    const int64_t segA = ra.sp_first[sa_], segB = ra.sp_first[sb_];
+    const int nA = (int)(ra.sp_first[sa_ + 1] - segA);
+    const int cnt_c = min(FAST_SUB, nA - c0);
+    const int la = 2 * lane, lb = la + 1;
+    const bool has_a = la < cnt_c, has_b = lb < cnt_c;
+    const float half_m_guard = 0.5f - fa.guard;
+    const float nb_hi = fa.nbins_f + fa.guard;
+    const int f0 = blockIdx.y * a.frames_per_chunk;
+    const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
+
+    for (int fl = f0; fl < f1; fl++) {
+        const int f = fa.f_base + fl;
+        const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+        const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
+        const int gi = a.n_cells == 1 ? 0 : f;
+        const FrameScale *__restrict__ fs = fa.fs + gi;
+        const double *__restrict__ g = a.geom + (size_t)gi * GEOM_STRIDE;
+        float sc[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
+        const uint32_t *__restrict__ stB = ra.start2 + ((size_t)fl * a.S + sb_) * (size_t)(nkeys + 1);
+        // this lane's two centre atoms and their slabs
+        const QAtom ca = Qf[segA + c0 + min(la, cnt_c - 1)], cb = Qf[segA + c0 + min(lb, cnt_c - 1)];
+        const int za = (int)__umulhi(ca.uz, (unsigned)nz), zb = (int)__umulhi(cb.uz, (unsigned)nz);
+        // slab / y-bin extent of the sub-tile (it is sorted by (slab, ybin): first and last atom)
+        const QAtom cf = Qf[segA + c0], cl = Qf[segA + c0 + cnt_c - 1];
+        const int s_first = (int)__umulhi(cf.uz, (unsigned)nz), s_last = (int)__umulhi(cl.uz, (unsigned)nz);
+        const bool one_slab = s_first == s_last;
+        int ylo = 0, yhi = 255;
+        bool y_full = true;
+        if (one_slab) {
+            const int y0 = (int)(cf.uy >> 24) - ra.gy_bins, y1 = (int)(cl.uy >> 24) + ra.gy_bins;
+            if (y1 - y0 + 1 < 256) { y_full = false; ylo = y0 & 255; yhi = y1 & 255; }
+        }
+        // partner slabs: [s_first - 1 (different species only), s_last + 1], each at most once
+        int p_begin = same ? s_first : s_first - 1;
+        int p_count = s_last + 1 - p_begin + 1;
+        if (p_count > nz) { p_count = nz; }
+        for (int pi = 0; pi < p_count; pi++) {
+            const int ps = ((p_begin + pi) % nz + nz) % nz;
+            // per-lane rule for this partner slab: threshold on the partner's sorted index
+            //   -1: every partner counts, INT_MAX: none, i: partners with index > i
+            auto thresh = [&](int zc, int iabs) {
+                const int d = ((ps - zc) % nz + nz) % nz;
+                if (same) return d == 1 ? -1 : (d == 0 ? iabs : 0x7fffffff);
+                return (d <= 1 || d == nz - 1) ? -1 : 0x7fffffff;
+            };
+            const int tha = thresh(za, c0 + la), thb = thresh(zb, c0 + lb);
+            // y ranges of this slab: [ylo, yhi] circular -> one or two index ranges
+            int rb[2], re[2];
+            const uint32_t *row = stB + ps * 256;
+            if (y_full || ylo <= yhi) {
+                rb[0] = (int)row[y_full ? 0 : ylo]; re[0] = (int)row[(y_full ? 255 : yhi) + 1];
+                rb[1] = re[1] = 0;
+            } else {
+                rb[0] = (int)row[0]; re[0] = (int)row[yhi + 1];
+                rb[1] = (int)row[ylo]; re[1] = (int)row[256];
+            }
+            for (int r = 0; r < 2; r++) {
+                for (int base = rb[r]; base < re[r]; base += FAST_TILE) {
+                    const int cntj = min(FAST_TILE, re[r] - base);
+                    const int cntj4 = (cntj + 3) & ~3;
+                    __syncthreads();
+                    for (int k = tid; k < cntj4; k += FAST_THREADS) {
+                        const QAtom q = Qf[segB + base + min(k, cntj - 1)];
+                        tq[k] = make_uint4(q.ux, q.uy, q.uz, q.idx);
+                    }
+                    __syncthreads();
+                    // per-lane thresholds relative to this chunk (fast_quad's "j > ia" form)
+                    const int ia = tha == -1 ? -1 : (tha == 0x7fffffff ? 0x7fffffff : tha - base);
+                    const int ib = thb == -1 ? -1 : (thb == 0x7fffffff ? 0x7fffffff : thb - base);
+                    for (int j0 = 4 * wave; j0 < cntj4; j0 += 16)
+                        fast_quad<ORTHO, true, true>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                                                     nb_hi, ca.ux, ca.uy, ca.uz, ca.idx, cb.ux, cb.uy, cb.uz, cb.idx, p);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int lo = min(sa_, sb_), hi = max(sa_, sb_);
+    unsigned long long *U = a.U + ((size_t)lo * a.S + hi) * (size_t)nbins;
+    for (int k = tid; k < nbins; k += FAST_THREADS) {
+        unsigned v = hist[k];
+        if (v) atomicAdd(&U[k], (unsigned long long)v);
+    }
+}
+
 // hist[a][b][k] += (a == b) ? 2*U[a][a][k] + nsp[a]*selfh[k] : U[min][max][k]
 __global__ void rdf_finalize_kernel(const unsigned long long *U, const unsigned long long *selfh,
                                     const long long *nsp, unsigned long long *hist, int S, int nbins)
@@ -672,6 +794,99 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             fa.guard = (float)guard_f;
             fa.nbins_f = (float)nbins;
             fa.guard64 = guard_m;
+            // ---- two-level cell list for small cutoffs (range kernel) ----
+            int axis_y = (axis + 1) % 3;
+            if (hmin[(axis + 2) % 3] > hmin[axis_y]) axis_y = (axis + 2) % 3;
+            const int nz2 = (int)std::min(64.0, floor(hmin[axis] / (rmax * (1.0 + 1e-5))));
+            bool use_range = false;
+            if (nz2 >= 3 && t->n_cells == 1 && !(getenv("AMOF_RDF_NORANGE"))) {
+                // visited share of the partners: 1-D slab list vs (3 slabs) x (y strip + 2 rmax)
+                int64_t nmax = 0;
+                for (int x = 0; x < S; x++) nmax = std::max<int64_t>(nmax, ftiles.nsp[x]);
+                const double strip = std::min(1.0, (double)FAST_SUB * nz2 / std::max<double>(1.0, (double)nmax));
+                const double f1 = std::min(1.0, 2.0 * rmax / hmin[axis] + 2.0 / 256 + 0.02);
+                const double f2 = std::min(1.0, 3.0 / nz2) * std::min(1.0, 2.0 * rmax / hmin[axis_y] + strip + 2.0 / 256);
+                use_range = f2 < 0.6 * f1 || getenv("AMOF_RDF_FORCE_RANGE") != nullptr;   // (forced: tests)
+            }
+            if (use_range) {
+                const int gy = (int)ceil(rmax * (1.0 + 1e-5) / hmin[axis_y] * 256.0) + 1;
+                // scale records: stored component order is (remaining axis, axis_y, axis)
+                const int ax_x = 3 - axis - axis_y;
+                const int ord2[3] = {ax_x, axis_y, axis};
+                for (int64_t k = 0; k < nc; k++) {
+                    const double *c = t->cell + 9 * k;
+                    FrameScale &r = fsv[(size_t)k];
+                    for (int q = 0; q < 9; q++) r.sc64[q] = 0.0;
+                    if (ortho) {
+                        for (int q = 0; q < 3; q++) r.sc64[q] = c[4 * ord2[q]] * two32 / dr;
+                    } else {
+                        for (int q = 0; q < 3; q++)
+                            for (int x = 0; x < 3; x++) r.sc64[3 * q + x] = c[3 * ord2[q] + x] * two32 / dr;
+                    }
+                    for (int q = 0; q < 9; q++) r.sc[q] = (float)r.sc64[q];
+                    r.cull_gap = 0u;
+                }
+                AMOF_TRY(upload(ctx, SLOT_AUX5, fsv.data(), fsv.size() * sizeof(FrameScale), &d_fs));
+                fa.fs = (const FrameScale *)d_fs;
+                std::vector<int4> rwork;
+                for (int sa2 = 0; sa2 < S; sa2++)
+                    for (int64_t c0 = 0; c0 < ftiles.nsp[sa2]; c0 += FAST_SUB)
+                        for (int sb2 = sa2; sb2 < S; sb2++)
+                            if (ftiles.nsp[sb2] > 0) rwork.push_back(make_int4(sa2, (int)c0, sb2, 0));
+                void *d_rwork, *d_start2, *d_Q2, *d_flag2;
+                AMOF_TRY(upload(ctx, SLOT_AUX6, rwork.data(), rwork.size() * sizeof(int4), &d_rwork));
+                const size_t per_frame = (size_t)t->n_atoms * sizeof(QAtom) + (size_t)S * (nz2 * 256 + 1) * sizeof(uint32_t);
+                int64_t FB2 = std::max<int64_t>(1, (int64_t)(1ll << 30) / (int64_t)per_frame);
+                FB2 = std::min<int64_t>(std::min<int64_t>(FB2, 32768), t->n_frames);
+                AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB2 * t->n_atoms * sizeof(QAtom), &d_Q2));
+                AMOF_TRY(ensure(ctx, SLOT_AUX7, (size_t)FB2 * S * (nz2 * 256 + 1) * sizeof(uint32_t), &d_start2));
+                AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag2));
+                AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag2, 0, sizeof(int32_t), ctx->stream));
+                RdfRangeArgs ra;
+                ra.f = fa;
+                ra.f.Q = (const QAtom *)d_Q2;
+                ra.f.xcd_map = 0;
+                ra.start2 = (const uint32_t *)d_start2;
+                ra.sp_first = (const int64_t *)d_spfirst;
+                ra.work = (const int4 *)d_rwork;
+                ra.nz = nz2;
+                ra.gy_bins = gy;
+                size_t lds2 = FAST_TILE * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
+                int64_t launches = 0;
+                for (int64_t fb = 0; fb < t->n_frames && !rwork.empty(); fb += FB2) {
+                    const int64_t nf = std::min<int64_t>(FB2, t->n_frames - fb);
+                    AMOF_TRY(launch_quantize2(ctx, pos_dev, (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm,
+                                              (const int64_t *)d_spfirst, S, t->n_atoms, (int)fb, (int)nf, axis, axis_y, nz2,
+                                              (QAtom *)d_Q2, (uint32_t *)d_start2, (int32_t *)d_flag2));
+                    ra.f.f_base = (int32_t)fb;
+                    ra.f.nf = (int32_t)nf;
+                    int64_t want_chunks = (8 * 2048 + (int64_t)rwork.size() - 1) / (int64_t)rwork.size();
+                    int64_t fpc = std::max<int64_t>(1, nf / std::max<int64_t>(1, want_chunks));
+                    fpc = std::min<int64_t>(fpc, 16);
+                    int64_t chunks = (nf + fpc - 1) / fpc;
+                    ra.f.a.frames_per_chunk = (int32_t)fpc;
+                    dim3 grid((unsigned)rwork.size(), (unsigned)chunks);
+                    if (launches == 0) timing_dom_begin(ctx);
+                    hipError_t e;
+                    if (ortho) {
+                        e = hipFuncSetAttribute((const void *)rdf_range_kernel_fast<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                        if (e == hipSuccess) hipLaunchKernelGGL(rdf_range_kernel_fast<true>, grid, dim3(FAST_THREADS), lds2, ctx->stream, ra);
+                    } else {
+                        e = hipFuncSetAttribute((const void *)rdf_range_kernel_fast<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                        if (e == hipSuccess) hipLaunchKernelGGL(rdf_range_kernel_fast<false>, grid, dim3(FAST_THREADS), lds2, ctx->stream, ra);
+                    }
+                    AMOF_HIP_TRY(ctx, e);
+                    AMOF_HIP_TRY(ctx, hipGetLastError());
+                    launches++;
+                }
+                timing_dom_end(ctx, launches);
+                int32_t flag2 = 0;
+                AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag2, d_flag2, sizeof flag2, hipMemcpyDeviceToHost, ctx->stream));
+                AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (flag2) AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));
+                else done = true;
+            }
+            if (!done && !use_range) {
             int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
             FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), t->n_frames);
             void *d_Q, *d_flag;
@@ -724,6 +939,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             } else {
                 done = true;
             }
+            }   // tile kernel (not the range kernel)
         }
         if (!done) {
         unsigned chunks;

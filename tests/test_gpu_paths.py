@@ -173,3 +173,26 @@ def test_direct_msd_matches_reference_restatement(hip_ctx):
         np.testing.assert_allclose(d.data[eldata.chemical_symbols[int(e)]].values, ref[e], rtol=1e-9, atol=1e-12)
     # wrapped random walk: the running unwrap recovers the true displacement
     assert d.data["X"].values[-1] > 1.0
+
+
+@pytest.mark.parametrize("tri", [False, True])
+def test_rdf_range_kernel_two_level_cell_list(hip_ctx, tri):
+    # long cell, small cutoff: the 2-level (slab x y-bin) range kernel is selected; it must agree
+    # with the 1-D slab path, the exact kernels and the oracle
+    base = H.replicate(H.zif4_frame(), (2, 2, 5))            # 5440 atoms, 30.8 x 30.8 x 92.2 A
+    packed = H.random_walk(base, 3, 0.08, 61, ortho=not tri)
+    kinds, sp = H.species_of(packed.numbers)
+    for rmax, nb in [(5.0, 500), (9.5, 333)]:
+        with _env(AMOF_RDF_FORCE_RANGE="1"):
+            got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        with _env(AMOF_RDF_NORANGE="1"):
+            slab, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
+        assert np.array_equal(got, ref) and np.array_equal(slab, ref)
+    # exactly three slabs (nz = 3): the forward-slab rule must not double count across the wrap
+    small = H.random_walk(H.replicate(H.zif4_frame(), (1, 1, 2)), 2, 0.05, 62, ortho=not tri)
+    for rmax, nb in [(5.0, 250), (12.0, 240), (12.29, 1229)]:        # nz = 7, 3, 3
+        with _env(AMOF_RDF_FORCE_RANGE="1"):
+            got, _, _ = hip_ctx.rdf_accumulate(small, rmax, nb)
+        ref, _ = clib.rdf_hist(small.pos, small.cell, H.species_of(small.numbers)[1], 4, rmax, nb)
+        assert np.array_equal(got, ref), rmax
