@@ -151,3 +151,123 @@ class Rdf(object):
     def read_rdf_file(self, path_to_data):
         path_to_data = _path.append_suffix(path_to_data, 'rdf')
         self.data = pd.read_feather(path_to_data)
+
+    def get_coordination_number(self, nn_set, cutoff, density):
+        """
+        return coordination number (reference amof/rdf.py:124-131)
+        nn_set: str indicating pair of neighbours
+        cutoff: float, in Angstrom
+        density: float, no units
+        """
+        return get_coordination_number(self.data['r'], self.data[nn_set], cutoff, density)
+
+
+def _basic_simps(y, start, stop, x):
+    """scipy.integrate._quadrature._basic_simpson for sample points x (scipy 1.7.1, [3P-memory])"""
+    step = 2
+    h = np.diff(x)
+    sl0, sl1, sl2 = slice(start, stop, step), slice(start + 1, stop + 1, step), slice(start + 2, stop + 2, step)
+    h0 = h[sl0]
+    h1 = h[sl1]
+    hsum = h0 + h1
+    hprod = h0 * h1
+    h0divh1 = h0 / h1
+    tmp = hsum / 6.0 * (y[sl0] * (2 - 1.0 / h0divh1) + y[sl1] * (hsum * hsum / hprod) + y[sl2] * (2 - h0divh1))
+    return np.sum(tmp)
+
+
+def simps(y, x):
+    """``scipy.integrate.simps(y, x)`` as in scipy 1.7.1 (default ``even='avg'``), which the reference
+    pins (requirements.txt:15) and calls at amof/rdf.py:226.  Modern ``scipy.integrate.simpson`` treats
+    an even number of samples differently, so the algorithm is restated here ([3P-memory])."""
+    y = np.asarray(y, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    N = len(y)
+    if N < 2:
+        return 0.0
+    if N % 2 == 0:
+        val = 0.5 * (x[-1] - x[-2]) * (y[-1] + y[-2]) + 0.5 * (x[1] - x[0]) * (y[1] + y[0])
+        result = _basic_simps(y, 0, N - 3, x) + _basic_simps(y, 1, N - 2, x)
+        return result / 2.0 + val / 2.0
+    return _basic_simps(y, 0, N - 2, x)
+
+
+def get_coordination_number(r, rdf, cutoff, density):
+    """
+    return coordination number (reference amof/rdf.py:216-227)
+    r, rdf: arrays of same size
+    cutoff: float, in Angstrom
+    density: float, number density of the entire system (counting every species) in Angstrom^-3
+    """
+    r = np.asarray(r)
+    rdf = np.asarray(rdf)
+    mask = (r > 0) & (r < cutoff)
+    r = r[mask]
+    rdf = rdf[mask]
+    integral = simps(rdf * (r ** 2), r)
+    return 4 * np.pi * density * integral
+
+
+class CoordinationNumber(object):
+    """
+    Class to compute CoordinationNumber from RDF (mirror of reference amof/rdf.py:135-214;
+    deprecated there: "Subjected to numerical errors in the integration step.  Best to use
+    amof.cn.CoordinationNumber").
+
+    Per frame, the partial RDF of every neighbour set is histogrammed on the GPU with
+    ``dr`` (default 1e-4 A) up to the largest cutoff and integrated with Simpson's rule.
+    The reference asks asap3 for ``get_rdf`` on an object that never ran ``update()``
+    (amof/rdf.py:181-185); what is computed here is the evident intent, the RDF of that frame.
+    """
+
+    def __init__(self):
+        """default constructor"""
+        logger.warning('Compute CoordinationNumber from RDF, best to use amof.cn.CoordinationNumber')
+        self.data = pd.DataFrame({"Step": np.empty([0])})
+
+    @classmethod
+    def from_trajectory(cls, trajectory, nb_set_and_cutoff, delta_Step=1, first_frame=0, dr=0.0001, parallel=False,
+                        device=None):
+        from . import trajectory as _trajectory
+        cn_class = cls()
+        step = _trajectory.construct_step(delta_Step=delta_Step, first_frame=first_frame,
+                                          number_of_frames=len(trajectory))
+        cn_class.compute_cn(trajectory, nb_set_and_cutoff, step, dr, parallel, device=device)
+        return cn_class
+
+    def compute_cn(self, trajectory, nb_set_and_cutoff, step, dr, parallel=False, device=None):
+        packed = pack_trajectory(trajectory)
+        rmax = float(np.max(list(nb_set_and_cutoff.values())))
+        logger.info("Start computing coordination number for %s frames with dr = %s and rmax = %s", len(packed), dr, rmax)
+        bins = int(rmax // dr)
+        r = np.arange(bins) * dr
+        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        ctx = _hip.get_context(dev)
+        natoms = packed.n_atoms
+        rows = []
+        for k in range(len(packed)):
+            hist, vol, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=(k, k + 1))
+            idx = {z: i for i, z in enumerate(kinds)}
+            dic = {'Step': step[k]}
+            density = natoms / vol                                     # amof.atom.get_number_density
+            for nn_set, cutoff in nb_set_and_cutoff.items():
+                za, zb = tuple(_data.atomic_numbers[i] for i in nn_set.split('-'))
+                n_a = int((packed.numbers == za).sum())
+                g = normalize_rdf(hist[idx[za], idx[zb]], n_a, natoms, vol, rmax, bins)
+                dic[nn_set] = get_coordination_number(r, g, cutoff, density)
+            rows.append(dic)
+        self.data = pd.DataFrame(rows)
+
+    @classmethod
+    def from_file(cls, filename):
+        cn_class = cls()
+        cn_class.read_cn_file(filename)
+        return cn_class
+
+    def read_cn_file(self, filename):
+        filename = _path.append_suffix(filename, 'cn')
+        self.data = pd.read_feather(filename)
+
+    def write_to_file(self, filename):
+        filename = _path.append_suffix(filename, 'cn')
+        self.data.to_feather(filename)

@@ -145,3 +145,19 @@ def test_to_device_round_trip(zif4):
     a = CoordinationNumber.from_trajectory(packed, {'Zn-N': 2.5}).data.values
     b = CoordinationNumber.from_trajectory(dev, {'Zn-N': 2.5}).data.values
     assert np.array_equal(a, b)
+
+
+def test_rdf_integration_coordination_number(zif4):
+    # deprecated RDF-integration CN: must agree with the counting CN up to its integration error
+    from amof_amd.rdf import CoordinationNumber as RdfCn
+    packed = H.random_walk(zif4, 3, 0.02, 21)
+    a = RdfCn.from_trajectory(packed, {'Zn-N': 2.5, 'C-H': 1.3}, delta_Step=2, first_frame=5, dr=0.001)
+    b = CoordinationNumber.from_trajectory(packed, {'Zn-N': 2.5, 'C-H': 1.3}, delta_Step=2, first_frame=5)
+    assert list(a.data.columns) == ["Step", "Zn-N", "C-H"] and list(a.data["Step"]) == [5, 7, 9]
+    np.testing.assert_allclose(a.data["Zn-N"].values, b.data["Zn-N"].values, rtol=0.01)
+    # single-frame histograms at dr = 1e-3 are spikes; Simpson's alternating 4/3, 2/3 weights make the
+    # integral noisy (the reference warns about exactly this, amof/rdf.py:139-141)
+    np.testing.assert_allclose(a.data["C-H"].values, b.data["C-H"].values, rtol=0.34)
+    rdf = Rdf.from_trajectory(packed, dr=0.001, rmax=6.0)
+    rho = 272 / zif4.get_volume()
+    assert rdf.get_coordination_number("Zn-N", 2.5, rho) == pytest.approx(4.0, rel=0.02)

@@ -131,3 +131,23 @@ def test_shard_range_partitions():
     assert dist.world() == (0, 1)
     x = np.arange(4, dtype=np.uint64)
     assert dist.all_reduce_sum(x) is x
+
+
+def test_simps_restatement_and_rdf_integration_cn():
+    import scipy.integrate
+    from amof_amd.rdf import simps, get_coordination_number
+    rng = np.random.default_rng(0)
+    x = np.sort(rng.uniform(0, 3, 41))
+    y = np.sin(x) + x ** 2
+    # odd number of samples: plain composite Simpson, identical in every scipy
+    assert simps(y, x) == pytest.approx(scipy.integrate.simpson(y, x=x), rel=1e-13)
+    # even number: scipy 1.7.1's 'avg' = mean of (Simpson on the first N-1 + trapezoid on the last interval)
+    # and (trapezoid on the first interval + Simpson on the last N-1)
+    xe, ye = x[:-1], y[:-1]
+    first = scipy.integrate.simpson(ye[:-1], x=xe[:-1]) + 0.5 * (xe[-1] - xe[-2]) * (ye[-1] + ye[-2])
+    last = scipy.integrate.simpson(ye[1:], x=xe[1:]) + 0.5 * (xe[1] - xe[0]) * (ye[1] + ye[0])
+    assert simps(ye, xe) == pytest.approx(0.5 * (first + last), rel=1e-13)
+    # CN of an ideal gas: 4 pi rho int_0^rc r^2 dr = rho * (4/3) pi rc^3
+    r = np.arange(3000) * 0.001
+    rho, rc = 0.05, 2.5
+    assert get_coordination_number(r, np.ones_like(r), rc, rho) == pytest.approx(rho * 4 / 3 * np.pi * rc ** 3, rel=2e-3)
