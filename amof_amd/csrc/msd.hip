@@ -307,16 +307,31 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel_global(const dou
     }
 }
 
-__global__ __launch_bounds__(MSD_THREADS) void com_T_kernel(const double *__restrict__ UT,
-                                                            const double *__restrict__ masses, int64_t N,
-                                                            int64_t Fp, int F, double total_mass,
-                                                            double *__restrict__ com)
+// centre of mass from the atom-major layout, in two deterministic stages: partial sums over
+// blocks of COMT_BLK atoms (thread = frame k, coalesced along k), then the blocks in order
+constexpr int COMT_BLK = 128;
+__global__ __launch_bounds__(MSD_THREADS) void com_T_partial_kernel(const double *__restrict__ UT,
+                                                                    const double *__restrict__ masses, int64_t N,
+                                                                    int64_t Fp, int F, double *__restrict__ part)
+{
+    const int k = blockIdx.x * MSD_THREADS + threadIdx.x;
+    const int c = blockIdx.y;
+    const int64_t i0 = (int64_t)blockIdx.z * COMT_BLK, i1 = min(i0 + COMT_BLK, N);
+    if (k >= F) return;
+    double s = 0.0;
+    for (int64_t i = i0; i < i1; i++) s += masses[i] * UT[(size_t)(3 * i + c) * Fp + k];
+    part[((size_t)blockIdx.z * 3 + c) * Fp + k] = s;
+}
+
+__global__ __launch_bounds__(MSD_THREADS) void com_T_final_kernel(const double *__restrict__ part, int nblk,
+                                                                  int64_t Fp, int F, double total_mass,
+                                                                  double *__restrict__ com)
 {
     const int k = blockIdx.x * MSD_THREADS + threadIdx.x;
     const int c = blockIdx.y;
     if (k >= F) return;
     double s = 0.0;
-    for (int64_t i = 0; i < N; i++) s += masses[i] * UT[(size_t)(3 * i + c) * Fp + k];
+    for (int b = 0; b < nblk; b++) s += part[((size_t)b * 3 + c) * Fp + k];
     com[3 * k + c] = s / total_mass;
 }
 
@@ -487,9 +502,15 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         hipLaunchKernelGGL(scan_column_kernel, dim3((unsigned)(3 * N)), dim3(MSD_THREADS), 0, ctx->stream,
                            (const double *)d_DT, pos_dev, Fp, (int)F, (double *)d_UT);
         if (remove_com) {
-            hipLaunchKernelGGL(com_T_kernel, dim3((unsigned)((F + MSD_THREADS - 1) / MSD_THREADS), 3),
+            const int nblk = (int)((N + COMT_BLK - 1) / COMT_BLK);
+            void *d_cpart;
+            AMOF_TRY(ensure(ctx, SLOT_AUX6, (size_t)nblk * 3 * Fp * sizeof(double), &d_cpart));
+            hipLaunchKernelGGL(com_T_partial_kernel, dim3((unsigned)((F + MSD_THREADS - 1) / MSD_THREADS), 3, (unsigned)nblk),
                                dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_UT, (const double *)d_mass, N, Fp,
-                               (int)F, total_mass, (double *)d_com);
+                               (int)F, (double *)d_cpart);
+            hipLaunchKernelGGL(com_T_final_kernel, dim3((unsigned)((F + MSD_THREADS - 1) / MSD_THREADS), 3),
+                               dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_cpart, nblk, Fp, (int)F, total_mass,
+                               (double *)d_com);
         }
         hipLaunchKernelGGL(delta_T_kernel, dim3((unsigned)N, (unsigned)((F + MSD_THREADS - 1) / MSD_THREADS)),
                            dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_UT, (const double *)d_com,
