@@ -13,10 +13,11 @@
  *   - plain C types only; no C++ exceptions cross the boundary; never aborts.
  *   - return value: 0 = AMOF_OK, negative = error; amof_last_error(ctx) gives
  *     a human-readable message for the last failing call on that context.
- *   - buffers are caller-owned; the library keeps no caller pointer after a
- *     host-output call returns.  "_dev" entry points take caller-owned DEVICE
- *     output buffers and enqueue work on the context's stream (see
- *     amof_ctx_set_stream); the caller synchronises.
+ *   - buffers are caller-owned; the library keeps no caller pointer after a call
+ *     returns.  Every entry point is synchronous: it returns after its work on the
+ *     context's stream has completed.  "_dev" entry points take caller-owned DEVICE
+ *     output buffers (e.g. a torch tensor that an RCCL all-reduce consumes next) and
+ *     run on the stream set with amof_ctx_set_stream.
  *   - a context is bound to one device and is not thread-safe; distinct
  *     contexts may be used concurrently.  ctypes releases the GIL during calls.
  *   - all integer results are exact and independent of launch geometry.
