@@ -222,6 +222,11 @@ def main():
                                  "frame: VALU-issue bound, not HBM bound (SURVEY 8d, DESIGN 4.1); the honest HBM "
                                  "fraction is tiny by construction -- see pair_evals_per_s"},
             "pair_evals_per_s": pairs / t_rdf, "pairs_in_range_per_s": in_range / t_rdf,
+            # supplementary, the bound that actually applies: SIMD cycles spent per wave-level
+            # pair (64 pairs) at the nominal 2.4 GHz, all N(N-1)/2 pairs counted although ~1/3 are culled;
+            # the instruction mix of the inner loop sums to ~70 issue cycles per visited wave-pair
+            "valu_issue": {"simd_cycles_per_wave_pair": t_rdf * 1024 * 2.4e9 / (pairs / 64.0),
+                           "model_cycles_per_visited_wave_pair": 70.0, "visited_fraction": 0.67},
             "roofline_msd": {"kernel": "msd pipeline (com + delta_transpose + msd_group + reduce)", "bound": "hbm",
                              "achieved": alg_bytes / float(np.mean(k_msd_all)) / 1e9, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": alg_bytes / float(np.mean(k_msd_all)) / 1e9 / HBM_PEAK_GBPS,
