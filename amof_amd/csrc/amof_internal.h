@@ -96,6 +96,36 @@ int build_images(amof_ctx *ctx, const amof_traj *t, const HostGeom &g, double R,
                  std::vector<double> &img /* [n_cells][max_img][3] */, std::vector<int32_t> &nimg,
                  int &max_img);
 
+// Error model of the f32 candidate distance of the fast paths (rdf.hip, nbr.hip):
+//   q~ = v_sqrt_f32( sum_c d_c^2 ),  d_c = sum_k float(i_k) * s_kc   (s = cell rows * 2^-32 [/ dr])
+// With u = 2^-24:  |q~ - q| <= (5 kappa + 3.06) u q, where kappa bounds how much larger than the
+// pair vector the summands of d_c can be (cancellation in sheared cells):
+//   sum_k |f_k| |C_kc| <= (|d| P)_c,  P = |C^-1| |C|,  kappa = sqrt(||P||_1 ||P||_inf) >= ||P||_2
+// (kappa = 1 for a diagonal cell, whose kernels multiply instead of summing: 4.5u + root).
+// v_sqrt_f32 on gfx950: <= 1 ulp from correctly rounded, relative error <= 1.56 u, measured
+// exhaustively (profiles/tools/sqrt_ulp.hip).  Both bounds carry a further 10 % margin.
+inline double fast_guard_rel(const HostGeom &g, int64_t n_cells)
+{
+    const double u = 1.0 / 16777216.0;
+    if (g.all_ortho) return 1.1 * (4.5 + 1.56) * u;
+    double kappa = 1.0;
+    for (int64_t k = 0; k < n_cells; k++) {
+        const double *c = g.rec.data() + (size_t)k * GEOM_STRIDE, *inv = c + 9;
+        double P[3][3], n1 = 0.0, ninf = 0.0;
+        for (int r = 0; r < 3; r++)
+            for (int x = 0; x < 3; x++) {
+                P[r][x] = 0.0;
+                for (int m = 0; m < 3; m++) P[r][x] += fabs(inv[3 * r + m]) * fabs(c[3 * m + x]);
+            }
+        for (int r = 0; r < 3; r++) {
+            ninf = std::max(ninf, P[r][0] + P[r][1] + P[r][2]);
+            n1 = std::max(n1, P[0][r] + P[1][r] + P[2][r]);
+        }
+        kappa = std::max(kappa, sqrt(n1 * ninf));
+    }
+    return 1.1 * (5.0 * kappa + 3.06) * u;
+}
+
 // species-sorted tiling of the atoms
 struct Tile {
     int32_t start;    // offset into perm

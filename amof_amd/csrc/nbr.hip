@@ -678,9 +678,17 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     fa.slab_start = (const uint32_t *)nf.d_slab;
     fa.cells = (const NbrCell *)nf.d_cells;
     fa.sp_first = (const int64_t *)nf.d_spfirst;
-    // f32 chain error <= 3.9e-7 relative (see rdf.hip) + image-choice slack 2e-7 near h/2: 1e-6;
-    // the fixed-point grid moves a distance by < csum * 2^-32 (x2 margin)
-    fa.guard_rel = 1e-6f;
+    // f32 chain error: fast_guard_rel (amof_internal.h); the fixed-point grid moves a distance by
+    // < csum * 2^-32 (x2 margin)
+    const double grel = fast_guard_rel(st.geom, nc);
+    fa.guard_rel = (float)(grel * (1.0 + 1e-6));
+    if (!nf.ortho) {
+        // sheared cells: wrapped and canonical images may differ at |s_k| = 1/2 -- both must then be
+        // decisively beyond every cutoff (see rdf.hip)
+        for (int x = 0; x < 3; x++)
+            if (R * (1.0 + 4.0 * grel + 1e-6) >= 0.5 * hmin[x]) nf.ok = false;
+        if (!nf.ok) return AMOF_OK;
+    }
     fa.guard_abs = (float)(csum * (1.0 / 2147483648.0));
     return AMOF_OK;
 }

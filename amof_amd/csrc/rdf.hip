@@ -186,14 +186,16 @@ __global__ __launch_bounds__(RDF_TILE) void rdf_tile_kernel_global(RdfArgs a)
 // fractional coordinates as 32-bit fixed point, species-sorted (16 B / atom).
 // In the pair loop the minimum image is then free -- the u32 difference wraps --
 // and an f32 candidate bin q~ = sqrt(d2~)/dr is accepted only when it is
-// provably the canonical one:  |q~ - q| <= g  with
-//     g = nbins * 1e-6  +  2 * quant / dr,   quant = 2^-31 * (|c0|+|c1|+|c2|)
-// (f32 chain: cvt, scale, 3 squares/fma, v_sqrt_f32 <= 1 ulp, scale: relative
-// error < 5.1e-7 on q; the fixed-point grid moves a distance by < quant).  A
-// lane whose q~ lies within g of an integer (or of nbins) recomputes the pair
-// with the canonical f64 arithmetic and exact sqrt/divide.  Where the two
-// disagree on the periodic image (|s_k| ~ 1/2) both distances are >= rmax(1-2e-7),
-// i.e. inside the guard of nbins, so the slow path decides those too.
+// provably the canonical one:  |q~ - q| <= g_f  with
+//     g_f = nbins * eps_f + g_m,   g_m = quant / dr + nbins * 1e-12,   quant = 2^-31 * (|c0|+|c1|+|c2|)
+// eps_f = fast_guard_rel() bounds the relative error of the f32 chain (cvt, scale, squares/fma and
+// v_sqrt_f32; 4.0e-7 for diagonal cells, (5 kappa + 3.06) * 2^-24 * 1.1 for sheared ones); the
+// fixed-point grid moves a distance by < quant.  A lane whose q~ lies within g_f of an integer (or
+// of nbins) is refined: first with the f64 distance of the same integer differences (decides unless
+// within g_m of the edge), then with the canonical f64 arithmetic and exact sqrt/divide.  At
+// |s_k| = 1/2 the wrapped image and the canonical one may differ: in a diagonal cell both have the
+// same length; sheared cells take the fast path only when the cutoff stays clear of every half
+// height, so both images are out of range there.
 // per-cell record of the fast path (one per frame when the cell changes)
 struct FrameScale {
     float sc[9];        // ORTHO: sc[0..2] = L_k * 2^-32 / dr ; else cell[k][c] * 2^-32 / dr (rows in stored order)
@@ -735,13 +737,20 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         // quant carries a factor 2 of margin (it also covers the f64 rounding of the fold, |s| < 1e4)
         const double quant = csum * (1.0 / 2147483648.0);
         const double guard_m = quant / dr + (double)nbins * 1e-12;
-        // f32 candidate: cvt, scale, product (3u each component), square, two fmas -> 9u on the
-        // squared distance, 4.5u after the root, + v_sqrt_f32 (1 ulp = 2u): 6.5u = 3.9e-7 relative;
-        // 5.5e-7 also covers a 2-ulp root
-        const double guard_f = (double)nbins * 5.5e-7 + guard_m;
+        // f32 candidate: relative error bound of the chain, see fast_guard_rel (amof_internal.h)
+        const double guard_f = (double)nbins * fast_guard_rel(geom, nc) + guard_m;
         const char *force = getenv("AMOF_RDF_KERNEL");
         bool fast = !extra && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS - 5120 &&
                     guard_f < 0.25 && !(force && strcmp(force, "v1") == 0);
+        if (fast && !ortho) {
+            // At |s_k| = 1/2 the wrapped fixed-point image and the canonical rint() image can be different
+            // lattice images of unequal length in a sheared cell (equal in a diagonal one): keep both
+            // decisively out of range, i.e. the cutoff clear of every half height by more than the guards.
+            for (int64_t k = 0; k < nc && fast; k++)
+                for (int x = 0; x < 3; x++)
+                    if (rmax * (1.0 + 4.0 * guard_f / (double)nbins + 1e-6) >= 0.5 * geom.rec[(size_t)k * GEOM_STRIDE + 18 + x])
+                        fast = false;
+        }
         bool done = false;
         if (fast) {
             HostTiles ftiles;
