@@ -67,6 +67,26 @@ def test_rdf_lattice_pairs_on_bin_edges(hip_ctx):
         assert np.array_equal(h, ref)
 
 
+def test_sheared_lattice_pairs_on_edges(hip_ctx):
+    # integer grid 2*Z^3 inside a strongly sheared cell with integer cell vectors: the Cartesian
+    # components are sums of large cancelling terms (the kappa factor of the f32 guard), and the
+    # distances 2, 4, 6, 2*sqrt(2) ... sit exactly on bin edges / on the cutoff
+    cell = np.array([[16.0, 0, 0], [8.0, 16.0, 0], [8.0, 8.0, 16.0]])
+    g = np.arange(8) * 2.0
+    pos = np.array([[x, y, z] for x in g for y in g for z in g], dtype=float)
+    numbers = np.where(np.arange(len(pos)) % 3 == 0, 30, 7)
+    packed = PackedTrajectory(np.stack([pos, pos + 0.375, pos - 7.0]), cell, numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    for rmax, nb in [(6.0, 12), (6.5, 650), (6.9, 69)]:
+        h, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, 2, rmax, nb)
+        assert np.array_equal(h, ref)
+    for rc in [2.0, np.sqrt(8.0), np.nextafter(np.sqrt(8.0), 9.0), 4.0, np.nextafter(4.0, 9.0)]:
+        rcm = np.full((2, 2), rc)
+        sets = [(0, 0), (0, 1), (1, 0), (1, 1)]
+        assert np.array_equal(hip_ctx.cn_count(packed, rcm, sets), clib.cn_counts(packed.pos, packed.cell, sp, 2, rcm, sets))
+
+
 @pytest.mark.parametrize("kind", ["elongated", "elongated_tri", "npt"])
 def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
     packed, _, _ = _traj(kind)
