@@ -99,8 +99,40 @@ def cpu_baseline(packed, rmax, nbins, window, rdf_frames):
     del pos_h
     t_msd = t_msd_sub * (N / float(sub.sum()))
     fps = F / (t_rdf * F + t_msd)
+    # the same RDF sample frame-parallel on every host core this process may use (the reference's
+    # parallel=True mode is frame-parallel too, amof/bad.py:151); ctypes releases the GIL
+    from concurrent.futures import ThreadPoolExecutor
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                     # container CPU quota (cgroup v2), e.g. "1600000 100000"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, 16)                   # one GPU's share of the host
+    per = 2
+    pick2 = np.linspace(0, F - 1, per * cores).astype(int)
+    pos_p = packed.pos[torch.as_tensor(pick2, device=packed.pos.device)].cpu().numpy()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda k: clib.rdf_hist(pos_p[per * k:per * (k + 1)], packed.cell, sp, len(kinds), rmax, nbins,
+                                            cell_list=True), range(cores)))
+    t_rdf_par = (time.perf_counter() - t0) / (per * cores)
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
         "value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
+        "all_cores": {"value": F / (t_rdf_par * F + t_msd), "unit": "frames/s", "cores": cores,
+                      "sample": "RDF: %d frames on %d threads, %.4f s/frame aggregate; MSD as above (single thread)"
+                                % (per * cores, cores, t_rdf_par)},
+        "cpu_model": cpu_model,
         "sample": "RDF: C oracle (cell list) on %d of %d frames, %.3f s/frame; MSD: numpy restatement of the "
                   "reference loops on all %d frames for 1/8 of the atoms (%.1f s), scaled x%.1f to all atoms"
                   % (rdf_frames, F, t_rdf, F, t_msd_sub, N / float(sub.sum())),
@@ -245,6 +277,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(packed, rmax, nbins, window, args.cpu_rdf_frames)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
             out["speedup_vs_cpu_1core"] = fps / out["cpu_baseline"]["value"]
+            # supplementary (never `value`): the same step from a host-resident packed trajectory, i.e. including
+            # the 24*N*F-byte PCIe staging of both passes
+            from amof_amd.frames import PackedTrajectory
+            host = PackedTrajectory(packed.pos.cpu().numpy(), packed.cell, packed.numbers)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Rdf.from_trajectory(host, device=local_rank, distributed=False)
+            WindowMsd.from_trajectory(host, delta_time=100, timestep=1, device=local_rank, distributed=False)
+            torch.cuda.synchronize()
+            out["host_resident_frames_per_s"] = F / (time.perf_counter() - t0)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
