@@ -223,7 +223,10 @@ class PackedTrajectory(object):
         return PackedTrajectory(pos, self.cell, self.numbers, self.masses, self.pbc)
 
     def formula_count(self):
-        return _Formula([_data.chemical_symbols[z] for z in self.numbers])._count
+        """``{symbol: count}`` in order of first appearance (``atoms.symbols.formula._count``)."""
+        zs, first, counts = np.unique(self.numbers, return_index=True, return_counts=True)
+        order = np.argsort(first)
+        return {_data.chemical_symbols[int(zs[k])]: int(counts[k]) for k in order}
 
     def frame(self, k):
         """Materialise frame ``k`` as a :class:`Frame` (host copy)."""
