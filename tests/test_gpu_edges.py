@@ -105,6 +105,26 @@ def test_non_periodic_axis(hip_ctx):
                           clib.cn_counts(packed.pos, packed.cell, sp, 2, rcm, sets, pbc=packed.pbc))
 
 
+def test_non_finite_coordinates_never_count(hip_ctx):
+    # a NaN or infinite coordinate makes every distance of that atom NaN in the canonical
+    # arithmetic: it is never a neighbour and never binned; everything else is unaffected
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (1, 1, 2)), 3, 0.05, 77)
+    pos = packed.pos.copy()
+    pos[0, 5, 1] = np.nan
+    pos[1, 300, 0] = np.inf
+    pos[2, 17] = [-np.inf, np.nan, 1.0]
+    bad = PackedTrajectory(pos, packed.cell, packed.numbers)
+    kinds, sp = H.species_of(bad.numbers)
+    S = len(kinds)
+    h, _, _ = hip_ctx.rdf_accumulate(bad, 6.0, 600)
+    assert np.array_equal(h, clib.rdf_hist(bad.pos, bad.cell, sp, S, 6.0, 600)[0])
+    clean, _, _ = hip_ctx.rdf_accumulate(packed, 6.0, 600)
+    assert 0 < int(clean.sum()) - int(h.sum()) < 3 * 2 * 400          # only the three atoms' pairs are gone
+    rcm = np.full((S, S), 2.0)
+    sets = [(a, b) for a in range(S) for b in range(S)]
+    assert np.array_equal(hip_ctx.cn_count(bad, rcm, sets), clib.cn_counts(bad.pos, bad.cell, sp, S, rcm, sets))
+
+
 def test_small_skewed_cell_counts_images(hip_ctx):
     cell = np.array([[4.0, 0, 0], [2.5, 3.5, 0], [1.0, 1.5, 3.0]])
     rng = np.random.default_rng(12)
