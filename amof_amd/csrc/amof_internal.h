@@ -104,10 +104,12 @@ int build_images(amof_ctx *ctx, const amof_traj *t, const HostGeom &g, double R,
 // (kappa = 1 for a diagonal cell, whose kernels multiply instead of summing: 4.5u + root).
 // v_sqrt_f32 on gfx950: <= 1 ulp from correctly rounded, relative error <= 1.56 u, measured
 // exhaustively (profiles/tools/sqrt_ulp.hip).  Both bounds carry a further 10 % margin.
-inline double fast_guard_rel(const HostGeom &g, int64_t n_cells)
+// sq_scaled: the diagonal-cell kernel squares the converted differences first and multiplies by the
+// squared scales (cvt 1u, square 3u, scale^2 1u, product/fma 5-6-7u on t): 3.5u + root.
+inline double fast_guard_rel(const HostGeom &g, int64_t n_cells, bool sq_scaled = false)
 {
     const double u = 1.0 / 16777216.0;
-    if (g.all_ortho) return 1.1 * (4.5 + 1.56) * u;
+    if (g.all_ortho) return 1.1 * ((sq_scaled ? 3.5 : 4.5) + 1.56) * u;
     double kappa = 1.0;
     for (int64_t k = 0; k < n_cells; k++) {
         const double *c = g.rec.data() + (size_t)k * GEOM_STRIDE, *inv = c + 9;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(RDF_TILE) void rdf_tile_kernel_global(RdfArgs a)
 // provably the canonical one:  |q~ - q| <= g_f  with
 //     g_f = nbins * eps_f + g_m,   g_m = quant / dr + nbins * 1e-12,   quant = 2^-31 * (|c0|+|c1|+|c2|)
 // eps_f = fast_guard_rel() bounds the relative error of the f32 chain (cvt, scale, squares/fma and
-// v_sqrt_f32; 4.0e-7 for diagonal cells, (5 kappa + 3.06) * 2^-24 * 1.1 for sheared ones); the
+// v_sqrt_f32; 3.3e-7 for diagonal cells, (5 kappa + 3.06) * 2^-24 * 1.1 for sheared ones); the
 // fixed-point grid moves a distance by < quant.  A lane whose q~ lies within g_f of an integer (or
 // of nbins) is refined: first with the f64 distance of the same integer differences (decides unless
 // within g_m of the edge), then with the canonical f64 arithmetic and exact sqrt/divide.  At
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(RDF_TILE) void rdf_tile_kernel_global(RdfArgs a)
 // height, so both images are out of range there.
 // per-cell record of the fast path (one per frame when the cell changes)
 struct FrameScale {
-    float sc[9];        // ORTHO: sc[0..2] = L_k * 2^-32 / dr ; else cell[k][c] * 2^-32 / dr (rows in stored order)
+    float sc[9];        // ORTHO: sc[0..2] = L_k * 2^-32 / dr, sc[3..5] their squares ; else cell[k][c] * 2^-32 / dr (rows in stored order)
     uint32_t cull_gap;  // slab-gap threshold of this cell (0 = culling off)
     double sc64[9];     // the same factors in f64 (level-2 refinement)
 };
@@ -225,8 +225,9 @@ __device__ __forceinline__ float fast_q(const float *sc, int ix, int iy, int iz)
     const float fx = (float)ix, fy = (float)iy, fz = (float)iz;
     float t;
     if (ORTHO) {
-        const float dx = fx * sc[0], dy = fy * sc[1], dz = fz * sc[2];
-        t = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        // squares first, then the squared scales sc[3..5]: 7u on t instead of 9u (see fast_guard_rel)
+        const float x2 = fx * fx, y2 = fy * fy, z2 = fz * fz;
+        t = fmaf(z2, sc[5], fmaf(y2, sc[4], x2 * sc[3]));
     } else {
         const float dx = fmaf(fz, sc[6], fmaf(fy, sc[3], fx * sc[0]));
         const float dy = fmaf(fz, sc[7], fmaf(fy, sc[4], fx * sc[1]));
@@ -738,7 +739,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         const double quant = csum * (1.0 / 2147483648.0);
         const double guard_m = quant / dr + (double)nbins * 1e-12;
         // f32 candidate: relative error bound of the chain, see fast_guard_rel (amof_internal.h)
-        const double guard_f = (double)nbins * fast_guard_rel(geom, nc) + guard_m;
+        const double guard_f = (double)nbins * fast_guard_rel(geom, nc, true) + guard_m;
         const char *force = getenv("AMOF_RDF_KERNEL");
         bool fast = !extra && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS - 5120 &&
                     guard_f < 0.25 && !(force && strcmp(force, "v1") == 0);
@@ -791,6 +792,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                         for (int x = 0; x < 3; x++) r.sc64[3 * q + x] = c[3 * ord[q] + x] * two32 / dr;
                 }
                 for (int q = 0; q < 9; q++) r.sc[q] = (float)r.sc64[q];
+                if (ortho)
+                    for (int q = 0; q < 3; q++) r.sc[3 + q] = (float)(r.sc64[q] * r.sc64[q]);
                 // a block is skipped when the slab gap alone exceeds rmax (1e-6 relative and 4 grid units of slack)
                 const double hax = geom.rec[(size_t)k * GEOM_STRIDE + 18 + axis];
                 r.cull_gap = cull ? (uint32_t)std::min(4294967295.0, ceil(rmax / hax * 4294967296.0 * (1.0 + 1e-6)) + 4.0) : 0u;
@@ -836,6 +839,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                             for (int x = 0; x < 3; x++) r.sc64[3 * q + x] = c[3 * ord2[q] + x] * two32 / dr;
                     }
                     for (int q = 0; q < 9; q++) r.sc[q] = (float)r.sc64[q];
+                    if (ortho)
+                        for (int q = 0; q < 3; q++) r.sc[3 + q] = (float)(r.sc64[q] * r.sc64[q]);
                     r.cull_gap = 0u;
                 }
                 AMOF_TRY(upload(ctx, SLOT_AUX5, fsv.data(), fsv.size() * sizeof(FrameScale), &d_fs));
@@ -917,7 +922,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.nf = (int32_t)nf;
                 int64_t want_chunks = (8 * 2048 + (int64_t)fpairs.size() - 1) / (int64_t)fpairs.size();
                 int64_t fpc = std::max<int64_t>(1, nf / std::max<int64_t>(1, want_chunks));
-                fpc = std::min<int64_t>(fpc, 16);
+                const char *fpc_env = getenv("AMOF_RDF_FPC");            // experiments: frames per chunk cap
+                fpc = std::min<int64_t>(fpc, fpc_env ? std::max(1, atoi(fpc_env)) : 16);
                 if (nf >= 64) fpc = std::min<int64_t>(fpc, nf / 32);   // >= 32 chunks: every XCD gets >= 4
                 int64_t chunks = (nf + fpc - 1) / fpc;
                 fa.xcd_map = chunks >= 32 ? 1 : 0;
