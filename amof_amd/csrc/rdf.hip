@@ -297,11 +297,7 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
     q = fast_q<ORTHO>(sc, ix, iy, iz);
     const bool in = live && (q < nb_hi);
     const bool safe = fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard;
-#ifdef AMOF_EXP_NOATOMIC
-    if (in && safe) hist[(threadIdx.x & 63) + 64] = (unsigned)q;
-#else
     if (in && safe) atomicAdd(&hist[(int)q], 1u);
-#endif
     return in && !safe;
 }
 
@@ -780,7 +776,6 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             std::vector<FrameScale> fsv((size_t)nc);
             const int ord[3] = {(axis + 1) % 3, (axis + 2) % 3, axis};
             const double two32 = 1.0 / 4294967296.0;
-            const char *dbg = getenv("AMOF_RDF_CULLGAP_DEBUG");   // timing experiments only (breaks results)
             for (int64_t k = 0; k < nc; k++) {
                 const double *c = t->cell + 9 * k;
                 FrameScale &r = fsv[(size_t)k];
@@ -797,7 +792,6 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 // a block is skipped when the slab gap alone exceeds rmax (1e-6 relative and 4 grid units of slack)
                 const double hax = geom.rec[(size_t)k * GEOM_STRIDE + 18 + axis];
                 r.cull_gap = cull ? (uint32_t)std::min(4294967295.0, ceil(rmax / hax * 4294967296.0 * (1.0 + 1e-6)) + 4.0) : 0u;
-                if (dbg && cull) r.cull_gap = (uint32_t)strtoul(dbg, nullptr, 10);
             }
             void *d_fs;
             AMOF_TRY(upload(ctx, SLOT_AUX5, fsv.data(), fsv.size() * sizeof(FrameScale), &d_fs));
