@@ -50,6 +50,8 @@ struct amof_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // host -> device staging that overlaps the kernels of the previous batch
+    hipEvent_t ev_copy = nullptr;
     hipEvent_t ev_all0 = nullptr, ev_all1 = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
     bool ev_valid = false;
     int64_t dom_launches = 0;
@@ -145,6 +147,20 @@ void build_tiles(const amof_traj *t, int tile, HostTiles &out);
 
 // staging of the position array (host -> device) or pass-through
 int stage_positions(amof_ctx *ctx, const amof_traj *t, const double **pos_dev);
+// Pipelined variant for kernels that walk the trajectory in frame batches: the device array is
+// allocated at once, frames are copied on the context's copy stream only when a batch needs them
+// (stager_need), and the compute stream waits on an event -- so the PCIe copy of batch k+1 runs
+// while batch k is being computed.  Device-resident and short trajectories degenerate to
+// stage_positions.
+struct Stager {
+    amof_ctx *ctx = nullptr;
+    const amof_traj *t = nullptr;
+    double *dev = nullptr;
+    int64_t upto = 0;       // frames [0, upto) are on the device (or queued ahead of the compute stream)
+    bool lazy = false;
+};
+int stager_begin(amof_ctx *ctx, const amof_traj *t, bool allow_lazy, Stager &st);
+int stager_need(Stager &st, int64_t f1);
 int upload(amof_ctx *ctx, Slot s, const void *src, size_t bytes, void **out);
 
 // fixed-point atom record of the fast paths: fractional coordinates * 2^32 in the stored

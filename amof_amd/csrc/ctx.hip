@@ -66,6 +66,42 @@ int stage_positions(amof_ctx *ctx, const amof_traj *t, const double **pos_dev)
     return AMOF_OK;
 }
 
+int stager_begin(amof_ctx *ctx, const amof_traj *t, bool allow_lazy, Stager &st)
+{
+    st.ctx = ctx;
+    st.t = t;
+    st.lazy = false;
+    st.upto = t->n_frames;
+    if (t->pos_on_device || !allow_lazy || t->n_frames < 1024) {
+        const double *p = nullptr;
+        AMOF_TRY(stage_positions(ctx, t, &p));
+        st.dev = const_cast<double *>(p);
+        return AMOF_OK;
+    }
+    // a copy queued by a call that ended early must not race a reallocation below
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    void *p = nullptr;
+    AMOF_TRY(ensure(ctx, SLOT_POS, (size_t)t->n_frames * (size_t)t->n_atoms * 3 * sizeof(double), &p));
+    st.dev = (double *)p;
+    st.lazy = true;
+    st.upto = 0;
+    return AMOF_OK;
+}
+
+int stager_need(Stager &st, int64_t f1)
+{
+    if (!st.lazy || f1 <= st.upto) return AMOF_OK;
+    amof_ctx *ctx = st.ctx;
+    const size_t per = (size_t)st.t->n_atoms * 3;
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(st.dev + (size_t)st.upto * per, st.t->pos + (size_t)st.upto * per,
+                                     (size_t)(f1 - st.upto) * per * sizeof(double), hipMemcpyHostToDevice,
+                                     ctx->copy_stream));
+    AMOF_HIP_TRY(ctx, hipEventRecord(ctx->ev_copy, ctx->copy_stream));
+    AMOF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0));
+    st.upto = f1;
+    return AMOF_OK;
+}
+
 void timing_begin(amof_ctx *ctx)
 {
     ctx->ev_valid = false;
@@ -268,6 +304,11 @@ int amof_ctx_create(int device, amof_ctx **out)
         return AMOF_EHIP;
     }
     ctx->stream = ctx->own_stream;
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming) != hipSuccess) {
+        amof_ctx_destroy(ctx);
+        return AMOF_EHIP;
+    }
     if (hipEventCreate(&ctx->ev_all0) != hipSuccess || hipEventCreate(&ctx->ev_all1) != hipSuccess ||
         hipEventCreate(&ctx->ev_dom0) != hipSuccess || hipEventCreate(&ctx->ev_dom1) != hipSuccess) {
         amof_ctx_destroy(ctx);
@@ -281,6 +322,7 @@ void amof_ctx_destroy(amof_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (int s = 0; s < SLOT_COUNT; s++)
         if (ctx->buf[s].p) (void)hipFree(ctx->buf[s].p);
@@ -288,6 +330,8 @@ void amof_ctx_destroy(amof_ctx *ctx)
     if (ctx->ev_all1) (void)hipEventDestroy(ctx->ev_all1);
     if (ctx->ev_dom0) (void)hipEventDestroy(ctx->ev_dom0);
     if (ctx->ev_dom1) (void)hipEventDestroy(ctx->ev_dom1);
+    if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

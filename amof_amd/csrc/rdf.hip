@@ -671,8 +671,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
 
     AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     timing_begin(ctx);
-    const double *pos_dev = nullptr;
-    AMOF_TRY(stage_positions(ctx, t, &pos_dev));
+    Stager stage;
+    AMOF_TRY(stager_begin(ctx, t, true, stage));
+    const double *pos_dev = stage.dev;
     void *d_geom, *d_img, *d_nimg, *d_perm, *d_tiles, *d_pairs, *d_U, *d_self, *d_nsp;
     AMOF_TRY(upload(ctx, SLOT_GEOM, geom.rec.data(), geom.rec.size() * sizeof(double), &d_geom));
     AMOF_TRY(upload(ctx, SLOT_IMG, img.data(), img.size() * sizeof(double), &d_img));
@@ -818,6 +819,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 use_range = f2 < 0.6 * f1 || getenv("AMOF_RDF_FORCE_RANGE") != nullptr;   // (forced: tests)
             }
             if (use_range) {
+                AMOF_TRY(stager_need(stage, t->n_frames));
                 const int gy = (int)ceil(rmax * (1.0 + 1e-5) / hmin[axis_y] * 256.0) + 1;
                 // scale records: stored component order is (remaining axis, axis_y, axis)
                 const int ax_x = 3 - axis - axis_y;
@@ -900,6 +902,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             if (!done && !use_range) {
             int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
             FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), t->n_frames);
+            // host-resident input: eight or so batches (each still >= 32 chunks of 16 frames), the copy of
+            // batch k+1 overlaps the kernels of batch k
+            if (stage.lazy) FB = std::min<int64_t>(FB, std::max<int64_t>(512, (t->n_frames + 7) / 8));
             void *d_Q, *d_flag;
             AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB * t->n_atoms * sizeof(QAtom), &d_Q));
             AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag));
@@ -909,6 +914,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             int64_t launches = 0;
             for (int64_t fb = 0; fb < t->n_frames; fb += FB) {
                 const int64_t nf = std::min<int64_t>(FB, t->n_frames - fb);
+                AMOF_TRY(stager_need(stage, fb + nf));
                 AMOF_TRY(launch_quantize(ctx, pos_dev, (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm,
                                          (const int64_t *)d_spfirst, S, t->n_atoms, (int)fb, (int)nf, axis, (QAtom *)d_Q,
                                          nullptr, (int32_t *)d_flag));
@@ -954,6 +960,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             }   // tile kernel (not the range kernel)
         }
         if (!done) {
+        AMOF_TRY(stager_need(stage, t->n_frames));
         unsigned chunks;
         pick_chunks(t->n_frames, a.frames_per_chunk, chunks);
         dim3 grid((unsigned)pairs.size(), chunks);

@@ -216,3 +216,19 @@ def test_rdf_range_kernel_two_level_cell_list(hip_ctx, tri):
             got, _, _ = hip_ctx.rdf_accumulate(small, rmax, nb)
         ref, _ = clib.rdf_hist(small.pos, small.cell, H.species_of(small.numbers)[1], 4, rmax, nb)
         assert np.array_equal(got, ref), rmax
+
+
+def test_rdf_pipelined_host_staging(hip_ctx):
+    # >= 1024 host-resident frames: the trajectory is copied batch by batch on a second stream
+    # while the previous batch is computed; same integers as the device-resident call and the oracle
+    import torch
+    packed = H.random_walk(H.zif4_frame(), 1100, 0.03, 91)
+    kinds, sp = H.species_of(packed.numbers)
+    host, _, vol_h = hip_ctx.rdf_accumulate(packed, 7.0, 700)
+    dev = PackedTrajectory(torch.as_tensor(packed.pos).cuda(), packed.cell, packed.numbers)
+    on_dev, _, vol_d = hip_ctx.rdf_accumulate(dev, 7.0, 700)
+    ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), 7.0, 700, cell_list=True)
+    assert np.array_equal(host, ref) and np.array_equal(on_dev, ref) and vol_h == vol_d
+    with _env(AMOF_RDF_KERNEL="v1"):                     # exact kernels: everything staged up front
+        exact, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, 700)
+    assert np.array_equal(exact, ref)
