@@ -545,6 +545,7 @@ struct NbrSetup {
     int max_img = 0;
     HostTiles tiles;
     NbrArgs a;
+    Stager stage;
 };
 
 static int nbr_setup(amof_ctx *ctx, const amof_traj *t, const double *cutoff, int tile, NbrSetup &s)
@@ -563,8 +564,8 @@ static int nbr_setup(amof_ctx *ctx, const amof_traj *t, const double *cutoff, in
     build_tiles(t, tile, s.tiles);
     AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     timing_begin(ctx);
-    const double *pos_dev = nullptr;
-    AMOF_TRY(stage_positions(ctx, t, &pos_dev));
+    AMOF_TRY(stager_begin(ctx, t, true, s.stage));
+    const double *pos_dev = s.stage.dev;
     void *d_geom, *d_img, *d_nimg, *d_perm, *d_tiles, *d_ft, *d_nt, *d_cut;
     AMOF_TRY(upload(ctx, SLOT_GEOM, s.geom.rec.data(), s.geom.rec.size() * sizeof(double), &d_geom));
     AMOF_TRY(upload(ctx, SLOT_IMG, s.img.data(), s.img.size() * sizeof(double), &d_img));
@@ -666,6 +667,8 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     for (int x = 0; x < S; x++) nf.sp_first[x + 1] = nf.sp_first[x] + st.tiles.nsp[x];
     int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
     nf.FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), std::max<int64_t>(1, t->n_frames));
+    // host-resident input: batches small enough that the copy of the next one overlaps this one's kernels
+    if (st.stage.lazy) nf.FB = std::min<int64_t>(nf.FB, std::max<int64_t>(512, (t->n_frames + 7) / 8));
     AMOF_TRY(upload(ctx, SLOT_AUX4, cells.data(), cells.size() * sizeof(NbrCell), &nf.d_cells));
     AMOF_TRY(upload(ctx, SLOT_AUX5, nf.sp_first.data(), nf.sp_first.size() * sizeof(int64_t), &nf.d_spfirst));
     AMOF_TRY(ensure(ctx, SLOT_HISTU, (size_t)nf.FB * t->n_atoms * sizeof(QAtom), &nf.d_Q));
@@ -746,6 +749,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         int64_t launches = 0;
         for (int64_t fb = 0; fb < t->n_frames && !fwork.empty(); fb += nf.FB) {
             const int64_t nfr = std::min<int64_t>(nf.FB, t->n_frames - fb);
+            AMOF_TRY(stager_need(st.stage, fb + nfr));
             AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, S,
                                      t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
                                      (int32_t *)nf.d_qflag));
@@ -770,6 +774,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
             done = true;
         }
     }
+    AMOF_TRY(stager_need(st.stage, t->n_frames));   // (no-op unless the fast path was skipped)
     if (!done && !work.empty()) {
         unsigned chunks;
         pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
@@ -846,6 +851,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         int64_t launches = 0;
         for (int64_t fb = 0; fb < t->n_frames && !fwork.empty(); fb += nf.FB) {
             const int64_t nfr = std::min<int64_t>(nf.FB, t->n_frames - fb);
+            AMOF_TRY(stager_need(st.stage, fb + nfr));
             AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, S,
                                      t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
                                      (int32_t *)nf.d_qflag));
@@ -882,6 +888,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 2 * sizeof(int32_t), ctx->stream));
         }
     }
+    AMOF_TRY(stager_need(st.stage, t->n_frames));   // (no-op unless the fast path was skipped)
     if (!done && !work.empty() && t->n_frames > 0) {
         unsigned chunks;
         pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);

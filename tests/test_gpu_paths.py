@@ -232,3 +232,13 @@ def test_rdf_pipelined_host_staging(hip_ctx):
     with _env(AMOF_RDF_KERNEL="v1"):                     # exact kernels: everything staged up front
         exact, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, 700)
     assert np.array_equal(exact, ref)
+    # CN / BAD share the pipelined staging
+    S = len(kinds)
+    zn, n = kinds.index(30), kinds.index(7)
+    rcm = np.zeros((S, S)); rcm[zn, n] = rcm[n, zn] = 2.5
+    edges = np.arange(int(180 // 0.5) + 2) * 0.5
+    assert np.array_equal(hip_ctx.cn_count(packed, rcm, [(zn, n), (n, zn)]),
+                          clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, [(zn, n), (n, zn)]))
+    hb, ab = hip_ctx.bad_hist(packed, rcm, [(zn, n), (n, zn)], edges)
+    hr, ar = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, [(zn, n), (n, zn)], edges)
+    assert np.array_equal(hb, hr) and np.array_equal(ab, ar) and ar.sum() > 0
