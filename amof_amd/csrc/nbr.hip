@@ -619,7 +619,7 @@ struct NbrFast {
     bool ok = false;
     int axis = 0;
     bool ortho = false;
-    int64_t FB = 0;              // frames per batch
+    int64_t FB = 0, FB0 = 0;     // frames per batch (largest, first)
     void *d_Q = nullptr, *d_slab = nullptr, *d_cells = nullptr, *d_spfirst = nullptr, *d_qflag = nullptr;
     std::vector<int64_t> sp_first;
     NbrFastArgs fa;
@@ -667,8 +667,8 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     for (int x = 0; x < S; x++) nf.sp_first[x + 1] = nf.sp_first[x] + st.tiles.nsp[x];
     int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
     nf.FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), std::max<int64_t>(1, t->n_frames));
-    // host-resident input: batches small enough that the copy of the next one overlaps this one's kernels
-    if (st.stage.lazy) nf.FB = std::min<int64_t>(nf.FB, std::max<int64_t>(512, (t->n_frames + 7) / 8));
+    // host-resident input: batches of 512, 1024, 2048 ... frames, the copy of the next one overlaps this one's kernels
+    nf.FB0 = st.stage.lazy ? std::min<int64_t>(nf.FB, 512) : nf.FB;
     AMOF_TRY(upload(ctx, SLOT_AUX4, cells.data(), cells.size() * sizeof(NbrCell), &nf.d_cells));
     AMOF_TRY(upload(ctx, SLOT_AUX5, nf.sp_first.data(), nf.sp_first.size() * sizeof(int64_t), &nf.d_spfirst));
     AMOF_TRY(ensure(ctx, SLOT_HISTU, (size_t)nf.FB * t->n_atoms * sizeof(QAtom), &nf.d_Q));
@@ -747,8 +747,8 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         nf.fa.a = a;
         nf.fa.a.work = (const int4 *)d_fwork;
         int64_t launches = 0;
-        for (int64_t fb = 0; fb < t->n_frames && !fwork.empty(); fb += nf.FB) {
-            const int64_t nfr = std::min<int64_t>(nf.FB, t->n_frames - fb);
+        for (int64_t fb = 0, cur = nf.FB0; fb < t->n_frames && !fwork.empty(); fb += cur, cur = std::min<int64_t>(2 * cur, nf.FB)) {
+            const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
             AMOF_TRY(stager_need(st.stage, fb + nfr));
             AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, S,
                                      t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
@@ -849,8 +849,8 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         size_t lds = NBRF_TILE * sizeof(uint4) + (size_t)AMOF_MAX_NEIGHBOURS * NBRF_TILE * sizeof(uint32_t) +
                      (size_t)nb * sizeof(unsigned);
         int64_t launches = 0;
-        for (int64_t fb = 0; fb < t->n_frames && !fwork.empty(); fb += nf.FB) {
-            const int64_t nfr = std::min<int64_t>(nf.FB, t->n_frames - fb);
+        for (int64_t fb = 0, cur = nf.FB0; fb < t->n_frames && !fwork.empty(); fb += cur, cur = std::min<int64_t>(2 * cur, nf.FB)) {
+            const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
             AMOF_TRY(stager_need(st.stage, fb + nfr));
             AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, S,
                                      t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,

@@ -902,9 +902,10 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             if (!done && !use_range) {
             int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
             FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), t->n_frames);
-            // host-resident input: eight or so batches (each still >= 32 chunks of 16 frames), the copy of
-            // batch k+1 overlaps the kernels of batch k
-            if (stage.lazy) FB = std::min<int64_t>(FB, std::max<int64_t>(512, (t->n_frames + 7) / 8));
+            // host-resident input: batches of 512, 1024, 2048 ... frames (each >= 32 chunks of 16 frames); the copy
+            // of batch k+1 overlaps the kernels of batch k, and only the first, small copy is exposed
+            int64_t cur = stage.lazy ? std::min<int64_t>(FB, 512) : FB;
+            if (const char *be = getenv("AMOF_RDF_BATCH")) cur = std::min<int64_t>(FB, std::max(1, atoi(be)));   // experiments
             void *d_Q, *d_flag;
             AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB * t->n_atoms * sizeof(QAtom), &d_Q));
             AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag));
@@ -912,8 +913,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             fa.Q = (const QAtom *)d_Q;
             size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
             int64_t launches = 0;
-            for (int64_t fb = 0; fb < t->n_frames; fb += FB) {
-                const int64_t nf = std::min<int64_t>(FB, t->n_frames - fb);
+            for (int64_t fb = 0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
+                const int64_t nf = std::min<int64_t>(cur, t->n_frames - fb);
                 AMOF_TRY(stager_need(stage, fb + nf));
                 AMOF_TRY(launch_quantize(ctx, pos_dev, (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm,
                                          (const int64_t *)d_spfirst, S, t->n_atoms, (int)fb, (int)nf, axis, (QAtom *)d_Q,
