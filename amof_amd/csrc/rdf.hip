@@ -756,6 +756,14 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             std::vector<int2> fpairs;
             for (int i = 0; i < (int)ftiles.tiles.size(); i++)
                 for (int j = i; j < (int)ftiles.tiles.size(); j++) fpairs.push_back(make_int2(i, j));
+            // heavy tile pairs first: the drain tail of the launch is filled with the light ones
+            {
+                auto cost = [&](const int2 &pr) {
+                    const double c = (double)ftiles.tiles[pr.x].count * (double)ftiles.tiles[pr.y].count;
+                    return pr.x == pr.y ? 0.5 * c : c;
+                };
+                std::stable_sort(fpairs.begin(), fpairs.end(), [&](const int2 &u, const int2 &v) { return cost(u) > cost(v); });
+            }
             void *d_ftiles, *d_fpairs;
             AMOF_TRY(upload(ctx, SLOT_AUX2, ftiles.tiles.data(), ftiles.tiles.size() * sizeof(Tile), &d_ftiles));
             AMOF_TRY(upload(ctx, SLOT_AUX3, fpairs.data(), fpairs.size() * sizeof(int2), &d_fpairs));
