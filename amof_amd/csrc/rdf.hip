@@ -213,6 +213,7 @@ struct RdfFastArgs {
     float nbins_f;
     double guard64;          // g_m (bins): f64-from-fixed-point candidate
     int32_t xcd_map;         // 1: chunk -> XCD affinity mapping of the grid
+    int32_t n_chunks;        // tile kernel: frames [c nf / n_chunks, (c+1) nf / n_chunks) belong to chunk c
 };
 
 constexpr int FAST_THREADS = 256;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         chunk = (kk / gridDim.x) * 8u + xcd;
         bx = kk % gridDim.x;
     }
-    if ((int)(chunk * a.frames_per_chunk) >= fa.nf) return;
+    if ((int)chunk >= fa.n_chunks) return;
     const int2 pr = a.pairs[bx];
     const Tile ti = a.tiles[pr.x];
     const Tile tj = a.tiles[pr.y];
@@ -378,8 +379,11 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const int nbins = a.nbins;
     for (int k = tid; k < nbins; k += FAST_THREADS) hist[k] = 0u;
 
-    const int f0 = chunk * a.frames_per_chunk;
-    const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
+    // equal shares (+-1 frame): with the XCD mapping n_chunks is a multiple of 8, so every XCD gets the same work
+    // (with the XCD mapping, XCD x owns the contiguous frame range [x nf/8, (x+1) nf/8), cut into n_chunks/8 shares)
+    const unsigned cs = fa.xcd_map ? (chunk & 7u) * ((unsigned)fa.n_chunks >> 3) + (chunk >> 3) : chunk;
+    const int f0 = (int)((long long)cs * fa.nf / fa.n_chunks);
+    const int f1 = (int)((long long)(cs + 1) * fa.nf / fa.n_chunks);
     // The four 128-atom centre sub-tiles of tile I are handled one after the other by the same
     // workgroup: the LDS histogram is flushed once for all of them (4x fewer global atomics).
     for (int sub = 0; sub * FAST_SUB < ti.count; sub++) {
@@ -938,6 +942,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.xcd_map = chunks >= 32 ? 1 : 0;
                 if (fa.xcd_map) chunks = (chunks + 7) / 8 * 8;         // the XCD mapping deals chunks in groups of 8
                 fa.a.frames_per_chunk = (int32_t)fpc;
+                fa.n_chunks = (int32_t)chunks;
                 dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
                 if (launches == 0) timing_dom_begin(ctx);
                 auto launch = [&](auto kern) -> hipError_t {
