@@ -1,6 +1,8 @@
 // Fixed-point folding + slab counting sort shared by the RDF and neighbour fast paths.
 #include <math.h>
 
+#include <algorithm>
+
 #include "amof_internal.h"
 
 namespace amof {
@@ -36,8 +38,12 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
                                                        const int32_t *__restrict__ perm,
                                                        const int64_t *__restrict__ sp_first, int S, int64_t N,
                                                        int f0, int axis, QAtom *__restrict__ Q,
-                                                       uint32_t *__restrict__ slab_start, int32_t *flag)
+                                                       uint32_t *__restrict__ slab_start, int32_t *flag, int cache_cap)
 {
+    // species segments of up to cache_cap atoms keep their quantised records in LDS between the
+    // counting pass and the placement pass, so the positions are read from HBM once
+    extern __shared__ __align__(16) unsigned char qcache_raw[];
+    QAtom *cache = reinterpret_cast<QAtom *>(qcache_raw);
     __shared__ unsigned cnt[QSLABS];
     __shared__ unsigned wsum[4];
     const int sp = blockIdx.x, fl = blockIdx.y, tid = threadIdx.x;
@@ -45,10 +51,12 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
     const int ax0 = (axis + 1) % 3, ax1 = (axis + 2) % 3;   // stored order: (ax0, ax1, axis)
     const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
     const int64_t k0 = sp_first[sp], k1 = sp_first[sp + 1];
+    const bool cached = k1 - k0 <= (int64_t)cache_cap;
     cnt[tid] = 0u;
     __syncthreads();
     for (int64_t k = k0 + tid; k < k1; k += 256) {
         const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        if (cached) cache[k - k0] = q;
         atomicAdd(&cnt[q.uz >> 24], 1u);
     }
     __syncthreads();
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
     __syncthreads();
     QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
     for (int64_t k = k0 + tid; k < k1; k += 256) {
-        const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        const QAtom q = cached ? cache[k - k0] : quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
         const unsigned slot = atomicAdd(&cnt[q.uz >> 24], 1u);
         Qf[slot] = q;
     }
@@ -161,8 +169,13 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
     if (nf <= 0 || S <= 0) return AMOF_OK;
     if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
     dim3 qgrid((unsigned)S, (unsigned)nf);
-    hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(256), 0, ctx->stream, pos_dev, d_geom, n_cells, d_perm, d_spfirst,
-                       S, N, f0, axis, d_Q, d_slab_start, d_flag);
+    // LDS record cache: up to 4608 atoms per species segment (72 KiB: two workgroups per CU); longer segments
+    // (or species counts unknown here: the cap is only a capacity) take the two-read path
+    const int cache_cap = (int)std::min<int64_t>(N, 4608);
+    const size_t lds = (size_t)cache_cap * sizeof(QAtom);
+    AMOF_HIP_TRY(ctx, hipFuncSetAttribute((const void *)quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(256), lds, ctx->stream, pos_dev, d_geom, n_cells, d_perm, d_spfirst,
+                       S, N, f0, axis, d_Q, d_slab_start, d_flag, cache_cap);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     return AMOF_OK;
 }
