@@ -126,6 +126,7 @@ int validate_traj(amof_ctx *ctx, const amof_traj *t, bool need_masses)
     if (!t) return fail(ctx, AMOF_EINVAL, "traj is NULL");
     if (t->n_frames < 0 || t->n_atoms < 0) return fail(ctx, AMOF_EINVAL, "negative n_frames / n_atoms");
     if (t->n_atoms > 0x7fffff00LL) return fail(ctx, AMOF_EINVAL, "n_atoms too large");
+    if (t->n_frames > 0x7fffff00LL) return fail(ctx, AMOF_EINVAL, "n_frames too large");
     if (t->n_species <= 0 || t->n_species > 64) return fail(ctx, AMOF_EINVAL, "n_species must be 1..64");
     if (t->n_cells != 1 && t->n_cells != t->n_frames)
         return fail(ctx, AMOF_EINVAL, "n_cells must be 1 or n_frames");

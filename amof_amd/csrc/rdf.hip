@@ -366,10 +366,11 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     // fabric.  Pure bijection of the grid: correctness does not depend on the placement.
     unsigned chunk = blockIdx.y, bx = blockIdx.x;
     if (fa.xcd_map) {      // (off when there are too few chunks to give every XCD its share)
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned xcd = lin & 7u, kk = lin >> 3;
-        chunk = (kk / gridDim.x) * 8u + xcd;
-        bx = kk % gridDim.x;
+        const unsigned long long lin = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned xcd = (unsigned)(lin & 7ull);
+        const unsigned long long kk = lin >> 3;
+        chunk = (unsigned)(kk / gridDim.x) * 8u + xcd;
+        bx = (unsigned)(kk % gridDim.x);
     }
     if ((int)chunk >= fa.n_chunks) return;
     const int2 pr = a.pairs[bx];
