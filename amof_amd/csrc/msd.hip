@@ -137,7 +137,9 @@ __global__ __launch_bounds__(MSD_THREADS) void delta_transpose_kernel(const doub
 __device__ __forceinline__ void lds_scan(double *u, int F, double *wtot, double carry_init)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int chunk = (F + MSD_THREADS - 1) / MSD_THREADS;
+    // odd chunk length: lanes then start an odd number of doubles apart, so the strided LDS accesses of a
+    // wave spread over all banks (an even stride such as 20 doubles is an 8-way conflict)
+    const int chunk = ((F + MSD_THREADS - 1) / MSD_THREADS) | 1;
     const int k0 = min(tid * chunk, F), k1 = min(k0 + chunk, F);
     double s = 0.0;
     for (int k = k0; k < k1; k++) s += u[k];
@@ -236,6 +238,72 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__
     } else {
         __syncthreads();
         for (int w = tid; w < W; w += MSD_THREADS) partial[(size_t)blockIdx.x * W + w] = wsum[w];
+    }
+}
+
+// Windows in arithmetic progression m_w = w * d (what WindowMsd always passes: window =
+// arange(0, max, delta_m), amof/msd.py:180).  The pairs (k, k + w d) of one residue class
+// r = k mod d live on the "comb" u[r], u[r + d], u[r + 2d], ...: a thread loads COMB_B + WT - 1
+// consecutive comb entries once and forms every pair (j, j + w), j in its COMB_B bases, w < WT,
+// from registers -- about 7 terms per LDS read instead of one term per two reads, which is what
+// bounded msd_group_kernel (LDS bandwidth).  Windows w >= W of the template bucket WT are
+// computed and dropped.  Same column load and prefix sum as msd_group_kernel.
+constexpr int COMB_B = 10;
+
+template <int WT>
+__global__ __launch_bounds__(MSD_THREADS) void msd_comb_kernel(const double *__restrict__ DT, int64_t Fp, int F,
+                                                               const int32_t *__restrict__ perm,
+                                                               const MsdGroup *__restrict__ groups, int d, int W,
+                                                               double *__restrict__ partial)
+{
+    constexpr int NV = COMB_B + WT - 1;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *u = reinterpret_cast<double *>(lds_raw);  // [F]
+    __shared__ double red[MSD_THREADS / 64];
+    const int tid = threadIdx.x;
+    const MsdGroup gr = groups[blockIdx.x];
+    const int nq = (F + d - 1) / d;                    // longest comb
+    const int ntask = d * ((nq + COMB_B - 1) / COMB_B);
+    double acc[WT];
+#pragma unroll
+    for (int w = 0; w < WT; w++) acc[w] = 0.0;
+    for (int c = 0; c < 3 * gr.count; c++) {
+        const int64_t atom = perm[gr.start + c / 3];
+        const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
+        __syncthreads();
+        for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
+            const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
+            u[k] = v2.x;
+            if (k + 1 < F) u[k + 1] = v2.y;
+        }
+        __syncthreads();
+        lds_scan(u, F, red, 0.0);
+        for (int t = tid; t < ntask; t += MSD_THREADS) {
+            const int r = t % d, J0 = (t / d) * COMB_B;
+            const int lim = (F - r + d - 1) / d - J0;   // valid comb entries of this task (from J0 on)
+            const double m0 = t == 0 ? 0.0 : 1.0;        // origin k = 0 is skipped (amof/msd.py:200: k starts at m+1)
+            double v[NV];
+            const double *ub = u + r + (size_t)d * J0;
+#pragma unroll
+            for (int e = 0; e < NV; e++) v[e] = e < lim ? ub[(size_t)d * e] : 0.0;
+#pragma unroll
+            for (int e = 1; e < NV; e++) {
+                if (e < lim) {
+#pragma unroll
+                    for (int i = (e - WT + 1 > 0 ? e - WT + 1 : 0); i <= (e - 1 < COMB_B - 1 ? e - 1 : COMB_B - 1); i++) {
+                        const double dd = v[e] - v[i];
+                        acc[e - i] = fma(i == 0 ? dd * m0 : dd, dd, acc[e - i]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < WT; w++) {
+        if (w < W) {
+            const double tot = block_sum(acc[w], red);
+            if (tid == 0) partial[(size_t)blockIdx.x * W + w] = tot;
+        }
     }
 }
 
@@ -527,8 +595,32 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
                                (const int32_t *)d_win, (int)W, (double *)d_part);
             return hipGetLastError();
         };
+        // windows in arithmetic progression from 0 (the only thing WindowMsd produces): comb kernel
+        int comb_d = 0;
+        if (W >= 2 && W <= 32 && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
+            comb_d = windows[1];
+            for (int w = 0; w < W; w++)
+                if ((int64_t)windows[w] != (int64_t)w * comb_d) comb_d = 0;
+        }
+        auto launch_comb = [&](auto kern) -> hipError_t {
+            const size_t lds = (size_t)F * sizeof(double);
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
+                               (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
+                               comb_d, (int)W, (double *)d_part);
+            return hipGetLastError();
+        };
         hipError_t e;
-        if (W <= 8) e = launch(msd_group_kernel<8>);
+        if (comb_d > 0 && W <= 4) e = launch_comb(msd_comb_kernel<4>);
+        else if (comb_d > 0 && W <= 8) e = launch_comb(msd_comb_kernel<8>);
+        else if (comb_d > 0 && W <= 12) e = launch_comb(msd_comb_kernel<12>);
+        else if (comb_d > 0 && W <= 16) e = launch_comb(msd_comb_kernel<16>);
+        else if (comb_d > 0 && W <= 20) e = launch_comb(msd_comb_kernel<20>);
+        else if (comb_d > 0 && W <= 24) e = launch_comb(msd_comb_kernel<24>);
+        else if (comb_d > 0 && W <= 28) e = launch_comb(msd_comb_kernel<28>);
+        else if (comb_d > 0) e = launch_comb(msd_comb_kernel<32>);
+        else if (W <= 8) e = launch(msd_group_kernel<8>);
         else if (W <= 32) e = launch(msd_group_kernel<32>);
         else e = launch(msd_group_kernel<0>);
         AMOF_HIP_TRY(ctx, e);

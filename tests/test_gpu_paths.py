@@ -242,3 +242,26 @@ def test_rdf_pipelined_host_staging(hip_ctx):
     hb, ab = hip_ctx.bad_hist(packed, rcm, [(zn, n), (n, zn)], edges)
     hr, ar = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, [(zn, n), (n, zn)], edges)
     assert np.array_equal(hb, hr) and np.array_equal(ab, ar) and ar.sum() > 0
+
+
+@pytest.mark.parametrize("F,d,W", [(7, 1, 3), (50, 3, 16), (333, 7, 24), (333, 11, 25), (1000, 100, 5), (1000, 31, 32),
+                                   (257, 13, 12), (90, 100, 1), (64, 2, 29), (1201, 50, 21)])
+def test_msd_comb_kernel_equals_generic_and_oracle(hip_ctx, F, d, W):
+    # windows w*d: the comb kernel (every template bucket, ragged comb ends, F < d, the skipped origin)
+    # against the generic LDS kernel and the numpy restatement
+    from oracle import numpy_oracle as no
+    rng = np.random.default_rng(F * 131 + d)
+    n = 9
+    cell = np.array([[9.0, 0, 0], [1.0, 10.0, 0], [0.5, -0.7, 11.0]])
+    pos = np.cumsum(rng.normal(scale=0.25, size=(F, n, 3)), axis=0) + 4.0
+    s = pos @ np.linalg.inv(cell)
+    packed = PackedTrajectory((s - np.floor(s)) @ cell, cell, [1, 1, 1, 1, 8, 8, 30, 30, 30])
+    window = np.array([w * d for w in range(W) if w * d < F], dtype=np.int32)
+    comb, kinds = hip_ctx.msd_window(packed, window)
+    with _env(AMOF_MSD_NOCOMB="1"):
+        generic, _ = hip_ctx.msd_window(packed, window)
+    np.testing.assert_allclose(comb, generic, rtol=1e-12, atol=1e-12)
+    elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window)
+    for e, r in zip(elements, ref):
+        got = comb[kinds.index(int(e))] / (packed.numbers == e).sum() / (F - window)
+        np.testing.assert_allclose(got, r, rtol=1e-9, atol=1e-12)
