@@ -259,11 +259,11 @@ def main():
             # the instruction mix of the inner loop sums to ~70 issue cycles per visited wave-pair
             "valu_issue": {"simd_cycles_per_wave_pair": t_rdf * 1024 * 2.4e9 / (pairs / 64.0),
                            "model_cycles_per_visited_wave_pair": 70.0, "visited_fraction": 0.67},
-            "roofline_msd": {"kernel": "msd pipeline (com + delta_transpose + msd_group + reduce)", "bound": "hbm",
+            "roofline_msd": {"kernel": "msd pipeline (com + delta_transpose + msd_comb + reduce)", "bound": "hbm",
                              "achieved": alg_bytes / float(np.mean(k_msd_all)) / 1e9, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": alg_bytes / float(np.mean(k_msd_all)) / 1e9 / HBM_PEAK_GBPS,
                              "traffic": traffic.get("msd_pipeline"), "pipeline_seconds": float(np.mean(k_msd_all)),
-                             "msd_group_kernel_seconds": float(np.mean(k_msd_dom))},
+                             "msd_window_kernel_seconds": float(np.mean(k_msd_dom))},
             "kernel_seconds_per_step": {"rdf_tile": t_rdf, "rdf_all_incl_quantize": float(np.mean(k_rdf_all)),
                                         "msd_all": float(np.mean(k_msd_all))},
         }
