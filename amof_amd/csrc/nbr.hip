@@ -684,7 +684,13 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     // f32 chain error: fast_guard_rel (amof_internal.h); the fixed-point grid moves a distance by
     // < csum * 2^-32 (x2 margin)
     const double grel = fast_guard_rel(st.geom, nc);
-    fa.guard_rel = (float)(grel * (1.0 + 1e-6));
+    // + 3u: the cutoff rounded to f32 (1u) and the roundings of r_in / r_out = rc -+ g in the kernels
+    {
+        const double want = grel + 3.0 / 16777216.0;
+        float fg = (float)want;
+        if ((double)fg < want) fg = nextafterf(fg, INFINITY);
+        fa.guard_rel = fg;
+    }
     if (!nf.ortho) {
         // sheared cells: wrapped and canonical images may differ at |s_k| = 1/2 -- both must then be
         // decisively beyond every cutoff (see rdf.hip)

@@ -209,8 +209,8 @@ struct RdfFastArgs {
     const FrameScale *fs;    // [n_cells]
     int32_t f_base;          // first frame of this batch
     int32_t nf;              // frames in this batch
-    float guard;             // g_f (bins): f32 candidate
-    float nbins_f;
+    float half_m_guard;      // 1/2 - g_f rounded DOWN (g_f in bins: the f32 candidate's error bound)
+    float nb_hi;             // nbins + g_f rounded UP
     double guard64;          // g_m (bins): f64-from-fixed-point candidate
     int32_t xcd_map;         // 1: chunk -> XCD affinity mapping of the grid
     int32_t n_chunks;        // tile kernel: frames [c nf / n_chunks, (c+1) nf / n_chunks) belong to chunk c
@@ -394,8 +394,8 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const int la = 2 * lane, lb = la + 1;                          // local indices in the sub-tile
     const int ia = sub * FAST_SUB + la, ib = ia + 1;               // indices in tile I
     const bool has_a = la < cnti, has_b = lb < cnti;
-    const float half_m_guard = 0.5f - fa.guard;
-    const float nb_hi = fa.nbins_f + fa.guard;
+    const float half_m_guard = fa.half_m_guard;
+    const float nb_hi = fa.nb_hi;
     const int cntj = tj.count;
     const int cntj4 = (cntj + 3) & ~3;
     const int full = cntj & ~3;
@@ -542,8 +542,8 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_range_kernel_fast(RdfRang
     const int cnt_c = min(FAST_SUB, nA - c0);
     const int la = 2 * lane, lb = la + 1;
     const bool has_a = la < cnt_c, has_b = lb < cnt_c;
-    const float half_m_guard = 0.5f - fa.guard;
-    const float nb_hi = fa.nbins_f + fa.guard;
+    const float half_m_guard = fa.half_m_guard;
+    const float nb_hi = fa.nb_hi;
     const int f0 = blockIdx.y * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
 
@@ -814,8 +814,15 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             fa.a.tiles = (const Tile *)d_ftiles;
             fa.a.pairs = (const int2 *)d_fpairs;
             fa.fs = (const FrameScale *)d_fs;
-            fa.guard = (float)guard_f;
-            fa.nbins_f = (float)nbins;
+            // thresholds in f32 with directed rounding, so that the f64 bound g_f is never undercut
+            {
+                const double hi = (double)nbins + guard_f, half = 0.5 - guard_f;
+                float fhi = (float)hi, fhalf = (float)half;
+                if ((double)fhi < hi) fhi = nextafterf(fhi, INFINITY);
+                if ((double)fhalf > half) fhalf = nextafterf(fhalf, -INFINITY);
+                fa.nb_hi = fhi;
+                fa.half_m_guard = fhalf;
+            }
             fa.guard64 = guard_m;
             // ---- two-level cell list for small cutoffs (range kernel) ----
             int axis_y = (axis + 1) % 3;
