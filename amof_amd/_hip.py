@@ -176,6 +176,18 @@ class _TrajHandle(object):
         self.S = len(self.kinds)
 
 
+def _locked(method):
+    """An ``amof_ctx`` is not thread-safe (include/amof_hip.h): serialise the calls of one Context.
+    ctypes drops the GIL during a call, so two Python threads could otherwise be inside the same
+    context at once; distinct Context objects still run concurrently."""
+    def wrapper(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+    wrapper.__name__ = method.__name__
+    wrapper.__doc__ = method.__doc__
+    return wrapper
+
+
 class Context(object):
     """One ``amof_ctx``: a device, a stream and its scratch memory."""
 
@@ -191,6 +203,7 @@ class Context(object):
             raise AmofError(rc, "amof_ctx_create(device=%d) failed" % device)
         self._h = h
         self.device = int(device)
+        self._lock = threading.RLock()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -213,6 +226,7 @@ class Context(object):
             raise ValueError(msg)
         raise AmofError(rc, msg)
 
+    @_locked
     def set_stream(self, stream_ptr):
         self._check(self._lib.amof_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
 
@@ -220,16 +234,20 @@ class Context(object):
         import torch
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @_locked
     def synchronize(self):
         self._check(self._lib.amof_ctx_synchronize(self._h))
 
+    @_locked
     def last_kernel_seconds(self, dominant=True):
         return self._lib.amof_last_kernel_seconds(self._h, 1 if dominant else 0)
 
+    @_locked
     def last_kernel_launches(self):
         return self._lib.amof_last_kernel_launches(self._h)
 
     # ------------------------------------------------------------ analyses --
+    @_locked
     def rdf_accumulate(self, packed, rmax, nbins, frame_range=None, out=None):
         """ordered-pair histograms ``[S][S][nbins]`` (u64) and the volume sum.
 
@@ -250,6 +268,7 @@ class Context(object):
         self._check(rc)
         return hist, vol.value, th.kinds
 
+    @_locked
     def cn_count(self, packed, cutoff, sets, frame_range=None, per_atom=False):
         th = _TrajHandle(packed, frame_range)
         cutoff = np.ascontiguousarray(cutoff, dtype=np.float64).reshape(th.S, th.S)
@@ -263,6 +282,7 @@ class Context(object):
         self._check(rc)
         return (sums, pa) if per_atom else sums
 
+    @_locked
     def bad_hist(self, packed, cutoff, triples, edges, frame_range=None, out=None):
         th = _TrajHandle(packed, frame_range)
         cutoff = np.ascontiguousarray(cutoff, dtype=np.float64).reshape(th.S, th.S)
@@ -287,6 +307,7 @@ class Context(object):
         self._check(rc)
         return hist, nang
 
+    @_locked
     def bad_hist_by_cn(self, packed, cutoff, triples, edges, cn_max=16, frame_range=None):
         """``(hist u64 [T][cn_max+1][nb], n_angles u64 [T][cn_max+1])`` keyed by neighbour count."""
         th = _TrajHandle(packed, frame_range)
@@ -303,6 +324,7 @@ class Context(object):
         self._check(rc)
         return hist, nang
 
+    @_locked
     def msd_window(self, packed, windows, unwrap=False, remove_com=True, atom_range=None):
         """``(sumsq [S][W] f64, kinds)``: raw sums of squared displacements."""
         th = _TrajHandle(packed)
@@ -316,6 +338,7 @@ class Context(object):
         return out, th.kinds
 
 
+    @_locked
     def msd_direct(self, packed):
         """``(msd [F][S+1] f64, kinds)``: column 0 = all atoms, then one per species."""
         th = _TrajHandle(packed)

@@ -265,3 +265,33 @@ def test_msd_comb_kernel_equals_generic_and_oracle(hip_ctx, F, d, W):
     for e, r in zip(elements, ref):
         got = comb[kinds.index(int(e))] / (packed.numbers == e).sum() / (F - window)
         np.testing.assert_allclose(got, r, rtol=1e-9, atol=1e-12)
+
+
+def test_threads_shared_and_separate_contexts(hip_ctx):
+    # a Context serialises its callers; two Contexts (own streams and scratch) run concurrently
+    import threading
+    from amof_amd import _hip
+    trajs = [H.random_walk(H.zif4_frame(), 40 + 7 * k, 0.05, 100 + k) for k in range(4)]
+    refs = []
+    for tr in trajs:
+        kinds, sp = H.species_of(tr.numbers)
+        refs.append(clib.rdf_hist(tr.pos, tr.cell, sp, len(kinds), 7.0, 350, cell_list=True)[0])
+    other = _hip.Context(0)
+    errors = []
+
+    def work(ctx, k):
+        try:
+            for _ in range(5):
+                h, _, _ = ctx.rdf_accumulate(trajs[k], 7.0, 350)
+                if not np.array_equal(h, refs[k]):
+                    errors.append("mismatch in thread %d" % k)
+        except Exception as exc:                       # noqa: BLE001 - reported below
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(hip_ctx if k < 2 else other, k)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    other.close()
+    assert not errors, errors
