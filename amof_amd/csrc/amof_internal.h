@@ -78,6 +78,22 @@ int ensure(amof_ctx *ctx, Slot s, size_t bytes, void **out);
         if (_rc != AMOF_OK) return _rc; \
     } while (0)
 
+// Raise a kernel's dynamic-LDS cap to everything a workgroup may have besides the kernel's static
+// LDS.  The value depends on the kernel only, not on the launch, so contexts used from different
+// threads cannot undercut each other by setting it for the same kernel.
+inline hipError_t allow_max_lds(const void *kern)
+{
+    int dev = 0, per_block = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    if (e != hipSuccess) return e;
+    hipFuncAttributes attr;
+    e = hipFuncGetAttributes(&attr, kern);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, per_block - (int)attr.sharedSizeBytes);
+}
+
 // --------------------------------------------------------------- geometry --
 // One record per distinct cell: 24 doubles.
 //   [0..8]  cell rows          [9..17] cell^-1 with non-periodic columns zeroed

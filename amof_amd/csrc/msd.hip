@@ -588,7 +588,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     timing_dom_begin(ctx);
     if (lds_resident) {
         auto launch = [&](auto kern) -> hipError_t {
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need);
+            hipError_t e = allow_max_lds((const void *)kern);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds_need, ctx->stream,
                                (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
@@ -604,7 +604,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         }
         auto launch_comb = [&](auto kern) -> hipError_t {
             const size_t lds = (size_t)F * sizeof(double);
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = allow_max_lds((const void *)kern);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
                                (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,

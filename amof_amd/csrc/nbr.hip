@@ -869,10 +869,10 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             if (launches == 0) timing_dom_begin(ctx);
             hipError_t e;
             if (nf.ortho) {
-                e = hipFuncSetAttribute((const void *)bad_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                e = allow_max_lds((const void *)bad_fast_kernel<true>);
                 if (e == hipSuccess) hipLaunchKernelGGL(bad_fast_kernel<true>, grid, dim3(NBRF_TILE), lds, ctx->stream, nf.fa);
             } else {
-                e = hipFuncSetAttribute((const void *)bad_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                e = allow_max_lds((const void *)bad_fast_kernel<false>);
                 if (e == hipSuccess) hipLaunchKernelGGL(bad_fast_kernel<false>, grid, dim3(NBRF_TILE), lds, ctx->stream, nf.fa);
             }
             AMOF_HIP_TRY(ctx, e);
@@ -903,7 +903,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                      BAD_TILE * sizeof(int) + (size_t)nb * sizeof(unsigned);
         const bool extra = st.max_img > 0, ortho = st.geom.all_ortho;
         auto launch = [&](auto kern) -> hipError_t {
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = allow_max_lds((const void *)kern);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, grid, dim3(BAD_TILE), lds, ctx->stream, a);
             return hipGetLastError();

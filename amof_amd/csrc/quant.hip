@@ -173,7 +173,7 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
     // (or species counts unknown here: the cap is only a capacity) take the two-read path
     const int cache_cap = (int)std::min<int64_t>(N, 4608);
     const size_t lds = (size_t)cache_cap * sizeof(QAtom);
-    AMOF_HIP_TRY(ctx, hipFuncSetAttribute((const void *)quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AMOF_HIP_TRY(ctx, allow_max_lds((const void *)quantize_kernel));
     hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(256), lds, ctx->stream, pos_dev, d_geom, n_cells, d_perm, d_spfirst,
                        S, N, f0, axis, d_Q, d_slab_start, d_flag, cache_cap);
     AMOF_HIP_TRY(ctx, hipGetLastError());

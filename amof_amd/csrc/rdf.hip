@@ -902,10 +902,10 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     if (launches == 0) timing_dom_begin(ctx);
                     hipError_t e;
                     if (ortho) {
-                        e = hipFuncSetAttribute((const void *)rdf_range_kernel_fast<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                        e = allow_max_lds((const void *)rdf_range_kernel_fast<true>);
                         if (e == hipSuccess) hipLaunchKernelGGL(rdf_range_kernel_fast<true>, grid, dim3(FAST_THREADS), lds2, ctx->stream, ra);
                     } else {
-                        e = hipFuncSetAttribute((const void *)rdf_range_kernel_fast<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                        e = allow_max_lds((const void *)rdf_range_kernel_fast<false>);
                         if (e == hipSuccess) hipLaunchKernelGGL(rdf_range_kernel_fast<false>, grid, dim3(FAST_THREADS), lds2, ctx->stream, ra);
                     }
                     AMOF_HIP_TRY(ctx, e);
@@ -954,8 +954,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
                 if (launches == 0) timing_dom_begin(ctx);
                 auto launch = [&](auto kern) -> hipError_t {
-                    hipError_t e2 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)lds);
+                    hipError_t e2 = allow_max_lds((const void *)kern);
                     if (e2 != hipSuccess) return e2;
                     hipLaunchKernelGGL(kern, grid, dim3(FAST_THREADS), lds, ctx->stream, fa);
                     return hipSuccess;
@@ -990,8 +989,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         if (nbins <= AMOF_MAX_LDS_BINS) {
             size_t lds = 3 * RDF_TILE * sizeof(double) + (size_t)nbins * sizeof(unsigned);
             auto launch = [&](auto kern) -> hipError_t {
-                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)lds);
+                hipError_t e = allow_max_lds((const void *)kern);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, grid, dim3(RDF_TILE), lds, ctx->stream, a);
                 return hipGetLastError();
