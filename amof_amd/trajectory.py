@@ -108,6 +108,22 @@ def _fit(pos, cell):
     return pos, cell
 
 
+def _read_xyz_maybe_gz(path, index, unzip):
+    """``unzip=True``: gunzip into a temporary file first, as the reference does
+    (amof/trajectory.py:50-56), then map that file with the native reader."""
+    if not unzip:
+        return read_xyz(path, index)
+    import gzip
+    import shutil
+    import tempfile
+    logger.info("Unzip trajectory file")
+    with tempfile.NamedTemporaryFile(suffix=".xyz") as tmp:
+        with gzip.open(path, "rb") as f_in:
+            shutil.copyfileobj(f_in, tmp)
+        tmp.flush()
+        return read_xyz(tmp.name, index)
+
+
 def read_lammps_traj(path_to_xyz, index=None, cell=None, unzip_xyz=False):
     """
     Args:
@@ -117,9 +133,7 @@ def read_lammps_traj(path_to_xyz, index=None, cell=None, unzip_xyz=False):
     Returns:
         PackedTrajectory (pbc = True, as Trajectory.set_cell does)
     """
-    if unzip_xyz:
-        raise NotImplementedError("gunzip the file first; the native reader maps the file")
-    pos, numbers, lattice = read_xyz(path_to_xyz, index)
+    pos, numbers, lattice = _read_xyz_maybe_gz(path_to_xyz, index, unzip_xyz)
     if cell is None:
         if lattice is None:
             raise ValueError("no cell given and the file carries no Lattice")
@@ -139,9 +153,7 @@ def read_cp2k_traj(path_to_xyz, path_to_cell, index=None, unzip_xyz=False):
     Returns:
         PackedTrajectory with one cell per frame (pbc = True)
     """
-    if unzip_xyz:
-        raise NotImplementedError("gunzip the file first; the native reader maps the file")
-    pos, numbers, _ = read_xyz(path_to_xyz, index)
+    pos, numbers, _ = _read_xyz_maybe_gz(path_to_xyz, index, unzip_xyz)
     cell = read_cp2k_cell(path_to_cell)
     if isinstance(index, str):
         index = string2index(index)

@@ -69,6 +69,22 @@ def test_read_cp2k_traj(tmp_path):
     assert len(frames) == 12 and frames[3].get_volume() == pytest.approx(abs(np.linalg.det(ref[3])))
 
 
+def test_gzipped_xyz_like_the_reference(tmp_path):
+    # unzip_xyz=True: gunzip to a temporary file, then read (amof/trajectory.py:50-56)
+    import gzip
+    packed = H.random_walk(H.zif4_frame(), 7, 0.1, 6, cell_jitter=0.01)
+    plain = str(tmp_path / "t.xyz")
+    T.write_xyz(plain, packed, fmt="%.17g")
+    with open(plain, "rb") as fi, gzip.open(plain + ".gz", "wb") as fo:
+        fo.write(fi.read())
+    got = T.read_lammps_traj(plain + ".gz", "1:6:2", unzip_xyz=True)
+    assert np.array_equal(got.pos, packed.pos[1:6:2]) and np.array_equal(got.cell, packed.cell[1:6:2])
+    cellfile = os.path.join(GOLDEN, "toy_trajectory_200.cell")
+    a = T.read_cp2k_traj(plain + ".gz", cellfile, slice(0, 7), unzip_xyz=True)
+    b = T.read_cp2k_traj(plain, cellfile, slice(0, 7))
+    assert np.array_equal(a.pos, b.pos) and np.array_equal(a.cell, b.cell)
+
+
 def test_errors(tmp_path):
     with pytest.raises(ValueError):
         T.read_xyz(str(tmp_path / "missing.xyz"))
