@@ -108,6 +108,74 @@ def _fit(pos, cell):
     return pos, cell
 
 
+class Trajectory(object):
+    """Mirror of the reference's ``amof.trajectory.Trajectory`` for the formats the native reader
+    covers (reference amof/trajectory.py:27-109).  ``self.traj`` is a :class:`PackedTrajectory`
+    (the reference holds a list of ``ase.Atoms``); every analysis class accepts it as is, and
+    ``.to_frames()`` materialises the list."""
+
+    def __init__(self):
+        self.traj = None
+
+    @classmethod
+    def from_traj(cls, filename, index=None, format=None, unzip=False):
+        """Read an XYZ / extended-XYZ file (amof/trajectory.py:37-60).
+
+        Args:
+            index: 'first_frame:last_frame:step' or slice(first_frame, last_frame, step); None = last frame
+            format: None, 'xyz' or 'extxyz' -- other ASE formats are not read natively
+            unzip: gunzip into a temporary file first
+        """
+        if format not in (None, "xyz", "extxyz"):
+            raise NotImplementedError("format %r is not read natively; convert to (ext)xyz" % (format,))
+        logger.info("Read trajectory %s", filename)
+        out = cls()
+        pos, numbers, lattice = _read_xyz_maybe_gz(filename, index, unzip)
+        if lattice is not None:
+            cell, pbc = lattice, (True, True, True)
+            if len(cell) > 1 and (cell == cell[0]).all():
+                cell = cell[:1]
+        else:                                   # plain xyz: no cell yet (ASE: zero cell, pbc False)
+            cell, pbc = np.zeros((1, 3, 3)), (False, False, False)
+        out.traj = PackedTrajectory(pos, cell, numbers, pbc=pbc)
+        return out
+
+    @classmethod
+    def from_lammps_data(cls, filename, atom_style):
+        raise NotImplementedError("LAMMPS data files are outside the accelerated path; read them with ASE and "
+                                  "hand the Atoms list to the analysis classes")
+
+    @staticmethod
+    def get_index_closest(myList, myNumber):
+        """Index of the entry of the sorted ``myList`` closest to ``myNumber``; the smaller index on a
+        tie (amof/trajectory.py:76-94; like the reference, the first/last VALUE is returned at the ends)."""
+        import bisect
+        pos = bisect.bisect_left(myList, myNumber)
+        if pos == 0:
+            return myList[0]
+        if pos == len(myList):
+            return myList[-1]
+        before = myList[pos - 1]
+        after = myList[pos]
+        if after - myNumber < myNumber - before:
+            return pos
+        return pos - 1
+
+    def set_cell(self, cell, set_pbc=True, fit_size=True):
+        """One cell per frame (amof/trajectory.py:96-114); sizes are fitted to the shorter of the two."""
+        cell = np.asarray(cell, dtype=np.float64).reshape(-1, 3, 3)
+        pos = self.traj.pos_host()
+        if len(pos) != len(cell):
+            if not fit_size:
+                raise ValueError("traj has %d frames, cell has %d" % (len(pos), len(cell)))
+            pos, cell = _fit(pos, cell)
+        pbc = (True, True, True) if set_pbc else tuple(self.traj.pbc)
+        self.traj = PackedTrajectory(pos, cell, self.traj.numbers, self.traj.masses, pbc)
+
+    def get_traj(self):
+        return self.traj
+
+
 def _read_xyz_maybe_gz(path, index, unzip):
     """``unzip=True``: gunzip into a temporary file first, as the reference does
     (amof/trajectory.py:50-56), then map that file with the native reader."""

@@ -85,6 +85,30 @@ def test_gzipped_xyz_like_the_reference(tmp_path):
     assert np.array_equal(a.pos, b.pos) and np.array_equal(a.cell, b.cell)
 
 
+def test_trajectory_class_mirror(tmp_path):
+    # amof.trajectory.Trajectory: from_traj / set_cell (fit_size) / get_traj / get_index_closest
+    packed = H.random_walk(H.zif4_frame(), 9, 0.1, 8)
+    xyz = str(tmp_path / "plain.xyz")
+    T.write_xyz(xyz, packed, comment_lattice=False, fmt="%.17g")
+    tr = T.Trajectory.from_traj(xyz, ":", format="xyz")
+    assert tr.get_traj().n_frames == 9 and not tr.get_traj().pbc.any()
+    cells = np.repeat(packed.cell, 6, axis=0) * np.linspace(1.0, 1.05, 6)[:, None, None]
+    tr.set_cell(cells, set_pbc=True)                         # 9 frames vs 6 cells: trimmed to 6
+    got = tr.get_traj()
+    assert got.n_frames == 6 and got.pbc.all() and np.array_equal(got.cell, cells)
+    assert np.array_equal(got.pos, packed.pos[:6])
+    with pytest.raises(ValueError):
+        tr.set_cell(cells[:2], fit_size=False)
+    ext = str(tmp_path / "ext.xyz")
+    T.write_xyz(ext, packed, fmt="%.17g")
+    assert T.Trajectory.from_traj(ext, "2:5").get_traj().pbc.all()
+    with pytest.raises(NotImplementedError):
+        T.Trajectory.from_traj(ext, format="lammps-dump-text")
+    masses = [1.0, 4.0, 7.0, 12.0]
+    assert T.Trajectory.get_index_closest(masses, 6.9) == 2 and T.Trajectory.get_index_closest(masses, 5.5) == 1
+    assert T.Trajectory.get_index_closest(masses, 0.5) == 1.0 and T.Trajectory.get_index_closest(masses, 99.0) == 12.0
+
+
 def test_errors(tmp_path):
     with pytest.raises(ValueError):
         T.read_xyz(str(tmp_path / "missing.xyz"))
