@@ -102,16 +102,32 @@ __global__ __launch_bounds__(MSD_THREADS) void delta_transpose_kernel(const doub
     __shared__ double tile[TR_F][3 * TR_A + 1];
     const int k0 = blockIdx.y * TR_F;
     const int64_t a0 = (int64_t)blockIdx.x * TR_A;
-    for (int idx = threadIdx.x; idx < TR_F * TR_A; idx += MSD_THREADS) {
+    // all eight items of a thread are loaded before any is wrapped: the kernel is latency bound otherwise
+    constexpr int ITEMS = TR_F * TR_A / MSD_THREADS;
+    double x1v[ITEMS], y1v[ITEMS], z1v[ITEMS], x0v[ITEMS], y0v[ITEMS], z0v[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int idx = threadIdx.x + it * MSD_THREADS;
+        const int k = k0 + idx / TR_A;
+        const int64_t a = a0 + idx % TR_A;
+        x1v[it] = y1v[it] = z1v[it] = x0v[it] = y0v[it] = z0v[it] = 0.0;
+        if (k < F && a < N && k >= 1) {
+            const double *p1 = pos + ((size_t)k * N + a) * 3;
+            const double *p0 = pos + ((size_t)(k - 1) * N + a) * 3;
+            x1v[it] = p1[0]; y1v[it] = p1[1]; z1v[it] = p1[2];
+            x0v[it] = p0[0]; y0v[it] = p0[1]; z0v[it] = p0[2];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int idx = threadIdx.x + it * MSD_THREADS;
         const int kl = idx / TR_A, al = idx % TR_A;
         const int k = k0 + kl;
         const int64_t a = a0 + al;
         double dx = 0.0, dy = 0.0, dz = 0.0;
         if (k < F && a < N && k >= 1) {
-            const double *p1 = pos + ((size_t)k * N + a) * 3;
-            const double *p0 = pos + ((size_t)(k - 1) * N + a) * 3;
-            double x1 = p1[0], y1 = p1[1], z1 = p1[2];
-            double x0 = p0[0], y0 = p0[1], z0 = p0[2];
+            double x1 = x1v[it], y1 = y1v[it], z1 = z1v[it];
+            double x0 = x0v[it], y0 = y0v[it], z0 = z0v[it];
             if (com) {
                 x1 -= com[3 * k]; y1 -= com[3 * k + 1]; z1 -= com[3 * k + 2];
                 x0 -= com[3 * (k - 1)]; y0 -= com[3 * (k - 1) + 1]; z0 -= com[3 * (k - 1) + 2];
