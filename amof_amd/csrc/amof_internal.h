@@ -38,6 +38,8 @@ enum Slot {
     SLOT_AUX5,
     SLOT_AUX6,
     SLOT_AUX7,
+    SLOT_AUX8,
+    SLOT_AUX9,
     SLOT_OUT0,
     SLOT_OUT1,
     SLOT_FLAGS,
@@ -192,6 +194,15 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
 int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                      const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis_z, int axis_y, int nz,
                      QAtom *d_Q, uint32_t *d_start2, int32_t *d_flag);
+
+// 3-D cell sort for the cell-list RDF kernel: all atoms of a frame sorted by
+// key = ((cz * ny + cy) * nx + cx) * S + species (x fastest), d_start3[nf][nkeys + 1] = offsets.
+// Q3[.].idx = species << CELL_SPECIES_SHIFT | atom index.  Scratch: d_keys u32 [nf][N],
+// d_cursor u32 [nf][nkeys].
+constexpr int CELL_SPECIES_SHIFT = 26;
+int launch_cell_sort(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_species,
+                     int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q3, uint32_t *d_start3,
+                     uint32_t *d_keys, uint32_t *d_cursor, int32_t *d_flag);
 
 void timing_begin(amof_ctx *ctx);
 void timing_end(amof_ctx *ctx);

@@ -148,6 +148,97 @@ __global__ __launch_bounds__(256) void quantize2_kernel(const double *__restrict
     }
 }
 
+// ---- 3-D cell sort (rdf_cell_kernel) -------------------------------------------------------
+__device__ __forceinline__ uint32_t cell_key(const QAtom &q, int nx, int ny, int nz, int S, int sp)
+{
+    const uint32_t cx = __umulhi(q.ux, (unsigned)nx), cy = __umulhi(q.uy, (unsigned)ny), cz = __umulhi(q.uz, (unsigned)nz);
+    return ((cz * (uint32_t)ny + cy) * (uint32_t)nx + cx) * (uint32_t)S + (uint32_t)sp;
+}
+
+__global__ __launch_bounds__(256) void cell_key_kernel(const double *__restrict__ pos, const double *__restrict__ geom,
+                                                       int n_cells, const int32_t *__restrict__ species, int S,
+                                                       int64_t N, int f0, int nx, int ny, int nz,
+                                                       uint32_t *__restrict__ keys, uint32_t *__restrict__ counts,
+                                                       int32_t *flag)
+{
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= N) return;
+    const int fl = blockIdx.y, f = f0 + fl;
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const QAtom q = quantize_atom(pos, g, N, f, a, 0, 1, 2, flag);
+    const uint32_t key = cell_key(q, nx, ny, nz, S, species[a]);
+    keys[(size_t)fl * N + a] = key;
+    atomicAdd(&counts[(size_t)fl * ((size_t)nx * ny * nz * S + 1) + key], 1u);
+}
+
+// one workgroup per frame: exclusive scan of the key counts, in place (start3), and a copy for the scatter
+__global__ __launch_bounds__(256) void cell_scan_kernel(uint32_t *__restrict__ start3, uint32_t *__restrict__ cursor,
+                                                        int nkeys)
+{
+    __shared__ unsigned wsum[4];
+    const int fl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t *st = start3 + (size_t)fl * (nkeys + 1);
+    uint32_t *cu = cursor + (size_t)fl * nkeys;
+    const int chunk = (nkeys + 255) / 256;
+    const int k0 = min(tid * chunk, nkeys), k1 = min(k0 + chunk, nkeys);
+    unsigned s = 0;
+    for (int k = k0; k < k1; k++) s += st[k];
+    unsigned incl = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - s;
+    for (int w = 0; w < wv; w++) run += wsum[w];
+    for (int k = k0; k < k1; k++) {
+        const unsigned c = st[k];
+        st[k] = run;
+        cu[k] = run;
+        run += c;
+    }
+    if (tid == 255) st[nkeys] = run;     // (the last thread's chunk ends at nkeys, possibly empty)
+}
+
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const double *__restrict__ pos, const double *__restrict__ geom,
+                                                           int n_cells, const int32_t *__restrict__ species, int64_t N,
+                                                           int f0, int nkeys, const uint32_t *__restrict__ keys,
+                                                           uint32_t *__restrict__ cursor, QAtom *__restrict__ Q3)
+{
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= N) return;
+    const int fl = blockIdx.y, f = f0 + fl;
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    int32_t dummy = 0;
+    QAtom q = quantize_atom(pos, g, N, f, a, 0, 1, 2, &dummy);
+    const uint32_t key = keys[(size_t)fl * N + a];
+    const unsigned slot = atomicAdd(&cursor[(size_t)fl * nkeys + key], 1u);
+    q.idx = ((uint32_t)species[a] << CELL_SPECIES_SHIFT) | (uint32_t)a;
+    Q3[(size_t)fl * N + slot] = q;
+}
+
+int launch_cell_sort(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_species,
+                     int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q3, uint32_t *d_start3,
+                     uint32_t *d_keys, uint32_t *d_cursor, int32_t *d_flag)
+{
+    if (nf <= 0 || N <= 0) return AMOF_OK;
+    if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
+    const int64_t nkeys64 = (int64_t)nx * ny * nz * S;
+    if (nx < 1 || ny < 1 || nz < 1 || nkeys64 > 0x3fffffff || N >= (1ll << CELL_SPECIES_SHIFT) || S > 64)
+        return fail(ctx, AMOF_EINVAL, "bad cell grid");
+    const int nkeys = (int)nkeys64;
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(d_start3, 0, (size_t)nf * (nkeys + 1) * sizeof(uint32_t), ctx->stream));
+    dim3 agrid((unsigned)((N + 255) / 256), (unsigned)nf);
+    hipLaunchKernelGGL(cell_key_kernel, agrid, dim3(256), 0, ctx->stream, pos_dev, d_geom, n_cells, d_species, S, N, f0,
+                       nx, ny, nz, d_keys, d_start3, d_flag);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3((unsigned)nf), dim3(256), 0, ctx->stream, d_start3, d_cursor, nkeys);
+    hipLaunchKernelGGL(cell_scatter_kernel, agrid, dim3(256), 0, ctx->stream, pos_dev, d_geom, n_cells, d_species, N, f0,
+                       nkeys, (const uint32_t *)d_keys, d_cursor, d_Q3);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    return AMOF_OK;
+}
+
 int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                      const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis_z, int axis_y, int nz,
                      QAtom *d_Q, uint32_t *d_start2, int32_t *d_flag)

@@ -624,6 +624,146 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_range_kernel_fast(RdfRang
     }
 }
 
+// --------------------------------------------------------------------------
+// Cell-list kernel: cutoffs far below the cell size (rmax <= h_k / 2.5 on every axis).
+//
+// Frames come sorted into a 3-D grid of cells at least rmax/2 thick (launch_cell_sort), x
+// fastest, species-sorted inside a cell.  One lane = one centre atom; it walks the 13 rows
+// (dz, dy) of the positive half shell -- (0,0), (0,1), (0,2), (1,-2..2), (2,-2..2) -- and in
+// each row the x-contiguous run of cells cx-2 .. cx+2 (row (0,0): from its own successor to
+// the end of cell cx+2), i.e. at most two index ranges per row (periodic wrap in x).  Every
+// unordered pair of atoms within reach is met exactly once (the grid has >= 5 cells per axis, so
+// +d and -d never name the same cell).  Partners are gathered from L2 (a frame's records fit in
+// it and all workgroups of a frame are dealt to one XCD); the pair arithmetic is the fast
+// path's three levels; the LDS histogram holds every unordered species pair.
+struct RdfCellArgs {
+    RdfFastArgs f;
+    const uint32_t *start3;   // [nf][nkeys + 1]
+    const uint32_t *keyoff;   // [S*S] offset of the pair (sa, sb) in the LDS histogram (pair key * nbins)
+    const uint32_t *keyU;     // [npk] offset of pair key k in U ((lo * S + hi) * nbins)
+    int32_t nx, ny, nz, npk;
+    int32_t frames_grid;      // frames in the grid (rounded up to a multiple of 8 with the XCD mapping)
+    int32_t cpt;              // centre atoms per thread (the workgroup covers 256 * cpt consecutive atoms)
+};
+
+constexpr int CELL_THREADS = 256;
+constexpr uint32_t CELL_IDX_MASK = (1u << CELL_SPECIES_SHIFT) - 1u;
+
+template <bool ORTHO>
+__global__ __launch_bounds__(CELL_THREADS) void rdf_cell_kernel(RdfCellArgs ca)
+{
+    const RdfFastArgs &fa = ca.f;
+    const RdfArgs &a = fa.a;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);          // [npk * nbins]
+    unsigned *koff = hist + (size_t)ca.npk * a.nbins;                // [S * S]
+    const int tid = threadIdx.x;
+    const int S = a.S, nbins = a.nbins;
+    // all workgroups of a frame on one XCD (its quantised records stay in that L2)
+    unsigned fl = blockIdx.y, bx = blockIdx.x;
+    if (fa.xcd_map) {
+        const unsigned long long lin = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned long long kk = lin >> 3;
+        fl = (unsigned)(kk / gridDim.x) * 8u + (unsigned)(lin & 7ull);
+        bx = (unsigned)(kk % gridDim.x);
+    }
+    if ((int)fl >= fa.nf) return;
+    for (int k = tid; k < ca.npk * nbins; k += CELL_THREADS) hist[k] = 0u;
+    for (int k = tid; k < S * S; k += CELL_THREADS) koff[k] = ca.keyoff[k];
+    __syncthreads();
+
+    const int f = fa.f_base + (int)fl;
+    const int N = (int)a.N;
+    const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+    const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
+    const int gi = a.n_cells == 1 ? 0 : f;
+    const FrameScale *__restrict__ fs = fa.fs + gi;
+    const double *__restrict__ g = a.geom + (size_t)gi * GEOM_STRIDE;
+    float sc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
+    const int nx = ca.nx, ny = ca.ny, nz = ca.nz;
+    const uint32_t *__restrict__ st = ca.start3 + (size_t)fl * ((size_t)nx * ny * nz * S + 1);
+    const float half_m_guard = fa.half_m_guard, nb_hi = fa.nb_hi;
+
+    for (int c = 0; c < ca.cpt; c++) {
+        const int i = ((int)bx * ca.cpt + c) * CELL_THREADS + tid;
+        const bool active = i < N;
+        const QAtom own = Qf[active ? i : N - 1];
+        const unsigned *krow = koff + (own.idx >> CELL_SPECIES_SHIFT) * S;
+        const uint32_t ida = own.idx & CELL_IDX_MASK;
+        const int cx = (int)__umulhi(own.ux, (unsigned)nx), cy = (int)__umulhi(own.uy, (unsigned)ny),
+                  cz = (int)__umulhi(own.uz, (unsigned)nz);
+        // the (at most) 26 partner index ranges of this centre, all looked up before any pair work
+        // (the table lookups are dependent global loads: issued together they cost one latency, not 26)
+        int js0[26], js1[26];
+#pragma unroll
+        for (int row = 0; row < 13; row++) {
+            // rows of the positive half shell
+            const int dz = row < 3 ? 0 : (row < 8 ? 1 : 2);
+            const int dy = row < 3 ? row : (row < 8 ? row - 5 : row - 10);
+            int cz2 = cz + dz, cy2 = cy + dy;
+            if (cz2 >= nz) cz2 -= nz;
+            if (cy2 >= ny) cy2 -= ny;
+            if (cy2 < 0) cy2 += ny;
+            const int rowbase = (cz2 * ny + cy2) * nx;
+            const int xlo = row == 0 ? cx : cx - 2, xhi = cx + 2;
+            // cells [xlo, xhi] with periodic wrap: at most two runs
+            int xa0, xb0, xa1 = 0, xb1 = -1;
+            if (xlo < 0) { xa0 = xlo + nx; xb0 = nx - 1; xa1 = 0; xb1 = xhi; }
+            else if (xhi >= nx) { xa0 = xlo; xb0 = nx - 1; xa1 = 0; xb1 = xhi - nx; }
+            else { xa0 = xlo; xb0 = xhi; }
+#pragma unroll
+            for (int seg = 0; seg < 2; seg++) {
+                const int xa = seg == 0 ? xa0 : xa1, xb = seg == 0 ? xb0 : xb1;
+                int j0 = 0, j1 = 0;
+                if (active && xa <= xb) {
+                    j0 = (int)st[(size_t)(rowbase + xa) * S];
+                    j1 = (int)st[(size_t)(rowbase + xb + 1) * S];
+                    if (row == 0 && seg == 0) j0 = i + 1;     // own cell: the partners after me
+                }
+                js0[2 * row + seg] = j0;
+                js1[2 * row + seg] = j1;
+            }
+        }
+#pragma unroll 1
+        for (int rs = 0; rs < 26; rs++) {
+            {
+                const int j0 = js0[rs], j1 = js1[rs];
+                // four partners per trip, all loaded before any is evaluated (the gathers come from L2)
+                for (int j = j0; __any(j < j1); j += 4) {
+                    uint4 qv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        qv[u] = j < j1 ? *reinterpret_cast<const uint4 *>(Qf + min(j + u, j1 - 1)) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (j + u < j1) {
+                            const uint4 qj = qv[u];
+                            const int ix = (int)(qj.x - own.ux), iy = (int)(qj.y - own.uy), iz = (int)(qj.z - own.uz);
+                            const float q = fast_q<ORTHO>(sc, ix, iy, iz);
+                            if (q < nb_hi) {
+                                unsigned *h = hist + krow[qj.w >> CELL_SPECIES_SHIFT];
+                                if (fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard) {
+                                    atomicAdd(&h[(int)q], 1u);
+                                } else {
+                                    rdf_pair_refine<ORTHO>(h, fa, fs, g, q, own.ux, own.uy, own.uz,
+                                                           make_uint4(qj.x, qj.y, qj.z, qj.w & CELL_IDX_MASK), p, ida);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < ca.npk * nbins; k += CELL_THREADS) {
+        const unsigned v = hist[k];
+        if (v) atomicAdd(&a.U[(size_t)ca.keyU[k / nbins] + (size_t)(k % nbins)], (unsigned long long)v);
+    }
+}
+
 // hist[a][b][k] += (a == b) ? 2*U[a][a][k] + nsp[a]*selfh[k] : U[min][max][k]
 __global__ void rdf_finalize_kernel(const unsigned long long *U, const unsigned long long *selfh,
                                     const long long *nsp, unsigned long long *hist, int S, int nbins)
@@ -824,12 +964,121 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.half_m_guard = fhalf;
             }
             fa.guard64 = guard_m;
+            // ---- 3-D cell list for cutoffs far below the cell size (cell kernel) ----
+            bool cell_taken = false;
+            {
+                int nk[3];
+                bool cell_ok = S <= 16 && t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && t->n_atoms >= 64 &&
+                               !getenv("AMOF_RDF_NOCELL");
+                for (int x = 0; x < 3; x++) {
+                    nk[x] = (int)std::min(1024.0, floor(hmin[x] / (0.5 * rmax * (1.0 + 1e-5))));
+                    if (nk[x] < 5) cell_ok = false;
+                }
+                const int npk = S * (S + 1) / 2;
+                const size_t lds3 = ((size_t)npk * nbins + (size_t)S * S) * sizeof(unsigned);
+                if (lds3 > 96 * 1024) cell_ok = false;
+                if (cell_ok) {
+                    // no point in cells emptier than ~2 atoms: thicker cells are still correct (reach stays 2)
+                    while ((int64_t)nk[0] * nk[1] * nk[2] > std::max<int64_t>(125, t->n_atoms / 2)) {
+                        int big = 0;
+                        for (int x = 1; x < 3; x++)
+                            if (nk[x] > nk[big]) big = x;
+                        if (nk[big] <= 5) break;
+                        nk[big]--;
+                    }
+                    // visited share of all pairs: half shell of 5x5x5 cells (lane utilisation ~0.8) vs the slab list
+                    const double f3 = 62.5 / ((double)nk[0] * nk[1] * nk[2]) / 0.8;
+                    const double f1c = std::min(1.0, 2.0 * rmax / hmin[axis] + 2.0 / 256 + 0.02);
+                    if (!(f3 < 0.5 * f1c) && !getenv("AMOF_RDF_FORCE_CELL")) cell_ok = false;
+                }
+                if (cell_ok) {
+                    const int nkeys = nk[0] * nk[1] * nk[2] * S;
+                    AMOF_TRY(stager_need(stage, t->n_frames));
+                    std::vector<FrameScale> fs3((size_t)nc);
+                    for (int64_t k = 0; k < nc; k++) {
+                        const double *c = t->cell + 9 * k;
+                        FrameScale &r = fs3[(size_t)k];
+                        for (int q = 0; q < 9; q++) r.sc64[q] = 0.0;
+                        if (ortho) {
+                            for (int q = 0; q < 3; q++) r.sc64[q] = c[4 * q] * two32 / dr;
+                        } else {
+                            for (int q = 0; q < 9; q++) r.sc64[q] = c[q] * two32 / dr;
+                        }
+                        for (int q = 0; q < 9; q++) r.sc[q] = (float)r.sc64[q];
+                        if (ortho)
+                            for (int q = 0; q < 3; q++) r.sc[3 + q] = (float)(r.sc64[q] * r.sc64[q]);
+                        r.cull_gap = 0u;
+                    }
+                    std::vector<uint32_t> ktab((size_t)S * S + npk);
+                    {
+                        int key = 0;
+                        for (int lo = 0; lo < S; lo++)
+                            for (int hi = lo; hi < S; hi++, key++) {
+                                ktab[(size_t)lo * S + hi] = ktab[(size_t)hi * S + lo] = (uint32_t)(key * nbins);
+                                ktab[(size_t)S * S + key] = (uint32_t)(((size_t)lo * S + hi) * nbins);
+                            }
+                    }
+                    void *d_fs3, *d_ktab, *d_spec, *d_Q3, *d_start3, *d_keys, *d_cursor, *d_flag3;
+                    AMOF_TRY(upload(ctx, SLOT_AUX5, fs3.data(), fs3.size() * sizeof(FrameScale), &d_fs3));
+                    AMOF_TRY(upload(ctx, SLOT_AUX8, ktab.data(), ktab.size() * sizeof(uint32_t), &d_ktab));
+                    AMOF_TRY(upload(ctx, SLOT_SPEC, t->species, (size_t)t->n_atoms * sizeof(int32_t), &d_spec));
+                    const size_t per_frame = (size_t)t->n_atoms * (sizeof(QAtom) + sizeof(uint32_t)) +
+                                             (size_t)(2 * nkeys + 1) * sizeof(uint32_t);
+                    int64_t FB3 = std::max<int64_t>(1, (int64_t)(1ll << 30) / (int64_t)per_frame);
+                    FB3 = std::min<int64_t>(std::min<int64_t>(FB3, 32768), t->n_frames);
+                    AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB3 * t->n_atoms * sizeof(QAtom), &d_Q3));
+                    AMOF_TRY(ensure(ctx, SLOT_AUX7, (size_t)FB3 * (nkeys + 1) * sizeof(uint32_t), &d_start3));
+                    AMOF_TRY(ensure(ctx, SLOT_AUX6, (size_t)FB3 * t->n_atoms * sizeof(uint32_t), &d_keys));
+                    AMOF_TRY(ensure(ctx, SLOT_AUX9, (size_t)FB3 * nkeys * sizeof(uint32_t), &d_cursor));
+                    AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag3));
+                    AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag3, 0, sizeof(int32_t), ctx->stream));
+                    RdfCellArgs ca;
+                    ca.f = fa;
+                    ca.f.fs = (const FrameScale *)d_fs3;
+                    ca.f.Q = (const QAtom *)d_Q3;
+                    ca.start3 = (const uint32_t *)d_start3;
+                    ca.keyoff = (const uint32_t *)d_ktab;
+                    ca.keyU = (const uint32_t *)d_ktab + (size_t)S * S;
+                    ca.nx = nk[0]; ca.ny = nk[1]; ca.nz = nk[2];
+                    ca.npk = npk;
+                    ca.cpt = t->n_atoms >= 4096 ? 2 : 1;
+                    const unsigned gx = (unsigned)((t->n_atoms + (int64_t)CELL_THREADS * ca.cpt - 1) / ((int64_t)CELL_THREADS * ca.cpt));
+                    int64_t launches = 0;
+                    for (int64_t fb = 0; fb < t->n_frames; fb += FB3) {
+                        const int64_t nf = std::min<int64_t>(FB3, t->n_frames - fb);
+                        AMOF_TRY(launch_cell_sort(ctx, pos_dev, (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_spec, S,
+                                                  t->n_atoms, (int)fb, (int)nf, nk[0], nk[1], nk[2], (QAtom *)d_Q3,
+                                                  (uint32_t *)d_start3, (uint32_t *)d_keys, (uint32_t *)d_cursor,
+                                                  (int32_t *)d_flag3));
+                        ca.f.f_base = (int32_t)fb;
+                        ca.f.nf = (int32_t)nf;
+                        ca.f.xcd_map = nf >= 16 ? 1 : 0;
+                        ca.frames_grid = (int32_t)(ca.f.xcd_map ? (nf + 7) / 8 * 8 : nf);
+                        dim3 grid(gx, (unsigned)ca.frames_grid);
+                        if (launches == 0) timing_dom_begin(ctx);
+                        hipError_t e = ortho ? allow_max_lds((const void *)rdf_cell_kernel<true>)
+                                             : allow_max_lds((const void *)rdf_cell_kernel<false>);
+                        AMOF_HIP_TRY(ctx, e);
+                        if (ortho) hipLaunchKernelGGL(rdf_cell_kernel<true>, grid, dim3(CELL_THREADS), lds3, ctx->stream, ca);
+                        else hipLaunchKernelGGL(rdf_cell_kernel<false>, grid, dim3(CELL_THREADS), lds3, ctx->stream, ca);
+                        AMOF_HIP_TRY(ctx, hipGetLastError());
+                        launches++;
+                    }
+                    timing_dom_end(ctx, launches);
+                    int32_t flag3 = 0;
+                    AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag3, d_flag3, sizeof flag3, hipMemcpyDeviceToHost, ctx->stream));
+                    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    if (flag3) AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));   // far-away atoms: exact kernels
+                    else done = true;
+                    cell_taken = true;    // (either done, or the exact kernels take over)
+                }
+            }
             // ---- two-level cell list for small cutoffs (range kernel) ----
             int axis_y = (axis + 1) % 3;
             if (hmin[(axis + 2) % 3] > hmin[axis_y]) axis_y = (axis + 2) % 3;
             const int nz2 = (int)std::min(64.0, floor(hmin[axis] / (rmax * (1.0 + 1e-5))));
             bool use_range = false;
-            if (nz2 >= 3 && t->n_cells == 1 && !(getenv("AMOF_RDF_NORANGE"))) {
+            if (nz2 >= 3 && t->n_cells == 1 && !cell_taken && !(getenv("AMOF_RDF_NORANGE"))) {
                 // visited share of the partners: 1-D slab list vs (3 slabs) x (y strip + 2 rmax)
                 int64_t nmax = 0;
                 for (int x = 0; x < S; x++) nmax = std::max<int64_t>(nmax, ftiles.nsp[x]);
@@ -919,7 +1168,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 if (flag2) AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));
                 else done = true;
             }
-            if (!done && !use_range) {
+            if (!done && !use_range && !cell_taken) {
             int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
             FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), t->n_frames);
             // host-resident input: batches of 512, 1024, 2048 ... frames (each >= 32 chunks of 16 frames); the copy

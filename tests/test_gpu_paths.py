@@ -295,3 +295,45 @@ def test_threads_shared_and_separate_contexts(hip_ctx):
         th.join()
     other.close()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("kind", ["ortho", "tri", "npt", "one_species", "tiny_cells"])
+def test_rdf_cell_kernel_three_level_cell_list(hip_ctx, kind):
+    # cutoffs far below the cell size: the 3-D cell-list kernel (forced), against the other fast paths,
+    # the exact kernels and the oracle
+    if kind == "one_species":
+        packed = H.random_gas(3000, [40.0, 37.0, 45.0], np.full(3000, 8), 71, F=2)
+        cases = [(4.0, 400), (7.3, 73)]
+    elif kind == "tiny_cells":
+        packed = H.random_gas(900, [30.0, 30.0, 30.0], np.array([1, 8, 30] * 300), 72, F=3)
+        cases = [(1.2, 120), (5.9, 59)]
+    else:
+        base = H.replicate(H.zif4_frame(), (2, 2, 3))            # 3264 atoms, 30.8 x 30.8 x 55.3 A
+        packed = H.random_walk(base, 3, 0.08, 73, ortho=(kind != "tri"), cell_jitter=0.01 if kind == "npt" else 0.0)
+        cases = [(5.0, 500), (6.1, 2310)]
+    kinds, sp = H.species_of(packed.numbers)
+    for rmax, nb in cases:
+        with _env(AMOF_RDF_FORCE_CELL="1"):
+            got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        with _env(AMOF_RDF_NOCELL="1"):
+            other, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
+        assert np.array_equal(got, ref), (kind, rmax, nb, int(got.sum()), int(ref.sum()))
+        assert np.array_equal(other, ref)
+
+
+def test_rdf_cell_kernel_lattice_on_bin_edges(hip_ctx):
+    # integer lattice (atoms exactly on cell faces of the 3-D grid, every distance on a bin edge) in an
+    # integer sheared cell: the cell-list kernel must find every pair once and refine all of them exactly
+    n = 18
+    g = np.arange(n) * 1.0
+    pts = np.array([[x, y, z] for x in g for y in g for z in g])
+    cell = np.array([[18.0, 0, 0], [3.0, 18.0, 0], [-2.0, 4.0, 18.0]])
+    numbers = np.where((pts.sum(axis=1) % 2) == 0, 11, 17)           # rock-salt colouring
+    packed = PackedTrajectory(np.stack([pts, pts + 0.5, pts - 3.25]), cell, numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    for rmax, nb in [(3.0, 30), (3.0, 300), (2.0, 2), (3.5, 7)]:
+        with _env(AMOF_RDF_FORCE_CELL="1"):
+            got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, 2, rmax, nb, cell_list=True)
+        assert np.array_equal(got, ref), (rmax, nb)
