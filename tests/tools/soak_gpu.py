@@ -1,7 +1,7 @@
 """Randomized parity soak, run by hand on a GPU box (`python tests/tools/soak_gpu.py SECONDS`; not collected by pytest): many more seeds than tests/test_gpu_random.py,
 plus adversarial lattice cases where distances sit on bin edges / cutoffs."""
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from amof_amd import _hip

@@ -1,7 +1,7 @@
 """Randomized MSD parity soak (comb / generic / long-trajectory kernels, unwrap on/off, changing cells) against the
 numpy restatement.  Run by hand on a GPU box: `python tests/tools/soak_gpu_msd.py SECONDS` (not collected by pytest)."""
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from amof_amd import _hip
 from amof_amd.frames import PackedTrajectory

@@ -2,7 +2,7 @@
 range kernel, 1-D cell lists of CN/BAD): medium-size random systems against the C oracle's cell-list variant.
 Run by hand on a GPU box: `python tests/tools/soak_gpu_tiles.py SECONDS` (not collected by pytest)."""
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from amof_amd import _hip
 from amof_amd.frames import PackedTrajectory
