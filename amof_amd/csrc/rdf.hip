@@ -647,6 +647,9 @@ struct RdfCellArgs {
 };
 
 constexpr int CELL_THREADS = 256;
+#ifndef CELL_UNROLL
+#define CELL_UNROLL 8   // partners gathered per trip
+#endif
 constexpr uint32_t CELL_IDX_MASK = (1u << CELL_SPECIES_SHIFT) - 1u;
 
 template <bool ORTHO>
@@ -730,14 +733,14 @@ __global__ __launch_bounds__(CELL_THREADS) void rdf_cell_kernel(RdfCellArgs ca)
         for (int rs = 0; rs < 26; rs++) {
             {
                 const int j0 = js0[rs], j1 = js1[rs];
-                // four partners per trip, all loaded before any is evaluated (the gathers come from L2)
-                for (int j = j0; __any(j < j1); j += 4) {
-                    uint4 qv[4];
+                // several partners per trip, all loaded before any is evaluated (the gathers come from L2)
+                for (int j = j0; __any(j < j1); j += CELL_UNROLL) {
+                    uint4 qv[CELL_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < CELL_UNROLL; u++)
                         qv[u] = j < j1 ? *reinterpret_cast<const uint4 *>(Qf + min(j + u, j1 - 1)) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < CELL_UNROLL; u++) {
                         if (j + u < j1) {
                             const uint4 qj = qv[u];
                             const int ix = (int)(qj.x - own.ux), iy = (int)(qj.y - own.uy), iz = (int)(qj.z - own.uz);
