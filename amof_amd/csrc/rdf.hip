@@ -989,10 +989,12 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                         if (nk[big] <= 5) break;
                         nk[big]--;
                     }
-                    // visited share of all pairs: half shell of 5x5x5 cells (lane utilisation ~0.8) vs the slab list
+                    // visited share of all pairs: half shell of 5x5x5 cells (lane utilisation ~0.8) vs the slab list's
+                    // f1c / 2; a gathered pair costs ~1.8x a broadcast one and the sort is a fixed cost per frame
+                    // (crossovers measured with profiles/tools/sweep_cell.py)
                     const double f3 = 62.5 / ((double)nk[0] * nk[1] * nk[2]) / 0.8;
                     const double f1c = std::min(1.0, 2.0 * rmax / hmin[axis] + 2.0 / 256 + 0.02);
-                    if (!(f3 < 0.5 * f1c) && !getenv("AMOF_RDF_FORCE_CELL")) cell_ok = false;
+                    if (!(f3 < 0.28 * f1c && t->n_atoms >= 4000) && !getenv("AMOF_RDF_FORCE_CELL")) cell_ok = false;
                 }
                 if (cell_ok) {
                     const int nkeys = nk[0] * nk[1] * nk[2] * S;
