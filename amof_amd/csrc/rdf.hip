@@ -385,42 +385,46 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const unsigned cs = fa.xcd_map ? (chunk & 7u) * ((unsigned)fa.n_chunks >> 3) + (chunk >> 3) : chunk;
     const int f0 = (int)((long long)cs * fa.nf / fa.n_chunks);
     const int f1 = (int)((long long)(cs + 1) * fa.nf / fa.n_chunks);
-    // The four 128-atom centre sub-tiles of tile I are handled one after the other by the same
-    // workgroup: the LDS histogram is flushed once for all of them (4x fewer global atomics).
-    for (int sub = 0; sub * FAST_SUB < ti.count; sub++) {
-    __syncthreads();                                               // previous sub-tile fully consumed
-    // two adjacent centre atoms per lane (adjacent = close in slab order); same in every wave
-    const int cnti = min(FAST_SUB, ti.count - sub * FAST_SUB);     // centre atoms of this sub-tile
+    // The (up to four) 128-atom centre sub-tiles of tile I are handled by the same workgroup, frame by
+    // frame: a step is (frame, sub-tile); tile J of a frame is staged once and serves all its sub-tiles,
+    // and the LDS histogram is flushed once for everything.
+    const int nsub = (ti.count + FAST_SUB - 1) / FAST_SUB;
     const int la = 2 * lane, lb = la + 1;                          // local indices in the sub-tile
-    const int ia = sub * FAST_SUB + la, ib = ia + 1;               // indices in tile I
-    const bool has_a = la < cnti, has_b = lb < cnti;
     const float half_m_guard = fa.half_m_guard;
     const float nb_hi = fa.nb_hi;
     const int cntj = tj.count;
     const int cntj4 = (cntj + 3) & ~3;
     const int full = cntj & ~3;
 
-    // LDS-DMA of one frame's tiles into buffer b: wave w moves J entries [64w, 64w+64) and
-    // [256+64w, ...), waves 0/1 also move the centre sub-tile; indices are clamped (slots
-    // beyond the counts are never used unmasked)
-    auto stage = [&](int fl, int b) {
+    // LDS-DMA (1 KiB per wave instruction), indices clamped (slots beyond the counts are never used unmasked):
+    // tile J of frame fl into J buffer jb -- wave w moves entries [64w, 64w+64) and [256+64w, ...)
+    auto stage_j = [&](int fl, int jb) {
         const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
-        uint4 *tq = tqb + b * FAST_TILE, *tc = tcb + b * FAST_SUB;
+        uint4 *tq = tqb + jb * FAST_TILE;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const int k = r * 256 + wave * 64 + lane;
             if (r * 256 + wave * 64 < cntj4) dma_1k(Qf + tj.start + min(k, cntj - 1), tq + r * 256 + wave * 64);
         }
-        if (wave < 2 && wave * 64 < cnti)
-            dma_1k(Qf + ti.start + sub * FAST_SUB + min(wave * 64 + lane, cnti - 1), tc + wave * 64);
+    };
+    // centre sub-tile `sub` of frame fl into centre buffer cb -- waves 0/1
+    auto stage_c = [&](int fl, int sub, int cb) {
+        const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
+        const int cnt = min(FAST_SUB, ti.count - sub * FAST_SUB);
+        if (wave < 2 && wave * 64 < cnt)
+            dma_1k(Qf + ti.start + sub * FAST_SUB + min(wave * 64 + lane, cnt - 1), tcb + cb * FAST_SUB + wave * 64);
     };
 
-    if (f0 < f1) stage(f0, 0);
-    for (int fl = f0; fl < f1; fl++) {
-        const int b = (fl - f0) & 1;
+    const int nsteps = (f1 - f0) * nsub;
+    if (nsteps > 0) { stage_j(f0, 0); stage_c(f0, 0, 0); }
+    for (int step = 0, fl = f0, sub = 0; step < nsteps; step++) {
+        const int jb = (fl - f0) & 1, cbuf = step & 1;
+        const int cnti = min(FAST_SUB, ti.count - sub * FAST_SUB);     // centre atoms of this sub-tile
+        const int ia = sub * FAST_SUB + la, ib = ia + 1;               // indices in tile I
+        const bool has_a = la < cnti, has_b = lb < cnti;
         const int f = fa.f_base + fl;
         const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
-        const uint4 *tq = tqb + b * FAST_TILE, *tc = tcb + b * FAST_SUB;
+        const uint4 *tq = tqb + jb * FAST_TILE, *tc = tcb + cbuf * FAST_SUB;
         const int gi = a.n_cells == 1 ? 0 : f;
         const FrameScale *__restrict__ fs = fa.fs + gi;
         const double *__restrict__ g = a.geom + (size_t)gi * GEOM_STRIDE;
@@ -428,9 +432,15 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
 #pragma unroll
         for (int k = 0; k < 9; k++)
             sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for frame fl has landed
-        __syncthreads();                                    // everyone's has; frame fl-1 is fully consumed
-        if (fl + 1 < f1) stage(fl + 1, b ^ 1);              // next frame streams in behind the arithmetic
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for this step has landed
+        __syncthreads();                                    // everyone's has; the previous step is fully consumed
+        // what the next step needs streams in behind the arithmetic
+        {
+            const int nsub_next = sub + 1 < nsub ? sub + 1 : 0;
+            const int fl_next = sub + 1 < nsub ? fl : fl + 1;
+            if (step + 1 < nsteps) stage_c(fl_next, nsub_next, cbuf ^ 1);
+            if (sub == 0 && fl + 1 < f1) stage_j(fl + 1, jb ^ 1);   // (buffer jb^1: frame fl-1, consumed before this barrier)
+        }
         const uint4 ca = tc[min(la, cnti - 1)], cb = tc[min(lb, cnti - 1)];
         const uint32_t uax = ca.x, uay = ca.y, uaz = ca.z, ida = ca.w;
         const uint32_t ubx = cb.x, uby = cb.y, ubz = cb.z, idb = cb.w;
@@ -492,8 +502,8 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                                                   nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
             }
         }
+        if (++sub == nsub) { sub = 0; fl++; }
     }
-    }   // sub-tiles
     __syncthreads();
     unsigned long long *U = a.U + ((size_t)ti.species * a.S + tj.species) * (size_t)nbins;
     for (int k = tid; k < nbins; k += FAST_THREADS) {
