@@ -656,14 +656,14 @@ struct RdfCellArgs {
     int32_t cpt;              // centre atoms per thread (the workgroup covers 256 * cpt consecutive atoms)
 };
 
-constexpr int CELL_THREADS = 256;
+constexpr int CELL_THREADS = 512;
 #ifndef CELL_UNROLL
-#define CELL_UNROLL 8   // partners gathered per trip
+#define CELL_UNROLL 4   // partners gathered per trip
 #endif
 constexpr uint32_t CELL_IDX_MASK = (1u << CELL_SPECIES_SHIFT) - 1u;
 
 template <bool ORTHO>
-__global__ __launch_bounds__(CELL_THREADS) void rdf_cell_kernel(RdfCellArgs ca)
+__global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs ca)
 {
     const RdfFastArgs &fa = ca.f;
     const RdfArgs &a = fa.a;
@@ -707,10 +707,7 @@ __global__ __launch_bounds__(CELL_THREADS) void rdf_cell_kernel(RdfCellArgs ca)
         const uint32_t ida = own.idx & CELL_IDX_MASK;
         const int cx = (int)__umulhi(own.ux, (unsigned)nx), cy = (int)__umulhi(own.uy, (unsigned)ny),
                   cz = (int)__umulhi(own.uz, (unsigned)nz);
-        // the (at most) 26 partner index ranges of this centre, all looked up before any pair work
-        // (the table lookups are dependent global loads: issued together they cost one latency, not 26)
-        int js0[26], js1[26];
-#pragma unroll
+#pragma unroll 1
         for (int row = 0; row < 13; row++) {
             // rows of the positive half shell
             const int dz = row < 3 ? 0 : (row < 8 ? 1 : 2);
@@ -726,23 +723,20 @@ __global__ __launch_bounds__(CELL_THREADS) void rdf_cell_kernel(RdfCellArgs ca)
             if (xlo < 0) { xa0 = xlo + nx; xb0 = nx - 1; xa1 = 0; xb1 = xhi; }
             else if (xhi >= nx) { xa0 = xlo; xb0 = nx - 1; xa1 = 0; xb1 = xhi - nx; }
             else { xa0 = xlo; xb0 = xhi; }
-#pragma unroll
-            for (int seg = 0; seg < 2; seg++) {
-                const int xa = seg == 0 ? xa0 : xa1, xb = seg == 0 ? xb0 : xb1;
-                int j0 = 0, j1 = 0;
-                if (active && xa <= xb) {
-                    j0 = (int)st[(size_t)(rowbase + xa) * S];
-                    j1 = (int)st[(size_t)(rowbase + xb + 1) * S];
-                    if (row == 0 && seg == 0) j0 = i + 1;     // own cell: the partners after me
+            // both runs are looked up before either is walked (dependent global loads)
+            int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0;
+            if (active) {
+                ja0 = (int)st[(size_t)(rowbase + xa0) * S];
+                ja1 = (int)st[(size_t)(rowbase + xb0 + 1) * S];
+                if (row == 0) ja0 = i + 1;                    // own cell: the partners after me
+                if (xa1 <= xb1) {
+                    jb0 = (int)st[(size_t)(rowbase + xa1) * S];
+                    jb1 = (int)st[(size_t)(rowbase + xb1 + 1) * S];
                 }
-                js0[2 * row + seg] = j0;
-                js1[2 * row + seg] = j1;
             }
-        }
 #pragma unroll 1
-        for (int rs = 0; rs < 26; rs++) {
-            {
-                const int j0 = js0[rs], j1 = js1[rs];
+            for (int seg = 0; seg < 2; seg++) {
+                const int j0 = seg == 0 ? ja0 : jb0, j1 = seg == 0 ? ja1 : jb1;
                 // several partners per trip, all loaded before any is evaluated (the gathers come from L2)
                 for (int j = j0; __any(j < j1); j += CELL_UNROLL) {
                     uint4 qv[CELL_UNROLL];
@@ -1004,7 +998,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     // (crossovers measured with profiles/tools/sweep_cell.py)
                     const double f3 = 62.5 / ((double)nk[0] * nk[1] * nk[2]) / 0.8;
                     const double f1c = std::min(1.0, 2.0 * rmax / hmin[axis] + 2.0 / 256 + 0.02);
-                    if (!(f3 < 0.28 * f1c && t->n_atoms >= 4000) && !getenv("AMOF_RDF_FORCE_CELL")) cell_ok = false;
+                    if (!(f3 < 0.32 * f1c && t->n_atoms >= 4000) && !getenv("AMOF_RDF_FORCE_CELL")) cell_ok = false;
                 }
                 if (cell_ok) {
                     const int nkeys = nk[0] * nk[1] * nk[2] * S;
@@ -1056,7 +1050,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     ca.keyU = (const uint32_t *)d_ktab + (size_t)S * S;
                     ca.nx = nk[0]; ca.ny = nk[1]; ca.nz = nk[2];
                     ca.npk = npk;
-                    ca.cpt = t->n_atoms >= 4096 ? 2 : 1;
+                    ca.cpt = 1;
                     const unsigned gx = (unsigned)((t->n_atoms + (int64_t)CELL_THREADS * ca.cpt - 1) / ((int64_t)CELL_THREADS * ca.cpt));
                     int64_t launches = 0;
                     for (int64_t fb = 0; fb < t->n_frames; fb += FB3) {
