@@ -33,7 +33,9 @@ __device__ __forceinline__ QAtom quantize_atom(const double *__restrict__ pos, c
 // `axis` (order inside a slab is arbitrary -- every result downstream is an integer count,
 // independent of the order).  slab_start (optional) [nf][S][SLABS+1]: offset, relative to
 // the species segment, of the first atom of every slab.
-__global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict__ pos,
+constexpr int QUANT_THREADS = 1024;
+
+__global__ __launch_bounds__(QUANT_THREADS) void quantize_kernel(const double *__restrict__ pos,
                                                        const double *__restrict__ geom, int n_cells,
                                                        const int32_t *__restrict__ perm,
                                                        const int64_t *__restrict__ sp_first, int S, int64_t N,
@@ -52,36 +54,38 @@ __global__ __launch_bounds__(256) void quantize_kernel(const double *__restrict_
     const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
     const int64_t k0 = sp_first[sp], k1 = sp_first[sp + 1];
     const bool cached = k1 - k0 <= (int64_t)cache_cap;
-    cnt[tid] = 0u;
+    if (tid < QSLABS) cnt[tid] = 0u;
     __syncthreads();
-    for (int64_t k = k0 + tid; k < k1; k += 256) {
+    for (int64_t k = k0 + tid; k < k1; k += QUANT_THREADS) {
         const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
         if (cached) cache[k - k0] = q;
         atomicAdd(&cnt[q.uz >> 24], 1u);
     }
     __syncthreads();
-    // exclusive scan of the 256 counters (one per thread)
-    unsigned v = cnt[tid], incl = v;
+    // exclusive scan of the 256 counters (one per thread of the first four waves)
+    unsigned v = tid < QSLABS ? cnt[tid] : 0u, incl = v;
     const int lane = tid & 63, wv = tid >> 6;
     for (int off = 1; off < 64; off <<= 1) {
         unsigned n = __shfl_up(incl, off, 64);
         if (lane >= off) incl += n;
     }
-    if (lane == 63) wsum[wv] = incl;
+    if (lane == 63 && wv < 4) wsum[wv] = incl;
     __syncthreads();
     unsigned base = 0;
-    for (int w = 0; w < wv; w++) base += wsum[w];
+    for (int w = 0; w < wv && w < 4; w++) base += wsum[w];
     __syncthreads();
     const unsigned excl = base + incl - v;
-    cnt[tid] = excl;
-    if (slab_start) {
-        uint32_t *st = slab_start + ((size_t)fl * S + sp) * (QSLABS + 1);
-        st[tid] = excl;
-        if (tid == 255) st[QSLABS] = excl + v;
+    if (tid < QSLABS) {
+        cnt[tid] = excl;
+        if (slab_start) {
+            uint32_t *st = slab_start + ((size_t)fl * S + sp) * (QSLABS + 1);
+            st[tid] = excl;
+            if (tid == QSLABS - 1) st[QSLABS] = excl + v;
+        }
     }
     __syncthreads();
     QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
-    for (int64_t k = k0 + tid; k < k1; k += 256) {
+    for (int64_t k = k0 + tid; k < k1; k += QUANT_THREADS) {
         const QAtom q = cached ? cache[k - k0] : quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
         const unsigned slot = atomicAdd(&cnt[q.uz >> 24], 1u);
         Qf[slot] = q;
@@ -265,7 +269,7 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
     const int cache_cap = (int)std::min<int64_t>(N, 4608);
     const size_t lds = (size_t)cache_cap * sizeof(QAtom);
     AMOF_HIP_TRY(ctx, allow_max_lds((const void *)quantize_kernel));
-    hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(256), lds, ctx->stream, pos_dev, d_geom, n_cells, d_perm, d_spfirst,
+    hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(QUANT_THREADS), lds, ctx->stream, pos_dev, d_geom, n_cells, d_perm, d_spfirst,
                        S, N, f0, axis, d_Q, d_slab_start, d_flag, cache_cap);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     return AMOF_OK;
