@@ -59,3 +59,33 @@ def test_two_ranks_equal_single_process(tmp_path):
                 np.testing.assert_allclose(got.values, df.values, rtol=1e-12, atol=1e-15)
             else:               # built from merged integer counts: identical
                 assert np.array_equal(got.values, df.values), k
+
+
+def _worker_rccl(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    for mode in (None, "local"):
+        res = _run_all(_build(), mode)
+        for k, df in res.items():
+            df.to_pickle(os.path.join(out_dir, "%s_%s.pkl" % (k, mode)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank(tmp_path):
+    # the code path the 8-GPU bench takes (backend "nccl" = RCCL: CUDA-tensor all-reduce, object
+    # all-gather), with the one rank a single-GPU box allows
+    import pandas as pd
+    port = 31600 + os.getpid() % 2000
+    mp.spawn(_worker_rccl, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    single = _run_all(_build(), False)
+    for k, df in single.items():
+        for mode in ("None", "local"):
+            got = pd.read_pickle(os.path.join(str(tmp_path), "%s_%s.pkl" % (k, mode)))
+            assert list(got.columns) == list(df.columns), k
+            np.testing.assert_allclose(got.values, df.values, rtol=1e-12, atol=1e-15)
