@@ -29,6 +29,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_destroy", "amof_last_error",
     "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_last_kernel_seconds", "amof_last_kernel_launches",
+    "amof_last_path",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_bad_hist_by_cn",
     "amof_msd_window", "amof_msd_direct",
@@ -95,6 +96,8 @@ def load_library():
         lib.amof_last_kernel_seconds.restype = ctypes.c_double
         lib.amof_last_kernel_launches.argtypes = [P]
         lib.amof_last_kernel_launches.restype = ctypes.c_int64
+        lib.amof_last_path.argtypes = [P]
+        lib.amof_last_path.restype = ctypes.c_char_p
         TP = ctypes.POINTER(AmofTraj)
         lib.amof_rdf_accumulate.argtypes = [P, TP, ctypes.c_double, ctypes.c_int32, P, ctypes.POINTER(ctypes.c_double)]
         lib.amof_rdf_accumulate_dev.argtypes = lib.amof_rdf_accumulate.argtypes
@@ -241,6 +244,11 @@ class Context(object):
     @_locked
     def last_kernel_seconds(self, dominant=True):
         return self._lib.amof_last_kernel_seconds(self._h, 1 if dominant else 0)
+
+    @_locked
+    def last_path(self):
+        """Kernel family that produced the last result ("rdf_tile", "rdf_cell", "cn_fast", "msd_comb", ...)."""
+        return self._lib.amof_last_path(self._h).decode()
 
     @_locked
     def last_kernel_launches(self):

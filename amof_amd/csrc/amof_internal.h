@@ -58,6 +58,7 @@ struct amof_ctx {
     bool ev_valid = false;
     int64_t dom_launches = 0;
     std::string err;
+    const char *last_path = "";   // kernel family of the last dominant launch (static strings)
     amof::DevBuf buf[amof::SLOT_COUNT];
 };
 
@@ -206,7 +207,7 @@ int launch_cell_sort(amof_ctx *ctx, const double *pos_dev, const double *d_geom,
 
 void timing_begin(amof_ctx *ctx);
 void timing_end(amof_ctx *ctx);
-void timing_dom_begin(amof_ctx *ctx);
+void timing_dom_begin(amof_ctx *ctx, const char *path);
 void timing_dom_end(amof_ctx *ctx, int64_t launches);
 
 // ------------------------------------------------------- device arithmetic --

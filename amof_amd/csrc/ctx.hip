@@ -113,7 +113,11 @@ void timing_end(amof_ctx *ctx)
     (void)hipEventRecord(ctx->ev_all1, ctx->stream);
     ctx->ev_valid = true;
 }
-void timing_dom_begin(amof_ctx *ctx) { (void)hipEventRecord(ctx->ev_dom0, ctx->stream); }
+void timing_dom_begin(amof_ctx *ctx, const char *path)
+{
+    ctx->last_path = path;
+    (void)hipEventRecord(ctx->ev_dom0, ctx->stream);
+}
 void timing_dom_end(amof_ctx *ctx, int64_t launches)
 {
     (void)hipEventRecord(ctx->ev_dom1, ctx->stream);
@@ -366,5 +370,6 @@ double amof_last_kernel_seconds(const amof_ctx *ctx, int which)
 }
 
 int64_t amof_last_kernel_launches(const amof_ctx *ctx) { return ctx ? ctx->dom_launches : 0; }
+const char *amof_last_path(const amof_ctx *ctx) { return ctx ? ctx->last_path : ""; }
 
 }  // extern "C"

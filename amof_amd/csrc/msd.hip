@@ -601,7 +601,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
                            (const double *)d_geom, (int)t->n_cells, N, Fp, (int)F, (double *)d_DT);
     }
     AMOF_HIP_TRY(ctx, hipGetLastError());
-    timing_dom_begin(ctx);
+    timing_dom_begin(ctx, "msd_global");
     if (lds_resident) {
         auto launch = [&](auto kern) -> hipError_t {
             hipError_t e = allow_max_lds((const void *)kern);
@@ -627,6 +627,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
                                comb_d, (int)W, (double *)d_part);
             return hipGetLastError();
         };
+        ctx->last_path = comb_d > 0 ? "msd_comb" : "msd_group";
         hipError_t e;
         if (comb_d > 0 && W <= 4) e = launch_comb(msd_comb_kernel<4>);
         else if (comb_d > 0 && W <= 8) e = launch_comb(msd_comb_kernel<8>);
@@ -688,7 +689,7 @@ extern "C" int amof_msd_direct(amof_ctx *ctx, const amof_traj *t, double *msd)
     AMOF_TRY(ensure(ctx, SLOT_AUX3, (size_t)F * 3 * N * sizeof(double), &d_sq));
     AMOF_TRY(ensure(ctx, SLOT_OUT0, (size_t)F * (S + 1) * sizeof(double), &d_out));
     if (N > 0) {
-        timing_dom_begin(ctx);
+        timing_dom_begin(ctx, "msd_direct");
         hipLaunchKernelGGL(direct_walk_kernel, dim3((unsigned)((3 * N + 255) / 256)), dim3(256), 0, ctx->stream, pos_dev,
                            (const double *)d_cell, (int)t->n_cells, N, (int)F, (double *)d_sq);
         timing_dom_end(ctx, 1);

@@ -764,7 +764,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
             unsigned chunks;
             pick_chunks(nfr, fwork.size(), nf.fa.a.frames_per_chunk, chunks);
             dim3 grid((unsigned)fwork.size(), chunks);
-            if (launches == 0) timing_dom_begin(ctx);
+            if (launches == 0) timing_dom_begin(ctx, "cn_fast");
             if (nf.ortho) hipLaunchKernelGGL(cn_fast_kernel<true>, grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
             else hipLaunchKernelGGL(cn_fast_kernel<false>, grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
             AMOF_HIP_TRY(ctx, hipGetLastError());
@@ -786,7 +786,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
         dim3 grid((unsigned)work.size(), chunks);
         const bool extra = st.max_img > 0, ortho = st.geom.all_ortho;
-        timing_dom_begin(ctx);
+        timing_dom_begin(ctx, "cn_exact");
         if (ortho && !extra) hipLaunchKernelGGL((cn_kernel<true, false>), grid, dim3(CN_TILE), 0, ctx->stream, a);
         else if (ortho && extra) hipLaunchKernelGGL((cn_kernel<true, true>), grid, dim3(CN_TILE), 0, ctx->stream, a);
         else if (!ortho && !extra) hipLaunchKernelGGL((cn_kernel<false, false>), grid, dim3(CN_TILE), 0, ctx->stream, a);
@@ -866,7 +866,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             unsigned chunks;
             pick_chunks(nfr, fwork.size(), nf.fa.a.frames_per_chunk, chunks);
             dim3 grid((unsigned)fwork.size(), chunks);
-            if (launches == 0) timing_dom_begin(ctx);
+            if (launches == 0) timing_dom_begin(ctx, "bad_fast");
             hipError_t e;
             if (nf.ortho) {
                 e = allow_max_lds((const void *)bad_fast_kernel<true>);
@@ -908,7 +908,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             hipLaunchKernelGGL(kern, grid, dim3(BAD_TILE), lds, ctx->stream, a);
             return hipGetLastError();
         };
-        timing_dom_begin(ctx);
+        timing_dom_begin(ctx, "bad_exact");
         hipError_t e;
         if (ortho && !extra) e = launch(bad_kernel<true, false>);
         else if (ortho && extra) e = launch(bad_kernel<true, true>);

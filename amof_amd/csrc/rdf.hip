@@ -1064,7 +1064,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                         ca.f.xcd_map = nf >= 16 ? 1 : 0;
                         ca.frames_grid = (int32_t)(ca.f.xcd_map ? (nf + 7) / 8 * 8 : nf);
                         dim3 grid(gx, (unsigned)ca.frames_grid);
-                        if (launches == 0) timing_dom_begin(ctx);
+                        if (launches == 0) timing_dom_begin(ctx, "rdf_cell");
                         hipError_t e = ortho ? allow_max_lds((const void *)rdf_cell_kernel<true>)
                                              : allow_max_lds((const void *)rdf_cell_kernel<false>);
                         AMOF_HIP_TRY(ctx, e);
@@ -1157,7 +1157,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     int64_t chunks = (nf + fpc - 1) / fpc;
                     ra.f.a.frames_per_chunk = (int32_t)fpc;
                     dim3 grid((unsigned)rwork.size(), (unsigned)chunks);
-                    if (launches == 0) timing_dom_begin(ctx);
+                    if (launches == 0) timing_dom_begin(ctx, "rdf_range");
                     hipError_t e;
                     if (ortho) {
                         e = allow_max_lds((const void *)rdf_range_kernel_fast<true>);
@@ -1210,7 +1210,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.a.frames_per_chunk = (int32_t)fpc;
                 fa.n_chunks = (int32_t)chunks;
                 dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
-                if (launches == 0) timing_dom_begin(ctx);
+                if (launches == 0) timing_dom_begin(ctx, "rdf_tile");
                 auto launch = [&](auto kern) -> hipError_t {
                     hipError_t e2 = allow_max_lds((const void *)kern);
                     if (e2 != hipSuccess) return e2;
@@ -1243,7 +1243,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         unsigned chunks;
         pick_chunks(t->n_frames, a.frames_per_chunk, chunks);
         dim3 grid((unsigned)pairs.size(), chunks);
-        timing_dom_begin(ctx);
+        timing_dom_begin(ctx, "rdf_exact");
         if (nbins <= AMOF_MAX_LDS_BINS) {
             size_t lds = 3 * RDF_TILE * sizeof(double) + (size_t)nbins * sizeof(unsigned);
             auto launch = [&](auto kern) -> hipError_t {

@@ -27,6 +27,7 @@ def test_cfg5_100k_triclinic_rdf(hip_ctx):
     ref, vol = clib.rdf_hist(packed.pos[:1], packed.cell, sp, 4, 10.0, 999, cell_list=True)
     one, _, _ = hip_ctx.rdf_accumulate(packed, 10.0, 999, frame_range=(0, 1))
     assert np.array_equal(one, ref)
+    assert hip_ctx.last_path() == "rdf_cell"                        # the 3-D cell-list kernel serves this config
     t0 = time.perf_counter()
     hip_ctx.rdf_accumulate(packed, 10.0, 999)
     dt = time.perf_counter() - t0

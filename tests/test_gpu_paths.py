@@ -44,11 +44,15 @@ def _traj(kind):
 @pytest.mark.parametrize("kind", ["elongated", "elongated_tri", "npt", "cubicish"])
 def test_rdf_fast_equals_exact_equals_oracle(hip_ctx, kind):
     packed, rmax, nb = _traj(kind)
-    fast, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-    with _env(AMOF_RDF_NOCULL="1"):
-        nocull, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+    with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
+        fast, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        assert hip_ctx.last_path() == "rdf_tile"
+        with _env(AMOF_RDF_NOCULL="1"):
+            nocull, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_tile"
     with _env(AMOF_RDF_KERNEL="v1"):
         exact, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        assert hip_ctx.last_path() == "rdf_exact"
     kinds, sp = H.species_of(packed.numbers)
     ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
     assert np.array_equal(fast, ref) and np.array_equal(nocull, ref) and np.array_equal(exact, ref)
@@ -102,10 +106,14 @@ def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
     triples = [(zn, n), (n, -1), (-1, -1), (c, c), (c, -1)]
     edges = np.arange(int(180 // 0.5) + 2) * 0.5
     s_fast, pa_fast = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+    assert hip_ctx.last_path() == "cn_fast"
     h_fast, a_fast = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_fast"
     with _env(AMOF_NBR_KERNEL="v1"):
         s_ex, pa_ex = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+        assert hip_ctx.last_path() == "cn_exact"
         h_ex, a_ex = hip_ctx.bad_hist(packed, rcm, triples, edges)
+        assert hip_ctx.last_path() == "bad_exact"
     s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
     h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
     assert np.array_equal(s_fast, s_ref) and np.array_equal(pa_fast, pa_ref)
@@ -137,6 +145,7 @@ def test_far_away_atoms_fall_back(hip_ctx):
     far = PackedTrajectory(packed.pos + np.array([2.0e5 * packed.cell[0, 0, 0], 0, 0]), packed.cell, packed.numbers)
     kinds, sp = H.species_of(packed.numbers)
     h, _, _ = hip_ctx.rdf_accumulate(far, 6.0, 60)
+    assert hip_ctx.last_path() == "rdf_exact"
     ref, _ = clib.rdf_hist(far.pos, far.cell, sp, len(kinds), 6.0, 60)
     assert np.array_equal(h, ref)
     rcm = np.zeros((4, 4)); rcm[2, 3] = rcm[3, 2] = 2.5
@@ -203,17 +212,20 @@ def test_rdf_range_kernel_two_level_cell_list(hip_ctx, tri):
     packed = H.random_walk(base, 3, 0.08, 61, ortho=not tri)
     kinds, sp = H.species_of(packed.numbers)
     for rmax, nb in [(5.0, 500), (9.5, 333)]:
-        with _env(AMOF_RDF_FORCE_RANGE="1"):
+        with _env(AMOF_RDF_FORCE_RANGE="1", AMOF_RDF_NOCELL="1"):
             got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-        with _env(AMOF_RDF_NORANGE="1"):
+            assert hip_ctx.last_path() == "rdf_range"
+        with _env(AMOF_RDF_NORANGE="1", AMOF_RDF_NOCELL="1"):
             slab, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_tile"
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
         assert np.array_equal(got, ref) and np.array_equal(slab, ref)
     # exactly three slabs (nz = 3): the forward-slab rule must not double count across the wrap
-    small = H.random_walk(H.replicate(H.zif4_frame(), (1, 1, 2)), 2, 0.05, 62, ortho=not tri)
+    small = H.random_walk(H.replicate(H.zif4_frame(), (2, 2, 2)), 2, 0.05, 62, ortho=not tri)   # 30.8 x 30.8 x 36.9 A
     for rmax, nb in [(5.0, 250), (12.0, 240), (12.29, 1229)]:        # nz = 7, 3, 3
-        with _env(AMOF_RDF_FORCE_RANGE="1"):
+        with _env(AMOF_RDF_FORCE_RANGE="1", AMOF_RDF_NOCELL="1"):
             got, _, _ = hip_ctx.rdf_accumulate(small, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_range"
         ref, _ = clib.rdf_hist(small.pos, small.cell, H.species_of(small.numbers)[1], 4, rmax, nb)
         assert np.array_equal(got, ref), rmax
 
@@ -258,8 +270,10 @@ def test_msd_comb_kernel_equals_generic_and_oracle(hip_ctx, F, d, W):
     packed = PackedTrajectory((s - np.floor(s)) @ cell, cell, [1, 1, 1, 1, 8, 8, 30, 30, 30])
     window = np.array([w * d for w in range(W) if w * d < F], dtype=np.int32)
     comb, kinds = hip_ctx.msd_window(packed, window)
+    assert hip_ctx.last_path() == ("msd_comb" if len(window) >= 2 else "msd_group")
     with _env(AMOF_MSD_NOCOMB="1"):
         generic, _ = hip_ctx.msd_window(packed, window)
+        assert hip_ctx.last_path() == "msd_group"
     np.testing.assert_allclose(comb, generic, rtol=1e-12, atol=1e-12)
     elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window)
     for e, r in zip(elements, ref):
@@ -315,8 +329,10 @@ def test_rdf_cell_kernel_three_level_cell_list(hip_ctx, kind):
     for rmax, nb in cases:
         with _env(AMOF_RDF_FORCE_CELL="1"):
             got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_cell"
         with _env(AMOF_RDF_NOCELL="1"):
             other, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() in ("rdf_tile", "rdf_range")
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
         assert np.array_equal(got, ref), (kind, rmax, nb, int(got.sum()), int(ref.sum()))
         assert np.array_equal(other, ref)
@@ -335,5 +351,6 @@ def test_rdf_cell_kernel_lattice_on_bin_edges(hip_ctx):
     for rmax, nb in [(3.0, 30), (3.0, 300), (2.0, 2), (3.5, 7)]:
         with _env(AMOF_RDF_FORCE_CELL="1"):
             got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_cell"
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, 2, rmax, nb, cell_list=True)
         assert np.array_equal(got, ref), (rmax, nb)
