@@ -13,6 +13,14 @@ from tests.test_gpu_random import _case
 ctx = _hip.get_context(0)
 t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 240
 bad = 0
+paths = {}
+
+
+def _note():
+    k = ctx.last_path()
+    paths[k] = paths.get(k, 0) + 1
+
+
 n = 0
 seed = 1000
 while time.time() < t_end:
@@ -45,6 +53,7 @@ while time.time() < t_end:
     nb = int(rng.choice([int(rmax * k) for k in (1, 2, 4, 10, 100)] + [333]))
     nb = max(nb, 1)
     h, _, _ = ctx.rdf_accumulate(lat, rmax, nb)
+    _note()
     ref, _ = clib.rdf_hist(lat.pos, lat.cell, sp, len(kinds), rmax, nb)
     n += 1
     if not np.array_equal(h, ref):
@@ -55,6 +64,7 @@ while time.time() < t_end:
     sets = [(a, b) for a in range(len(kinds)) for b in range(len(kinds))]
     if rc < hmin / 2:
         s1 = ctx.cn_count(lat, rcm, sets)
+        _note()
         s2 = clib.cn_counts(lat.pos, lat.cell, sp, len(kinds), rcm, sets)
         n += 1
         if not np.array_equal(s1, s2):
@@ -62,4 +72,5 @@ while time.time() < t_end:
             print("LATTICE CN MISMATCH seed", seed, rc, flush=True)
     if n % 200 < 3:
         print("progress: %d comparisons, %d mismatches" % (n, bad), flush=True)
+print("kernel families exercised:", dict(sorted(paths.items())))
 print("SOAK DONE: %d comparisons, %d mismatches" % (n, bad))

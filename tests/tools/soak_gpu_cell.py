@@ -12,6 +12,14 @@ from tests import helpers as H
 ctx = _hip.get_context(0)
 t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 180)
 bad = n = 0
+paths = {}
+
+
+def _note():
+    k = ctx.last_path()
+    paths[k] = paths.get(k, 0) + 1
+
+
 seed = 20000
 while time.time() < t_end:
     seed += 1
@@ -41,6 +49,7 @@ while time.time() < t_end:
     rmax = float(hmin * rng.uniform(0.02, 0.39))
     nb = int(rng.choice([1, 13, 400, 999, 2000]))
     h, _, _ = ctx.rdf_accumulate(packed, rmax, nb)
+    _note()
     ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds_s), rmax, nb, cell_list=True)
     n += 1
     if not np.array_equal(h, ref):
@@ -48,4 +57,5 @@ while time.time() < t_end:
         print("CELL RDF MISMATCH seed", seed, N, F, S, rmax, nb, flush=True)
     if n % 100 == 0:
         print("progress: %d comparisons, %d mismatches" % (n, bad), flush=True)
+print("kernel families exercised:", dict(sorted(paths.items())))
 print("SOAK DONE: %d comparisons, %d mismatches" % (n, bad))

@@ -10,6 +10,14 @@ from oracle import numpy_oracle as no
 ctx = _hip.get_context(0)
 t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 120)
 bad = n = 0
+paths = {}
+
+
+def _note():
+    k = ctx.last_path()
+    paths[k] = paths.get(k, 0) + 1
+
+
 seed = 9000
 worst = 0.0
 while time.time() < t_end:
@@ -41,6 +49,7 @@ while time.time() < t_end:
     window = window.astype(np.int32)
     unwrap = bool(seed % 7 == 0)
     sumsq, kinds = ctx.msd_window(packed, window, unwrap=unwrap)
+    _note()
     elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window, unwrap=unwrap)
     for e, r in zip(elements, ref):
         got = sumsq[kinds.index(int(e))] / (packed.numbers == e).sum() / (F - window)
@@ -52,4 +61,5 @@ while time.time() < t_end:
             print("MSD MISMATCH seed", seed, F, N, len(window), unwrap, float(err), flush=True)
     if n % 300 < 3:
         print("progress: %d comparisons, %d mismatches, worst relative error %.2e" % (n, bad, worst), flush=True)
+print("kernel families exercised:", dict(sorted(paths.items())))
 print("SOAK DONE: %d comparisons, %d mismatches, worst relative error %.2e" % (n, bad, worst))

@@ -12,6 +12,14 @@ from tests import helpers as H
 ctx = _hip.get_context(0)
 t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 240)
 bad = n = 0
+paths = {}
+
+
+def _note():
+    k = ctx.last_path()
+    paths[k] = paths.get(k, 0) + 1
+
+
 seed = 5000
 while time.time() < t_end:
     seed += 1
@@ -37,6 +45,7 @@ while time.time() < t_end:
     rmax = min(rmax, 14.0)
     nb = int(rng.choice([50, 700, 2310, 5000]))
     h, _, _ = ctx.rdf_accumulate(packed, rmax, nb)
+    _note()
     ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds_s), rmax, nb, cell_list=True)
     n += 1
     if not np.array_equal(h, ref):
@@ -46,6 +55,7 @@ while time.time() < t_end:
     rcm = np.maximum(rcm, rcm.T)
     sets = [(a, b) for a in range(len(kinds_s)) for b in range(len(kinds_s))]
     s1 = ctx.cn_count(packed, rcm, sets)
+    _note()
     s2 = clib.cn_counts(packed.pos, packed.cell, sp, len(kinds_s), rcm, sets)
     n += 1
     if not np.array_equal(s1, s2):
@@ -57,6 +67,7 @@ while time.time() < t_end:
         try:
             hr, ar = clib.bad_hist(packed.pos, packed.cell, sp, len(kinds_s), rcm, triples, edges)
             hg, ag = ctx.bad_hist(packed, rcm, triples, edges)
+            _note()
             n += 1
             if not (np.array_equal(hr, hg) and np.array_equal(ar, ag)):
                 bad += 1
@@ -64,4 +75,5 @@ while time.time() < t_end:
         except (ZeroDivisionError, _hip.AmofError) as exc:
             print("skip BAD seed", seed, type(exc).__name__, flush=True)
     print("progress: %d comparisons, %d mismatches (seed %d, N=%d)" % (n, bad, seed, N), flush=True)
+print("kernel families exercised:", dict(sorted(paths.items())))
 print("SOAK DONE: %d comparisons, %d mismatches" % (n, bad))
