@@ -90,6 +90,7 @@ def test_many_bins_uses_global_histogram_path(hip_ctx):
     packed = H.random_walk(H.zif4_frame(), 2, 0.05, 9)
     nb = _hip.load_library() and 40000                     # > AMOF_MAX_LDS_BINS
     h, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, nb)
+    assert hip_ctx.last_path() == "rdf_exact"               # (the global-histogram variant of the exact kernels)
     assert np.array_equal(h, _oracle_rdf(packed, 7.0, nb))
 
 
@@ -189,6 +190,7 @@ def test_msd_long_trajectory_uses_global_path(hip_ctx):
     window = np.array([0, 1, 7, 500, 9999, 20000, 20999], dtype=np.int32)
     for unwrap in (False, True):
         sumsq, kinds = hip_ctx.msd_window(packed, window, unwrap=unwrap)
+        assert hip_ctx.last_path() == "msd_global"
         elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window, unwrap=unwrap)
         for e, r in zip(elements, ref):
             got = sumsq[kinds.index(int(e))] / (packed.numbers == e).sum() / (F - window)
