@@ -355,12 +355,138 @@ class Context(object):
         return out, th.kinds
 
 
+class MultiContext(object):
+    """Several GPUs from ONE process: a :class:`Context` per device, a thread per context (ctypes
+    drops the GIL during the calls).  Frames are sharded for RDF / CN / BAD, atoms for MSD; integer
+    results are summed on the host, so they equal the single-GPU ones bit for bit.  The usual
+    multi-GPU route stays one process per GPU with torch.distributed (amof_amd.dist); this is the
+    convenience for scripts that are not launched with torchrun.  A device may be listed twice
+    (two contexts with their own streams on one GPU)."""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise ValueError("empty device list")
+        self.ctxs = [Context(d) for d in self.devices]
+        self.device = self.devices[0]
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+
+    def _shards(self, lo, hi):
+        from . import dist as _d
+        n = len(self.ctxs)
+        return [tuple(x + lo for x in _d.shard_range(hi - lo, k, n)) for k in range(n)]
+
+    @staticmethod
+    def _for_device(packed, ctx, frame_range=None):
+        """The trajectory as device ``ctx.device`` can read it: host arrays as they are, a CUDA tensor on
+        another device copied over (the needed frames only)."""
+        if not packed.on_device or packed.pos.device.index == ctx.device:
+            return packed, frame_range
+        import torch
+        f0, f1 = (0, packed.n_frames) if frame_range is None else frame_range
+        pos = packed.pos[f0:f1].to(torch.device("cuda", ctx.device))
+        cell = packed.cell if packed.cell.shape[0] == 1 else packed.cell[f0:f1]
+        return PackedTrajectory(pos, cell, packed.numbers, packed.masses, packed.pbc), (0, f1 - f0)
+
+    def _run(self, jobs):
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(len(jobs)) as ex:
+            return [f.result() for f in [ex.submit(j) for j in jobs]]
+
+    def rdf_accumulate(self, packed, rmax, nbins, frame_range=None, out=None):
+        assert out is None, "device-resident accumulation is a single-context feature"
+        lo, hi = (0, packed.n_frames) if frame_range is None else frame_range
+        jobs = []
+        for ctx, (a, b) in zip(self.ctxs, self._shards(lo, hi)):
+            def job(ctx=ctx, a=a, b=b):
+                tr, fr = self._for_device(packed, ctx, (a, b))
+                return ctx.rdf_accumulate(tr, rmax, nbins, frame_range=fr)
+            jobs.append(job)
+        res = self._run(jobs)
+        return sum(r[0] for r in res), float(sum(r[1] for r in res)), res[0][2]
+
+    def cn_count(self, packed, cutoff, sets, frame_range=None, per_atom=False):
+        lo, hi = (0, packed.n_frames) if frame_range is None else frame_range
+        jobs = []
+        for ctx, (a, b) in zip(self.ctxs, self._shards(lo, hi)):
+            def job(ctx=ctx, a=a, b=b):
+                tr, fr = self._for_device(packed, ctx, (a, b))
+                return ctx.cn_count(tr, cutoff, sets, frame_range=fr, per_atom=per_atom)
+            jobs.append(job)
+        res = self._run(jobs)
+        if per_atom:
+            return np.concatenate([r[0] for r in res], axis=0), np.concatenate([r[1] for r in res], axis=0)
+        return np.concatenate(res, axis=0)
+
+    def bad_hist(self, packed, cutoff, triples, edges, frame_range=None, out=None):
+        assert out is None, "device-resident accumulation is a single-context feature"
+        lo, hi = (0, packed.n_frames) if frame_range is None else frame_range
+        jobs = []
+        for ctx, (a, b) in zip(self.ctxs, self._shards(lo, hi)):
+            def job(ctx=ctx, a=a, b=b):
+                tr, fr = self._for_device(packed, ctx, (a, b))
+                return ctx.bad_hist(tr, cutoff, triples, edges, frame_range=fr)
+            jobs.append(job)
+        res = self._run(jobs)
+        return sum(r[0] for r in res), sum(r[1] for r in res)
+
+    def bad_hist_by_cn(self, packed, cutoff, triples, edges, cn_max=16, frame_range=None):
+        lo, hi = (0, packed.n_frames) if frame_range is None else frame_range
+        jobs = []
+        for ctx, (a, b) in zip(self.ctxs, self._shards(lo, hi)):
+            def job(ctx=ctx, a=a, b=b):
+                tr, fr = self._for_device(packed, ctx, (a, b))
+                return ctx.bad_hist_by_cn(tr, cutoff, triples, edges, cn_max=cn_max, frame_range=fr)
+            jobs.append(job)
+        res = self._run(jobs)
+        return sum(r[0] for r in res), sum(r[1] for r in res)
+
+    def msd_window(self, packed, windows, unwrap=False, remove_com=True, atom_range=None):
+        lo, hi = (0, packed.n_atoms) if atom_range is None else atom_range
+        jobs = []
+        for ctx, (a, b) in zip(self.ctxs, self._shards(lo, hi)):
+            def job(ctx=ctx, a=a, b=b):
+                tr, _ = self._for_device(packed, ctx)
+                return ctx.msd_window(tr, windows, unwrap=unwrap, remove_com=remove_com, atom_range=(a, b))
+            jobs.append(job)
+        res = self._run(jobs)
+        return sum(r[0] for r in res), res[0][1]
+
+    def msd_direct(self, packed):
+        return self.ctxs[0].msd_direct(self._for_device(packed, self.ctxs[0])[0])
+
+    def last_kernel_seconds(self, dominant=False):
+        return max(c.last_kernel_seconds(dominant) for c in self.ctxs)
+
+    def last_kernel_launches(self):
+        return sum(c.last_kernel_launches() for c in self.ctxs)
+
+    def last_path(self):
+        return self.ctxs[0].last_path()
+
+    def synchronize(self):
+        for c in self.ctxs:
+            c.synchronize()
+
+
 _contexts = {}
 _ctx_lock = threading.Lock()
 
 
 def get_context(device=None):
-    """Cached :class:`Context` of a device (default: LOCAL_RANK or 0)."""
+    """Cached :class:`Context` of a device (default: LOCAL_RANK or 0); a list / tuple of devices gives
+    a cached :class:`MultiContext` (several GPUs driven from this process)."""
+    if isinstance(device, (list, tuple)):
+        key = tuple(int(d) for d in device)
+        with _ctx_lock:
+            ctx = _contexts.get(key)
+            if ctx is None:
+                ctx = MultiContext(key)
+                _contexts[key] = ctx
+            return ctx
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
         if device >= max(device_count(), 1):

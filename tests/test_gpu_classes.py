@@ -161,3 +161,28 @@ def test_rdf_integration_coordination_number(zif4):
     rdf = Rdf.from_trajectory(packed, dr=0.001, rmax=6.0)
     rho = 272 / zif4.get_volume()
     assert rdf.get_coordination_number("Zn-N", 2.5, rho) == pytest.approx(4.0, rel=0.02)
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_several_contexts_from_one_process(resident):
+    # device=[0, 0]: a MultiContext (two contexts / streams / threads; a real multi-GPU node would list
+    # different devices) shards frames (RDF, BAD, CN) or atoms (MSD) and merges on the host -- same results
+    from amof_amd.bad import Bad, BadByCn
+    from amof_amd.cn import CoordinationNumber
+    from amof_amd.msd import WindowMsd
+    from amof_amd.rdf import Rdf
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (1, 1, 2)), 11, 0.08, 123, cell_jitter=0.004)
+    if resident:
+        packed = packed.to_device(0)
+    cut = {'Zn-N': 2.5, 'C-N': 1.6}
+    for make in (lambda d: Rdf.from_trajectory(packed, dr=0.02, device=d, distributed=False),
+                 lambda d: Bad.from_trajectory(packed, cut, dtheta=0.5, device=d, distributed=False),
+                 lambda d: CoordinationNumber.from_trajectory(packed, cut, device=d, distributed=False)):
+        one, two = make(0).data, make([0, 0]).data
+        assert list(one.columns) == list(two.columns) and np.array_equal(one.values, two.values)
+    m1 = WindowMsd.from_trajectory(packed, delta_time=1, timestep=1, device=0, distributed=False).data
+    m2 = WindowMsd.from_trajectory(packed, delta_time=1, timestep=1, device=[0, 0], distributed=False).data
+    np.testing.assert_allclose(m2.values, m1.values, rtol=1e-12, atol=1e-15)
+    b1 = BadByCn.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=1.0, device=0, distributed=False)
+    b2 = BadByCn.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=1.0, device=[0, 0], distributed=False)
+    assert np.array_equal(b1.hist, b2.hist)
