@@ -287,6 +287,14 @@ def main():
             WindowMsd.from_trajectory(host, delta_time=100, timestep=1, device=local_rank, distributed=False)
             torch.cuda.synchronize()
             out["host_resident_frames_per_s"] = F / (time.perf_counter() - t0)
+            # supplementary: packing a list of ase.Atoms-like frames into the arrays above (pure Python + memcpy,
+            # identical for a CPU and a GPU path; SURVEY 8d asks for it separately)
+            from amof_amd.frames import Frame, pack_trajectory
+            nfr = min(F, 200)
+            frames = [Frame(host.numbers, host.pos[k], host.cell_of(k)) for k in range(nfr)]
+            t0 = time.perf_counter()
+            pack_trajectory(frames)
+            out["pack_atoms_list_frames_per_s"] = nfr / (time.perf_counter() - t0)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
