@@ -258,11 +258,15 @@ def pack_trajectory(trajectory):
     pos = np.empty((len(frames), n, 3), dtype=np.float64)
     cell = np.empty((len(frames), 3, 3), dtype=np.float64)
     for k, atoms in enumerate(frames):
-        p = atoms.get_positions()
+        # ``atoms.positions`` is a view in ASE (and here): one copy, straight into the packed array
+        p = getattr(atoms, "positions", None)
+        if p is None:
+            p = atoms.get_positions()
         if len(p) != n:
             raise ValueError("frame %d has %d atoms, frame 0 has %d" % (k, len(p), n))
         pos[k] = p
-        cell[k] = np.array(atoms.get_cell())
+        c = getattr(atoms, "cell", None)
+        cell[k] = np.asarray(c if c is not None else atoms.get_cell(), dtype=np.float64).reshape(3, 3)
     if (cell == cell[0]).all():
         cell = cell[:1].copy()
     pbc = np.array(getattr(first, "pbc", (True, True, True)), dtype=bool)
