@@ -270,7 +270,7 @@ template <int WT>
 __global__ __launch_bounds__(MSD_THREADS) void msd_comb_kernel(const double *__restrict__ DT, int64_t Fp, int F,
                                                                const int32_t *__restrict__ perm,
                                                                const MsdGroup *__restrict__ groups, int d, int W,
-                                                               double *__restrict__ partial)
+                                                               int Wstride, double *__restrict__ partial)
 {
     constexpr int NV = COMB_B + WT - 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -318,7 +318,69 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_kernel(const double *__r
     for (int w = 0; w < WT; w++) {
         if (w < W) {
             const double tot = block_sum(acc[w], red);
-            if (tid == 0) partial[(size_t)blockIdx.x * W + w] = tot;
+            if (tid == 0) partial[(size_t)blockIdx.x * Wstride + w] = tot;
+        }
+    }
+}
+
+// Further passes for W > 32: windows w0 .. w0 + Wn - 1 (Wn <= WT).  A task holds its COMB_B base
+// entries and the COMB_B + WT - 1 partner entries that start w0 comb steps later.
+template <int WT>
+__global__ __launch_bounds__(MSD_THREADS) void msd_comb_hi_kernel(const double *__restrict__ DT, int64_t Fp, int F,
+                                                                  const int32_t *__restrict__ perm,
+                                                                  const MsdGroup *__restrict__ groups, int d, int w0,
+                                                                  int Wn, int Wstride, double *__restrict__ partial)
+{
+    constexpr int NP = COMB_B + WT - 1;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *u = reinterpret_cast<double *>(lds_raw);  // [F]
+    __shared__ double red[MSD_THREADS / 64];
+    const int tid = threadIdx.x;
+    const MsdGroup gr = groups[blockIdx.x];
+    const int nq = (F + d - 1) / d;
+    const int ntask = d * ((nq + COMB_B - 1) / COMB_B);
+    double acc[WT];
+#pragma unroll
+    for (int w = 0; w < WT; w++) acc[w] = 0.0;
+    for (int c = 0; c < 3 * gr.count; c++) {
+        const int64_t atom = perm[gr.start + c / 3];
+        const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
+        __syncthreads();
+        for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
+            const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
+            u[k] = v2.x;
+            if (k + 1 < F) u[k + 1] = v2.y;
+        }
+        __syncthreads();
+        lds_scan(u, F, red, 0.0);
+        for (int t = tid; t < ntask; t += MSD_THREADS) {
+            const int r = t % d, J0 = (t / d) * COMB_B;
+            const int limp = (F - r + d - 1) / d - J0 - w0;   // valid partner entries of this task
+            if (limp <= 0) continue;
+            const double m0 = t == 0 ? 0.0 : 1.0;              // origin k = 0 is skipped
+            double vb[COMB_B], vp[NP];
+            const double *ub = u + r + (size_t)d * J0;
+#pragma unroll
+            for (int i = 0; i < COMB_B; i++) vb[i] = i < limp + w0 ? ub[(size_t)d * i] : 0.0;
+#pragma unroll
+            for (int e = 0; e < NP; e++) vp[e] = e < limp ? ub[(size_t)d * (w0 + e)] : 0.0;
+#pragma unroll
+            for (int e = 0; e < NP; e++) {
+                if (e < limp) {
+#pragma unroll
+                    for (int i = (e - WT + 1 > 0 ? e - WT + 1 : 0); i <= (e < COMB_B - 1 ? e : COMB_B - 1); i++) {
+                        const double dd = vp[e] - vb[i];
+                        acc[e - i] = fma(i == 0 ? dd * m0 : dd, dd, acc[e - i]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < WT; w++) {
+        if (w < Wn) {
+            const double tot = block_sum(acc[w], red);
+            if (tid == 0) partial[(size_t)blockIdx.x * Wstride + w0 + w] = tot;
         }
     }
 }
@@ -613,7 +675,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         };
         // windows in arithmetic progression from 0 (the only thing WindowMsd produces): comb kernel
         int comb_d = 0;
-        if (W >= 2 && W <= 32 && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
+        if (W >= 2 && W <= 128 && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
             comb_d = windows[1];
             for (int w = 0; w < W; w++)
                 if ((int64_t)windows[w] != (int64_t)w * comb_d) comb_d = 0;
@@ -624,7 +686,17 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
                                (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
-                               comb_d, (int)W, (double *)d_part);
+                               comb_d, (int)std::min(W, 32), (int)W, (double *)d_part);
+            return hipGetLastError();
+        };
+        // windows 32 .. W-1 in further passes of up to 32 (each re-reads the columns)
+        auto launch_comb_hi = [&](auto kern, int w0, int wn) -> hipError_t {
+            const size_t lds = (size_t)F * sizeof(double);
+            hipError_t e = allow_max_lds((const void *)kern);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
+                               (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
+                               comb_d, w0, wn, (int)W, (double *)d_part);
             return hipGetLastError();
         };
         ctx->last_path = comb_d > 0 ? "msd_comb" : "msd_group";
@@ -636,7 +708,15 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         else if (comb_d > 0 && W <= 20) e = launch_comb(msd_comb_kernel<20>);
         else if (comb_d > 0 && W <= 24) e = launch_comb(msd_comb_kernel<24>);
         else if (comb_d > 0 && W <= 28) e = launch_comb(msd_comb_kernel<28>);
-        else if (comb_d > 0) e = launch_comb(msd_comb_kernel<32>);
+        else if (comb_d > 0) {
+            e = launch_comb(msd_comb_kernel<32>);
+            for (int w0 = 32; w0 < W && e == hipSuccess; w0 += 32) {
+                const int wn = std::min(32, (int)W - w0);
+                if (wn <= 8) e = launch_comb_hi(msd_comb_hi_kernel<8>, w0, wn);
+                else if (wn <= 16) e = launch_comb_hi(msd_comb_hi_kernel<16>, w0, wn);
+                else e = launch_comb_hi(msd_comb_hi_kernel<32>, w0, wn);
+            }
+        }
         else if (W <= 8) e = launch(msd_group_kernel<8>);
         else if (W <= 32) e = launch(msd_group_kernel<32>);
         else e = launch(msd_group_kernel<0>);

@@ -257,7 +257,8 @@ def test_rdf_pipelined_host_staging(hip_ctx):
 
 
 @pytest.mark.parametrize("F,d,W", [(7, 1, 3), (50, 3, 16), (333, 7, 24), (333, 11, 25), (1000, 100, 5), (1000, 31, 32),
-                                   (257, 13, 12), (90, 100, 1), (64, 2, 29), (1201, 50, 21)])
+                                   (257, 13, 12), (90, 100, 1), (64, 2, 29), (1201, 50, 21),
+                                   (333, 3, 40), (1000, 7, 64), (2000, 9, 100), (700, 5, 33), (900, 11, 70)])
 def test_msd_comb_kernel_equals_generic_and_oracle(hip_ctx, F, d, W):
     # windows w*d: the comb kernel (every template bucket, ragged comb ends, F < d, the skipped origin)
     # against the generic LDS kernel and the numpy restatement
