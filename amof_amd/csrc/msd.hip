@@ -385,6 +385,75 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_hi_kernel(const double *
     }
 }
 
+// The same comb arithmetic for trajectories too long for LDS (F + W > 19 200): the columns are prefix-summed in
+// global memory first (scan_column_kernel); a workgroup then walks each column in batches of R residue classes,
+// staging only their comb entries -- T[j][rr] = U[rb + rr + d j], nq x R doubles, R contiguous doubles per global
+// segment -- and forms the pairs from registers as above.  One launch per 32 windows.
+template <int WT>
+__global__ __launch_bounds__(MSD_THREADS) void msd_comb_global_kernel(const double *__restrict__ UT, int64_t Fp, int F,
+                                                                      const int32_t *__restrict__ perm,
+                                                                      const MsdGroup *__restrict__ groups, int d, int R,
+                                                                      int w0, int Wn, int Wstride,
+                                                                      double *__restrict__ partial)
+{
+    constexpr int NP = COMB_B + WT - 1;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *T = reinterpret_cast<double *>(lds_raw);  // [nq][R]
+    __shared__ double red[MSD_THREADS / 64];
+    const int tid = threadIdx.x;
+    const MsdGroup gr = groups[blockIdx.x];
+    const int nq = (F + d - 1) / d;
+    const int nblk = (nq + COMB_B - 1) / COMB_B;
+    double acc[WT];
+#pragma unroll
+    for (int w = 0; w < WT; w++) acc[w] = 0.0;
+    for (int c = 0; c < 3 * gr.count; c++) {
+        const int64_t atom = perm[gr.start + c / 3];
+        const double *__restrict__ col = UT + (size_t)(3 * atom + c % 3) * Fp;
+        for (int rb = 0; rb < d; rb += R) {
+            const int Rn = min(R, d - rb);
+            __syncthreads();
+            for (int idx = tid; idx < nq * R; idx += MSD_THREADS) {
+                const int j = idx / R, rr = idx - j * R;
+                const int k = rb + rr + d * j;
+                T[idx] = (rr < Rn && k < F) ? col[k] : 0.0;
+            }
+            __syncthreads();
+            const int ntask = Rn * nblk;
+            for (int t = tid; t < ntask; t += MSD_THREADS) {
+                const int jb = t / Rn, rr = t - jb * Rn;
+                const int J0 = jb * COMB_B, r = rb + rr;
+                const int limp = (F - r + d - 1) / d - J0 - w0;   // valid partner entries of this task
+                if (limp <= 0) continue;
+                const double m0 = (r == 0 && J0 == 0) ? 0.0 : 1.0;   // origin k = 0 is skipped
+                double vb[COMB_B], vp[NP];
+                const double *tb = T + (size_t)J0 * R + rr;
+#pragma unroll
+                for (int i = 0; i < COMB_B; i++) vb[i] = i < limp + w0 ? tb[(size_t)R * i] : 0.0;
+#pragma unroll
+                for (int e = 0; e < NP; e++) vp[e] = e < limp ? tb[(size_t)R * (w0 + e)] : 0.0;
+#pragma unroll
+                for (int e = 0; e < NP; e++) {
+                    if (e < limp) {
+#pragma unroll
+                        for (int i = (e - WT + 1 > 0 ? e - WT + 1 : 0); i <= (e < COMB_B - 1 ? e : COMB_B - 1); i++) {
+                            const double dd = vp[e] - vb[i];
+                            acc[e - i] = fma(i == 0 ? dd * m0 : dd, dd, acc[e - i]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < WT; w++) {
+        if (w < Wn) {
+            const double tot = block_sum(acc[w], red);
+            if (tid == 0) partial[(size_t)blockIdx.x * Wstride + w0 + w] = tot;
+        }
+    }
+}
+
 // sumsq[s][w] = sum over the groups of species s, in a fixed order (deterministic):
 // one workgroup per (s, w); groups are species-sorted, so species s owns [g0, g1)
 __global__ __launch_bounds__(MSD_THREADS) void msd_reduce_kernel(const double *__restrict__ partial,
@@ -664,6 +733,13 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     }
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_dom_begin(ctx, "msd_global");
+    // windows in arithmetic progression from 0 (the only thing WindowMsd produces): comb kernels
+    int comb_d = 0;
+    if (W >= 2 && W <= (lds_resident ? 128 : 256) && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
+        comb_d = windows[1];
+        for (int w = 0; w < W; w++)
+            if ((int64_t)windows[w] != (int64_t)w * comb_d) comb_d = 0;
+    }
     if (lds_resident) {
         auto launch = [&](auto kern) -> hipError_t {
             hipError_t e = allow_max_lds((const void *)kern);
@@ -673,13 +749,6 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
                                (const int32_t *)d_win, (int)W, (double *)d_part);
             return hipGetLastError();
         };
-        // windows in arithmetic progression from 0 (the only thing WindowMsd produces): comb kernel
-        int comb_d = 0;
-        if (W >= 2 && W <= 128 && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
-            comb_d = windows[1];
-            for (int w = 0; w < W; w++)
-                if ((int64_t)windows[w] != (int64_t)w * comb_d) comb_d = 0;
-        }
         auto launch_comb = [&](auto kern) -> hipError_t {
             const size_t lds = (size_t)F * sizeof(double);
             hipError_t e = allow_max_lds((const void *)kern);
@@ -725,12 +794,28 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         // long trajectory: prefix-sum every column in place, then reduce the windows from global memory
         hipLaunchKernelGGL(scan_column_kernel, dim3((unsigned)(3 * N)), dim3(MSD_THREADS), 0, ctx->stream,
                            (const double *)d_DT, (const double *)nullptr, Fp, (int)F, (double *)d_DT);
+        const int64_t nq = comb_d > 0 ? (F + comb_d - 1) / comb_d : 0;
+        const int Rres = comb_d > 0 && nq > 0 ? (int)std::min<int64_t>(std::min<int64_t>(comb_d, 32), 16384 / nq) : 0;
+        if (Rres >= 1) {
+            // comb kernel on the scanned columns, 32 windows per launch
+            ctx->last_path = "msd_comb_global";
+            const size_t lds = (size_t)nq * Rres * sizeof(double);
+            AMOF_HIP_TRY(ctx, allow_max_lds((const void *)msd_comb_global_kernel<32>));
+            for (int w0 = 0; w0 < W; w0 += 32) {
+                hipLaunchKernelGGL(msd_comb_global_kernel<32>, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds,
+                                   ctx->stream, (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm,
+                                   (const MsdGroup *)d_groups, comb_d, Rres, w0, std::min(32, (int)W - w0), (int)W,
+                                   (double *)d_part);
+            }
+            AMOF_HIP_TRY(ctx, hipGetLastError());
+        } else {
         const unsigned wchunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(W, (4096 + (int64_t)groups.size() - 1) /
                                                                                     (int64_t)groups.size()));
         hipLaunchKernelGGL(msd_group_kernel_global, dim3((unsigned)groups.size(), std::min(wchunks, 65535u)),
                            dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm,
                            (const MsdGroup *)d_groups, (const int32_t *)d_win, (int)W, (double *)d_part);
         AMOF_HIP_TRY(ctx, hipGetLastError());
+        }
     }
     timing_dom_end(ctx, 1);
     hipLaunchKernelGGL(msd_reduce_kernel, dim3((unsigned)(S * W)), dim3(MSD_THREADS), 0, ctx->stream,

@@ -13,6 +13,24 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+class H_env(object):
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _oracle_rdf(packed, rmax, nb):
     kinds, sp = H.species_of(packed.numbers)
     return clib.rdf_hist(packed.pos_host(), packed.cell, sp, len(kinds), rmax, nb, pbc=packed.pbc)[0]
@@ -194,6 +212,22 @@ def test_msd_long_trajectory_uses_global_path(hip_ctx):
         elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window, unwrap=unwrap)
         for e, r in zip(elements, ref):
             got = sumsq[kinds.index(int(e))] / (packed.numbers == e).sum() / (F - window)
+            np.testing.assert_allclose(got, r, rtol=1e-9, atol=1e-12)
+    # evenly spaced windows on the same long trajectory: the comb kernel on globally scanned columns
+    for d, wmax in [(100, 105), (1000, 10), (7, 250), (333, 31)]:
+        wap = (np.arange(wmax) * d).astype(np.int32)
+        wap = wap[wap < F]
+        for unwrap in (False, True):
+            sumsq, kinds = hip_ctx.msd_window(packed, wap, unwrap=unwrap)
+            assert hip_ctx.last_path() == "msd_comb_global"
+            with H_env(AMOF_MSD_NOCOMB="1"):
+                generic, _ = hip_ctx.msd_window(packed, wap, unwrap=unwrap)
+                assert hip_ctx.last_path() == "msd_global"
+            np.testing.assert_allclose(sumsq, generic, rtol=1e-11, atol=1e-12)
+        elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, wap)
+        sumsq, kinds = hip_ctx.msd_window(packed, wap)
+        for e, r in zip(elements, ref):
+            got = sumsq[kinds.index(int(e))] / (packed.numbers == e).sum() / (F - wap)
             np.testing.assert_allclose(got, r, rtol=1e-9, atol=1e-12)
     # and many windows on a shorter one (W > 32: generic LDS kernel)
     short = PackedTrajectory(packed.pos[:600], cell, packed.numbers)
