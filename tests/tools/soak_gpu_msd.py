@@ -23,8 +23,8 @@ worst = 0.0
 while time.time() < t_end:
     seed += 1
     rng = np.random.default_rng(seed)
-    F = int(rng.choice([2, 3, 11, 64, 257, 1000, 2500]))
-    N = int(rng.choice([1, 5, 33, 130]))
+    F = int(rng.choice([2, 3, 11, 64, 257, 1000, 2500, 20500]))
+    N = int(rng.choice([1, 5, 33, 130])) if F < 20000 else int(rng.choice([1, 4]))
     S = int(rng.integers(1, 4))
     numbers = rng.choice([1, 8, 30][:S], size=N)
     cell = np.diag(rng.uniform(7.0, 15.0, 3))
