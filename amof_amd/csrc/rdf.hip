@@ -200,6 +200,8 @@ __global__ __launch_bounds__(RDF_TILE) void rdf_tile_kernel_global(RdfArgs a)
 struct FrameScale {
     float sc[9];        // ORTHO: sc[0..2] = L_k * 2^-32 / dr, sc[3..5] their squares ; else cell[k][c] * 2^-32 / dr (rows in stored order)
     uint32_t cull_gap;  // slab-gap threshold of this cell (0 = culling off)
+    uint32_t near_t[3]; // IMG variant: a pair with |i_k| > near_t[k] (stored axis order) is evaluated canonically
+    uint32_t _pad;
     double sc64[9];     // the same factors in f64 (level-2 refinement)
 };
 
@@ -285,16 +287,42 @@ __device__ __forceinline__ void rdf_pair_refine(unsigned *hist, const RdfFastArg
     rdf_count(hist, norm2(dx, dy, dz), fa.a.rmax2, fa.a.dr, fa.a.nbins);
 }
 
+// Canonical evaluation of a whole pair -- the base image and every listed further image, exactly as the exact
+// kernels (and the oracle) do it.  Used by the IMG variant for the pairs that lie within reach of a cell face.
+template <bool ORTHO>
+__device__ __forceinline__ void rdf_pair_images(unsigned *hist, const RdfFastArgs &fa, const double *__restrict__ g,
+                                                const double *__restrict__ p, uint32_t idx_i, uint32_t idx_j, int gi)
+{
+    const double *pi = p + (size_t)idx_i * 3, *pj = p + (size_t)idx_j * 3;
+    double dx, dy, dz;
+    pair_base<ORTHO>(g, pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2], dx, dy, dz);
+    rdf_count(hist, norm2(dx, dy, dz), fa.a.rmax2, fa.a.dr, fa.a.nbins);
+    const int ne = fa.a.max_img > 0 ? fa.a.nimg[gi] : 0;
+    const double *__restrict__ E = fa.a.img + (size_t)gi * fa.a.max_img * 3;
+    for (int m = 0; m < ne; m++)
+        rdf_count(hist, norm2(dx + E[3 * m], dy + E[3 * m + 1], dz + E[3 * m + 2]), fa.a.rmax2, fa.a.dr, fa.a.nbins);
+}
+
 // One pair on the fast path.  With g = guard_f: a candidate whose fractional
 // part is > g away from both bin edges is certainly in bin (int)q -- and if
 // that bin is >= nbins the pair is certainly out of range; everything else
 // below nbins + g is refined.  Returns true when the pair needs refinement.
-template <bool ORTHO>
+// IMG: the cutoff reaches beyond half a cell height (or too close to it): pairs whose fractional difference lies
+// within reach of a cell face (|i_k| > near_t[k]) can have a second image in range or an ambiguous base image --
+// they are not touched here (near = true) and are evaluated canonically, images included; for every other pair the
+// base image is unambiguous and the only one that can be in range.
+template <bool ORTHO, bool IMG = false>
 __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool live, float half_m_guard,
                                          float nb_hi, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj,
-                                         float &q)
+                                         float &q, const uint32_t *near_t = nullptr, bool *near = nullptr)
 {
     const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
+    if (IMG) {
+        const bool nr = ((uint32_t)ix + near_t[0] > 2u * near_t[0]) | ((uint32_t)iy + near_t[1] > 2u * near_t[1]) |
+                        ((uint32_t)iz + near_t[2] > 2u * near_t[2]);
+        *near = live && nr;
+        live = live && !nr;
+    }
     q = fast_q<ORTHO>(sc, ix, iy, iz);
     const bool in = live && (q < nb_hi);
     const bool safe = fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard;
@@ -302,13 +330,14 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
     return in && !safe;
 }
 
-template <bool ORTHO, bool DIAG, bool TAIL>
+template <bool ORTHO, bool DIAG, bool TAIL, bool IMG = false>
 __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const FrameScale *__restrict__ fs,
                                           const double *__restrict__ g, const float *sc, const uint4 *tq,
                                           int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
                                           float half_m_guard, float nb_hi, uint32_t uax, uint32_t uay,
                                           uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
-                                          uint32_t idb, const double *__restrict__ p)
+                                          uint32_t idb, const double *__restrict__ p,
+                                          const uint32_t *near_t = nullptr, int gi = 0)
 {
     // four partner atoms per trip, read by broadcast before any LDS atomic
     uint4 qj[4];
@@ -316,19 +345,40 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
     for (int u = 0; u < 4; u++) qj[u] = tq[j0 + u];
     float qa[4], qb[4];
     bool na[4], nb[4];   // per-pair "needs refinement" flags (kept as lane masks)
+    bool anynear = false;   // IMG: some pair of this quad lies within reach of a cell face (one mask only: SGPRs are scarce)
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int j = j0 + u;
         const bool la = has_a && (!TAIL || j < cntj) && (!DIAG || j > ia);
         const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
-        na[u] = fast_bin<ORTHO>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u]);
-        nb[u] = fast_bin<ORTHO>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u]);
+        bool ma = false, mb = false;
+        na[u] = fast_bin<ORTHO, IMG>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u], near_t, &ma);
+        nb[u] = fast_bin<ORTHO, IMG>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u], near_t, &mb);
+        anynear |= ma | mb;
     }
     if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {   // a few % of the pairs
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (na[u]) rdf_pair_refine<ORTHO>(hist, fa, fs, g, qa[u], uax, uay, uaz, qj[u], p, ida);
             if (nb[u]) rdf_pair_refine<ORTHO>(hist, fa, fs, g, qb[u], ubx, uby, ubz, qj[u], p, idb);
+        }
+    }
+    if (IMG) {
+        if (anynear) {   // rare: find the pairs again (cheap) and evaluate them canonically, one copy of the code
+#pragma unroll 1
+            for (int u = 0; u < 4; u++) {
+                const uint4 q = u == 0 ? qj[0] : (u == 1 ? qj[1] : (u == 2 ? qj[2] : qj[3]));
+                const int j = j0 + u;
+                const bool la = has_a && (!TAIL || j < cntj) && (!DIAG || j > ia);
+                const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
+                auto is_near = [&](uint32_t ux, uint32_t uy, uint32_t uz) {
+                    const uint32_t ix = q.x - ux, iy = q.y - uy, iz = q.z - uz;
+                    return (ix + near_t[0] > 2u * near_t[0]) | (iy + near_t[1] > 2u * near_t[1]) |
+                           (iz + near_t[2] > 2u * near_t[2]);
+                };
+                if (la && is_near(uax, uay, uaz)) rdf_pair_images<ORTHO>(hist, fa, g, p, ida, q.w, gi);
+                if (lb && is_near(ubx, uby, ubz)) rdf_pair_images<ORTHO>(hist, fa, g, p, idb, q.w, gi);
+            }
         }
     }
 }
@@ -349,7 +399,7 @@ __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
     __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst_wave, 16, 0, 0);
 }
 
-template <bool ORTHO, bool CULL>
+template <bool ORTHO, bool CULL, bool IMG = false>
 __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
     const RdfArgs &a = fa.a;
@@ -432,6 +482,11 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
 #pragma unroll
         for (int k = 0; k < 9; k++)
             sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
+        uint32_t near_t[3] = {0x7fffffffu, 0x7fffffffu, 0x7fffffffu};
+        if (IMG) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) near_t[k] = __builtin_amdgcn_readfirstlane(fs->near_t[k]);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for this step has landed
         __syncthreads();                                    // everyone's has; the previous step is fully consumed
         // what the next step needs streams in behind the arithmetic
@@ -490,16 +545,18 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
             // quads are dealt round-robin to the four waves
             if (diag) {
                 for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
-                    fast_quad<ORTHO, true, true>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard, nb_hi,
-                                                 uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+                    fast_quad<ORTHO, true, true, IMG>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                                                      nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p, near_t, gi);
             } else {
                 int j0 = qb + 4 * wave;
                 for (; j0 < qe_full; j0 += 16)
-                    fast_quad<ORTHO, false, false>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
-                                                   nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+                    fast_quad<ORTHO, false, false, IMG>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
+                                                        half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p,
+                                                        near_t, gi);
                 if (j0 == full && j0 < qe && full < cntj)
-                    fast_quad<ORTHO, false, true>(hist, fa, fs, g, sc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard,
-                                                  nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p);
+                    fast_quad<ORTHO, false, true, IMG>(hist, fa, fs, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
+                                                       half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p,
+                                                       near_t, gi);
             }
         }
         if (++sub == nsub) { sub = 0; fl++; }
@@ -901,8 +958,39 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     if (rmax * (1.0 + 4.0 * guard_f / (double)nbins + 1e-6) >= 0.5 * geom.rec[(size_t)k * GEOM_STRIDE + 18 + x])
                         fast = false;
         }
+        // Image-aware variant of the tile kernel: the cutoff reaches beyond half a cell height (further periodic
+        // images count) or comes too close to it.  Pairs whose fractional difference lies within reach of a cell
+        // face are evaluated canonically (base + every listed image); all others can only have their base image
+        // in range, and that base is unambiguous.  near_thr[cell][axis]: fixed-point threshold on |i_k|.
+        bool fast_img = false;
+        std::vector<uint32_t> near_thr;
+        if (!fast && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS - 5120 && guard_f < 0.25 &&
+            !(force && strcmp(force, "v1") == 0) && max_img <= 124 && !getenv("AMOF_RDF_NOIMG")) {
+            fast_img = true;
+            near_thr.assign((size_t)nc * 3, 0x7fffffffu);
+            for (int64_t k = 0; k < nc && fast_img; k++)
+                for (int x = 0; x < 3; x++) {
+                    const double h = geom.rec[(size_t)k * GEOM_STRIDE + 18 + x];
+                    // beyond |s| = 1/2 - tau an image shifted along this axis could come within the cutoff
+                    const double tau = rmax * (1.0 + 4.0 * guard_f / (double)nbins + 1e-6) / h - 0.5 + 1e-9;
+                    const double thr = 0.5 - std::max(tau, 0.0) - 1e-9;
+                    if (tau <= 0.0) {
+                        // clear of this half height by more than the guards: only an exact tie is ambiguous
+                        near_thr[(size_t)k * 3 + x] = 0x7fffffffu;
+                    } else if (thr < 0.3) {
+                        fast_img = false;      // two fifths of the pairs or more would go the canonical way
+                    } else {
+                        near_thr[(size_t)k * 3 + x] = (uint32_t)floor(thr * 4294967296.0) - 2u;
+                    }
+                }
+        }
+        if (fast && getenv("AMOF_RDF_FORCE_IMG")) {   // tests / measurements: the image-aware variant on a plain case
+            fast = false;
+            fast_img = true;
+            near_thr.assign((size_t)nc * 3, 0x7fffffffu);
+        }
         bool done = false;
-        if (fast) {
+        if (fast || fast_img) {
             HostTiles ftiles;
             build_tiles(t, FAST_TILE, ftiles);
             std::vector<int2> fpairs;
@@ -953,6 +1041,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 // a block is skipped when the slab gap alone exceeds rmax (1e-6 relative and 4 grid units of slack)
                 const double hax = geom.rec[(size_t)k * GEOM_STRIDE + 18 + axis];
                 r.cull_gap = cull ? (uint32_t)std::min(4294967295.0, ceil(rmax / hax * 4294967296.0 * (1.0 + 1e-6)) + 4.0) : 0u;
+                for (int q = 0; q < 3; q++) r.near_t[q] = fast_img ? near_thr[(size_t)k * 3 + ord[q]] : 0x7fffffffu;
+                r._pad = 0u;
             }
             void *d_fs;
             AMOF_TRY(upload(ctx, SLOT_AUX5, fsv.data(), fsv.size() * sizeof(FrameScale), &d_fs));
@@ -975,7 +1065,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             bool cell_taken = false;
             {
                 int nk[3];
-                bool cell_ok = S <= 16 && t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && t->n_atoms >= 64 &&
+                bool cell_ok = fast && S <= 16 && t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && t->n_atoms >= 64 &&
                                !getenv("AMOF_RDF_NOCELL");
                 for (int x = 0; x < 3; x++) {
                     nk[x] = (int)std::min(1024.0, floor(hmin[x] / (0.5 * rmax * (1.0 + 1e-5))));
@@ -1017,6 +1107,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                         if (ortho)
                             for (int q = 0; q < 3; q++) r.sc[3 + q] = (float)(r.sc64[q] * r.sc64[q]);
                         r.cull_gap = 0u;
+                        r.near_t[0] = r.near_t[1] = r.near_t[2] = 0x7fffffffu;
+                        r._pad = 0u;
                     }
                     std::vector<uint32_t> ktab((size_t)S * S + npk);
                     {
@@ -1087,7 +1179,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             if (hmin[(axis + 2) % 3] > hmin[axis_y]) axis_y = (axis + 2) % 3;
             const int nz2 = (int)std::min(64.0, floor(hmin[axis] / (rmax * (1.0 + 1e-5))));
             bool use_range = false;
-            if (nz2 >= 3 && t->n_cells == 1 && !cell_taken && !(getenv("AMOF_RDF_NORANGE"))) {
+            if (fast && nz2 >= 3 && t->n_cells == 1 && !cell_taken && !(getenv("AMOF_RDF_NORANGE"))) {
                 // visited share of the partners: 1-D slab list vs (3 slabs) x (y strip + 2 rmax)
                 int64_t nmax = 0;
                 for (int x = 0; x < S; x++) nmax = std::max<int64_t>(nmax, ftiles.nsp[x]);
@@ -1116,6 +1208,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     if (ortho)
                         for (int q = 0; q < 3; q++) r.sc[3 + q] = (float)(r.sc64[q] * r.sc64[q]);
                     r.cull_gap = 0u;
+                    r.near_t[0] = r.near_t[1] = r.near_t[2] = 0x7fffffffu;
+                    r._pad = 0u;
                 }
                 AMOF_TRY(upload(ctx, SLOT_AUX5, fsv.data(), fsv.size() * sizeof(FrameScale), &d_fs));
                 fa.fs = (const FrameScale *)d_fs;
@@ -1210,7 +1304,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.a.frames_per_chunk = (int32_t)fpc;
                 fa.n_chunks = (int32_t)chunks;
                 dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
-                if (launches == 0) timing_dom_begin(ctx, "rdf_tile");
+                if (launches == 0) timing_dom_begin(ctx, fast_img ? "rdf_tile_img" : "rdf_tile");
                 auto launch = [&](auto kern) -> hipError_t {
                     hipError_t e2 = allow_max_lds((const void *)kern);
                     if (e2 != hipSuccess) return e2;
@@ -1218,7 +1312,13 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     return hipSuccess;
                 };
                 hipError_t e;
-                if (ortho && cull) e = launch(rdf_tile_kernel_fast<true, true>);
+                if (fast_img) {
+                    if (ortho && cull) e = launch(rdf_tile_kernel_fast<true, true, true>);
+                    else if (ortho) e = launch(rdf_tile_kernel_fast<true, false, true>);
+                    else if (cull) e = launch(rdf_tile_kernel_fast<false, true, true>);
+                    else e = launch(rdf_tile_kernel_fast<false, false, true>);
+                }
+                else if (ortho && cull) e = launch(rdf_tile_kernel_fast<true, true>);
                 else if (ortho) e = launch(rdf_tile_kernel_fast<true, false>);
                 else if (cull) e = launch(rdf_tile_kernel_fast<false, true>);
                 else e = launch(rdf_tile_kernel_fast<false, false>);

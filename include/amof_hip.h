@@ -87,7 +87,7 @@ int amof_ctx_synchronize(amof_ctx *ctx);
 double amof_last_kernel_seconds(const amof_ctx *ctx, int which);
 /* number of launches of the dominant kernel in the last call */
 int64_t amof_last_kernel_launches(const amof_ctx *ctx);
-/* kernel family that produced the result of the last call, e.g. "rdf_tile", "rdf_cell", "rdf_range",
+/* kernel family that produced the result of the last call, e.g. "rdf_tile", "rdf_tile_img", "rdf_cell", "rdf_range",
  * "rdf_exact", "cn_fast", "cn_exact", "bad_fast", "bad_exact", "msd_comb", "msd_group", "msd_comb_global", "msd_global",
  * "msd_direct" (diagnostics and tests; "" before the first call) */
 const char *amof_last_path(const amof_ctx *ctx);

@@ -355,3 +355,25 @@ def test_rdf_cell_kernel_lattice_on_bin_edges(hip_ctx):
             assert hip_ctx.last_path() == "rdf_cell"
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, 2, rmax, nb, cell_list=True)
         assert np.array_equal(got, ref), (rmax, nb)
+
+
+@pytest.mark.parametrize("eps,jitter", [(0.02, 0.0), (0.10, 0.0), (0.03, 0.004)])
+def test_rdf_sheared_cell_default_cutoff_counts_images(hip_ctx, eps, jitter):
+    # a slightly sheared cell with the reference's default rmax (half the shortest cell LENGTH) needs further
+    # periodic images (rmax > half a cell HEIGHT): the image-aware tile kernel against the exact kernels and the oracle
+    from amof_amd.frames import Frame
+    base = H.replicate(H.zif4_frame(), (2, 2, 2))
+    shear = np.eye(3) + np.array([[0, eps, eps / 2], [0, 0, eps], [0, 0, 0]])
+    sheared = Frame(base.numbers, base.positions @ shear, base.cell @ shear)
+    packed = H.random_walk(sheared, 3, 0.08, 97, cell_jitter=jitter)
+    kinds, sp = H.species_of(packed.numbers)
+    rmax = float(np.min(packed.cell_lengths()) / 2)
+    for nb in (257, 1540):
+        got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        assert hip_ctx.last_path() == "rdf_tile_img"
+        with _env(AMOF_RDF_NOIMG="1"):
+            exact, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_exact"
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
+        assert np.array_equal(exact, ref)
+        assert np.array_equal(got, ref), (eps, nb, int(got.sum()), int(ref.sum()))
