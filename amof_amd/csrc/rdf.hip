@@ -219,6 +219,7 @@ struct RdfFastArgs {
 };
 
 constexpr int FAST_THREADS = 256;
+constexpr int IMG_QUEUE = 1024;     // IMG variant: parked near-face pairs per step (8 KiB of LDS)
 constexpr int FAST_TILE = 512;      // two centre atoms per thread
 
 // candidate bin coordinate q~ = |r_j - r_i| / dr from the fixed-point fractional coordinates
@@ -318,8 +319,11 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
 {
     const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
     if (IMG) {
-        const bool nr = ((uint32_t)ix + near_t[0] > 2u * near_t[0]) | ((uint32_t)iy + near_t[1] > 2u * near_t[1]) |
-                        ((uint32_t)iz + near_t[2] > 2u * near_t[2]);
+        // (axes that are clear of their half height carry the sentinel and are skipped: wave-uniform branches)
+        bool nr = false;
+        if (near_t[0] != 0x7fffffffu) nr |= (uint32_t)ix + near_t[0] > 2u * near_t[0];
+        if (near_t[1] != 0x7fffffffu) nr |= (uint32_t)iy + near_t[1] > 2u * near_t[1];
+        if (near_t[2] != 0x7fffffffu) nr |= (uint32_t)iz + near_t[2] > 2u * near_t[2];
         *near = live && nr;
         live = live && !nr;
     }
@@ -337,7 +341,8 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
                                           float half_m_guard, float nb_hi, uint32_t uax, uint32_t uay,
                                           uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
                                           uint32_t idb, const double *__restrict__ p,
-                                          const uint32_t *near_t = nullptr, int gi = 0)
+                                          const uint32_t *near_t = nullptr, int gi = 0, uint2 *nq = nullptr,
+                                          unsigned *nq_count = nullptr)
 {
     // four partner atoms per trip, read by broadcast before any LDS atomic
     uint4 qj[4];
@@ -364,20 +369,26 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
         }
     }
     if (IMG) {
-        if (anynear) {   // rare: find the pairs again (cheap) and evaluate them canonically, one copy of the code
+        if (anynear) {   // rare: find the pairs again (cheap) and park them for the dense canonical pass of this step
 #pragma unroll 1
             for (int u = 0; u < 4; u++) {
-                const uint4 q = u == 0 ? qj[0] : (u == 1 ? qj[1] : (u == 2 ? qj[2] : qj[3]));
+                const uint4 q = tq[j0 + u];      // (from LDS again: indexing the register copies would spill them)
                 const int j = j0 + u;
                 const bool la = has_a && (!TAIL || j < cntj) && (!DIAG || j > ia);
                 const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
                 auto is_near = [&](uint32_t ux, uint32_t uy, uint32_t uz) {
                     const uint32_t ix = q.x - ux, iy = q.y - uy, iz = q.z - uz;
-                    return (ix + near_t[0] > 2u * near_t[0]) | (iy + near_t[1] > 2u * near_t[1]) |
-                           (iz + near_t[2] > 2u * near_t[2]);
+                    return (near_t[0] != 0x7fffffffu && ix + near_t[0] > 2u * near_t[0]) |
+                           (near_t[1] != 0x7fffffffu && iy + near_t[1] > 2u * near_t[1]) |
+                           (near_t[2] != 0x7fffffffu && iz + near_t[2] > 2u * near_t[2]);
                 };
-                if (la && is_near(uax, uay, uaz)) rdf_pair_images<ORTHO>(hist, fa, g, p, ida, q.w, gi);
-                if (lb && is_near(ubx, uby, ubz)) rdf_pair_images<ORTHO>(hist, fa, g, p, idb, q.w, gi);
+                auto park = [&](uint32_t idc) {
+                    const unsigned slot = atomicAdd(nq_count, 1u);
+                    if (slot < (unsigned)IMG_QUEUE) nq[slot] = make_uint2(idc, q.w);
+                    else rdf_pair_images<ORTHO>(hist, fa, g, p, idc, q.w, gi);   // queue full: evaluate in place
+                };
+                if (la && is_near(uax, uay, uaz)) park(ida);
+                if (lb && is_near(ubx, uby, ubz)) park(idb);
             }
         }
     }
@@ -408,6 +419,9 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     uint4 *tqb = reinterpret_cast<uint4 *>(lds_raw);                         // [2][FAST_TILE]
     uint4 *tcb = tqb + 2 * FAST_TILE;                                        // [2][FAST_SUB]
     unsigned *hist = reinterpret_cast<unsigned *>(tcb + 2 * FAST_SUB);       // [nbins]
+    // IMG: queue of the pairs that need the canonical evaluation (drained densely once per step), two counters
+    uint2 *nq = reinterpret_cast<uint2 *>(hist + ((fa.a.nbins + 1) & ~1));   // [IMG_QUEUE]
+    __shared__ unsigned nq_count[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8), each
@@ -466,6 +480,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     };
 
     const int nsteps = (f1 - f0) * nsub;
+    if (IMG && tid < 2) nq_count[tid] = 0u;
     if (nsteps > 0) { stage_j(f0, 0); stage_c(f0, 0, 0); }
     for (int step = 0, fl = f0, sub = 0; step < nsteps; step++) {
         const int jb = (fl - f0) & 1, cbuf = step & 1;
@@ -489,6 +504,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for this step has landed
         __syncthreads();                                    // everyone's has; the previous step is fully consumed
+        if (IMG && tid == 0) nq_count[(step + 1) & 1] = 0u;  // (last read in the drain of step - 1, next used in step + 1)
         // what the next step needs streams in behind the arithmetic
         {
             const int nsub_next = sub + 1 < nsub ? sub + 1 : 0;
@@ -546,17 +562,27 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
             if (diag) {
                 for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
                     fast_quad<ORTHO, true, true, IMG>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
-                                                      nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p, near_t, gi);
+                                                      nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p, near_t, gi, nq,
+                                                      &nq_count[step & 1]);
             } else {
                 int j0 = qb + 4 * wave;
                 for (; j0 < qe_full; j0 += 16)
                     fast_quad<ORTHO, false, false, IMG>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
                                                         half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p,
-                                                        near_t, gi);
+                                                        near_t, gi, nq, &nq_count[step & 1]);
                 if (j0 == full && j0 < qe && full < cntj)
                     fast_quad<ORTHO, false, true, IMG>(hist, fa, fs, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
                                                        half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p,
-                                                       near_t, gi);
+                                                       near_t, gi, nq, &nq_count[step & 1]);
+            }
+        }
+        if (IMG) {
+            // dense canonical pass over the parked pairs of this step: every lane takes one
+            __syncthreads();
+            const int npark = (int)min(nq_count[step & 1], (unsigned)IMG_QUEUE);
+            for (int e = tid; e < npark; e += FAST_THREADS) {
+                const uint2 pr2 = nq[e];
+                rdf_pair_images<ORTHO>(hist, fa, g, p, pr2.x, pr2.y, gi);
             }
         }
         if (++sub == nsub) { sub = 0; fl++; }
@@ -1284,6 +1310,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int32_t), ctx->stream));
             fa.Q = (const QAtom *)d_Q;
             size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
+            if (fast_img) lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + 1) & ~1) * sizeof(unsigned) +
+                                (size_t)IMG_QUEUE * sizeof(uint2);
             int64_t launches = 0;
             for (int64_t fb = 0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
                 const int64_t nf = std::min<int64_t>(cur, t->n_frames - fb);
