@@ -377,3 +377,15 @@ def test_rdf_sheared_cell_default_cutoff_counts_images(hip_ctx, eps, jitter):
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
         assert np.array_equal(exact, ref)
         assert np.array_equal(got, ref), (eps, nb, int(got.sum()), int(ref.sum()))
+
+
+def test_rdf_image_aware_variant_on_a_plain_case(hip_ctx):
+    # the image-aware variant forced on an input that does not need it: same integers as the plain tile kernel
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (2, 1, 2)), 3, 0.05, 98, ortho=True)
+    with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
+        plain, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, 700)
+        assert hip_ctx.last_path() == "rdf_tile"
+        with _env(AMOF_RDF_FORCE_IMG="1"):
+            img, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, 700)
+            assert hip_ctx.last_path() == "rdf_tile_img"
+    assert np.array_equal(plain, img)
