@@ -994,6 +994,15 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             !(force && strcmp(force, "v1") == 0) && max_img <= 124 && !getenv("AMOF_RDF_NOIMG")) {
             fast_img = true;
             near_thr.assign((size_t)nc * 3, 0x7fffffffu);
+            for (int64_t k = 0; k < nc && fast_img; k++) {
+                double share = 0.0;      // expected share of the pairs that go the canonical way
+                for (int x = 0; x < 3; x++) {
+                    const double h = geom.rec[(size_t)k * GEOM_STRIDE + 18 + x];
+                    share += 2.0 * std::max(0.0, rmax / h - 0.5);
+                }
+                // the parking queue holds 1024 of a step's 65 536 pairs; beyond that the exact kernels are the better choice
+                if (share > 0.03) fast_img = false;
+            }
             for (int64_t k = 0; k < nc && fast_img; k++)
                 for (int x = 0; x < 3; x++) {
                     const double h = geom.rec[(size_t)k * GEOM_STRIDE + 18 + x];
