@@ -216,10 +216,13 @@ struct RdfFastArgs {
     double guard64;          // g_m (bins): f64-from-fixed-point candidate
     int32_t xcd_map;         // 1: chunk -> XCD affinity mapping of the grid
     int32_t n_chunks;        // tile kernel: frames [c nf / n_chunks, (c+1) nf / n_chunks) belong to chunk c
+    int32_t img_queue;       // IMG variant: capacity of one parking buffer
+    int32_t img_defer;       // 1: two small buffers, a step's parked pairs are evaluated at the start of the next step
+                             // (no extra barrier); 0: one large buffer, evaluated at the end of the step
 };
 
 constexpr int FAST_THREADS = 256;
-constexpr int IMG_QUEUE = 1024;     // IMG variant: parked near-face pairs per step (8 KiB of LDS)
+constexpr int IMG_QUEUE_MAX = 1024; // IMG variant: parked near-face pairs per step and buffer (capacity chosen by the host)
 constexpr int FAST_TILE = 512;      // two centre atoms per thread
 
 // candidate bin coordinate q~ = |r_j - r_i| / dr from the fixed-point fractional coordinates
@@ -342,7 +345,7 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
                                           uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
                                           uint32_t idb, const double *__restrict__ p,
                                           const uint32_t *near_t = nullptr, int gi = 0, uint2 *nq = nullptr,
-                                          unsigned *nq_count = nullptr)
+                                          unsigned *nq_count = nullptr, unsigned nq_cap = 0)
 {
     // four partner atoms per trip, read by broadcast before any LDS atomic
     uint4 qj[4];
@@ -384,7 +387,7 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
                 };
                 auto park = [&](uint32_t idc) {
                     const unsigned slot = atomicAdd(nq_count, 1u);
-                    if (slot < (unsigned)IMG_QUEUE) nq[slot] = make_uint2(idc, q.w);
+                    if (slot < nq_cap) nq[slot] = make_uint2(idc, q.w);
                     else rdf_pair_images<ORTHO>(hist, fa, g, p, idc, q.w, gi);   // queue full: evaluate in place
                 };
                 if (la && is_near(uax, uay, uaz)) park(ida);
@@ -420,8 +423,11 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     uint4 *tcb = tqb + 2 * FAST_TILE;                                        // [2][FAST_SUB]
     unsigned *hist = reinterpret_cast<unsigned *>(tcb + 2 * FAST_SUB);       // [nbins]
     // IMG: queue of the pairs that need the canonical evaluation (drained densely once per step), two counters
-    uint2 *nq = reinterpret_cast<uint2 *>(hist + ((fa.a.nbins + 1) & ~1));   // [IMG_QUEUE]
-    __shared__ unsigned nq_count[2];
+    // (two buffers: a step parks into one while the previous step's is drained; three counters so that one can be
+    // reset a whole step away from its last reader and its next writer)
+    uint2 *nq_base = reinterpret_cast<uint2 *>(hist + ((fa.a.nbins + 1) & ~1));   // [2][img_queue]
+    const unsigned nq_cap = (unsigned)fa.img_queue;
+    __shared__ unsigned nq_count[3];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8), each
@@ -480,7 +486,9 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     };
 
     const int nsteps = (f1 - f0) * nsub;
-    if (IMG && tid < 2) nq_count[tid] = 0u;
+    if (IMG && tid < 3) nq_count[tid] = 0u;
+    const double *p_prev = nullptr, *g_prev = nullptr;
+    int gi_prev = 0;
     if (nsteps > 0) { stage_j(f0, 0); stage_c(f0, 0, 0); }
     for (int step = 0, fl = f0, sub = 0; step < nsteps; step++) {
         const int jb = (fl - f0) & 1, cbuf = step & 1;
@@ -504,7 +512,21 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for this step has landed
         __syncthreads();                                    // everyone's has; the previous step is fully consumed
-        if (IMG && tid == 0) nq_count[(step + 1) & 1] = 0u;  // (last read in the drain of step - 1, next used in step + 1)
+        if (IMG) {
+            // what the previous step parked is complete (barrier above): dense canonical pass, one pair per lane,
+            // while this step parks into the other buffer; the counter of step + 1 was last read a step ago
+            if (tid == 0) nq_count[(step + 1) % 3] = 0u;
+            if (fa.img_defer && step > 0) {
+                const uint2 *nqp = nq_base + (size_t)((step - 1) & 1) * nq_cap;
+                const int npark = (int)min(nq_count[(step - 1) % 3], nq_cap);
+                for (int e = tid; e < npark; e += FAST_THREADS) {
+                    const uint2 pr2 = nqp[e];
+                    rdf_pair_images<ORTHO>(hist, fa, g_prev, p_prev, pr2.x, pr2.y, gi_prev);
+                }
+            }
+            p_prev = p; g_prev = g; gi_prev = gi;
+        }
+        uint2 *nq = nq_base + (fa.img_defer ? (size_t)(step & 1) * nq_cap : 0);
         // what the next step needs streams in behind the arithmetic
         {
             const int nsub_next = sub + 1 < nsub ? sub + 1 : 0;
@@ -563,29 +585,38 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                 for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
                     fast_quad<ORTHO, true, true, IMG>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
                                                       nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p, near_t, gi, nq,
-                                                      &nq_count[step & 1]);
+                                                      &nq_count[step % 3], nq_cap);
             } else {
                 int j0 = qb + 4 * wave;
                 for (; j0 < qe_full; j0 += 16)
                     fast_quad<ORTHO, false, false, IMG>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
                                                         half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p,
-                                                        near_t, gi, nq, &nq_count[step & 1]);
+                                                        near_t, gi, nq, &nq_count[step % 3], nq_cap);
                 if (j0 == full && j0 < qe && full < cntj)
                     fast_quad<ORTHO, false, true, IMG>(hist, fa, fs, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
                                                        half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p,
-                                                       near_t, gi, nq, &nq_count[step & 1]);
+                                                       near_t, gi, nq, &nq_count[step % 3], nq_cap);
             }
         }
-        if (IMG) {
-            // dense canonical pass over the parked pairs of this step: every lane takes one
+        if (IMG && !fa.img_defer) {
+            // large shares: dense canonical pass over this step's parked pairs right away (one more barrier per step)
             __syncthreads();
-            const int npark = (int)min(nq_count[step & 1], (unsigned)IMG_QUEUE);
+            const int npark = (int)min(nq_count[step % 3], nq_cap);
             for (int e = tid; e < npark; e += FAST_THREADS) {
                 const uint2 pr2 = nq[e];
                 rdf_pair_images<ORTHO>(hist, fa, g, p, pr2.x, pr2.y, gi);
             }
         }
         if (++sub == nsub) { sub = 0; fl++; }
+    }
+    if (IMG && fa.img_defer && nsteps > 0) {   // the last step's parked pairs
+        __syncthreads();
+        const uint2 *nqp = nq_base + (size_t)((nsteps - 1) & 1) * nq_cap;
+        const int npark = (int)min(nq_count[(nsteps - 1) % 3], nq_cap);
+        for (int e = tid; e < npark; e += FAST_THREADS) {
+            const uint2 pr2 = nqp[e];
+            rdf_pair_images<ORTHO>(hist, fa, g_prev, p_prev, pr2.x, pr2.y, gi_prev);
+        }
     }
     __syncthreads();
     unsigned long long *U = a.U + ((size_t)ti.species * a.S + tj.species) * (size_t)nbins;
@@ -989,6 +1020,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         // face are evaluated canonically (base + every listed image); all others can only have their base image
         // in range, and that base is unambiguous.  near_thr[cell][axis]: fixed-point threshold on |i_k|.
         bool fast_img = false;
+        double img_share = 0.0;
         std::vector<uint32_t> near_thr;
         if (!fast && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS - 5120 && guard_f < 0.25 &&
             !(force && strcmp(force, "v1") == 0) && max_img <= 124 && !getenv("AMOF_RDF_NOIMG")) {
@@ -1002,6 +1034,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 }
                 // the parking queue holds 1024 of a step's 65 536 pairs; beyond that the exact kernels are the better choice
                 if (share > 0.03) fast_img = false;
+                img_share = std::max(img_share, share);
             }
             for (int64_t k = 0; k < nc && fast_img; k++)
                 for (int x = 0; x < 3; x++) {
@@ -1319,8 +1352,19 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int32_t), ctx->stream));
             fa.Q = (const QAtom *)d_Q;
             size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
-            if (fast_img) lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + 1) & ~1) * sizeof(unsigned) +
-                                (size_t)IMG_QUEUE * sizeof(uint2);
+            fa.img_queue = 0;
+            fa.img_defer = 0;
+            if (fast_img) {
+                // expected number of parked pairs per step (a step is 128 x 512 pairs).  Slightly sheared cells: two
+                // buffers of >= 96 entries, evaluated a step later -- small enough for five workgroups per CU and no
+                // extra barrier; larger shares: one buffer of 1024, evaluated at the end of the step.
+                const double expect = img_share * (double)FAST_SUB * FAST_TILE;
+                const double want = std::max(96.0, ceil(4.0 * expect / 32.0) * 32.0);
+                fa.img_defer = want <= 256.0 ? 1 : 0;
+                fa.img_queue = fa.img_defer ? (int32_t)want : IMG_QUEUE_MAX;
+                lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + 1) & ~1) * sizeof(unsigned) +
+                      (fa.img_defer ? 2 : 1) * (size_t)fa.img_queue * sizeof(uint2);
+            }
             int64_t launches = 0;
             for (int64_t fb = 0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
                 const int64_t nf = std::min<int64_t>(cur, t->n_frames - fb);
