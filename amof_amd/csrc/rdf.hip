@@ -1,16 +1,21 @@
 // RDF pair-distance histogram kernels (gfx950).
 //
-// Replaces asap3's RawRDF as driven by the reference at amof/rdf.py:88-93.
+// Replaces asap3's RawRDF as driven by the reference at amof/rdf.py:88-93.  Kernel families, picked per call by
+// rdf_run (amof_last_path names the one that produced the result):
+//   rdf_exact      rdf_tile_kernel<ORTHO,EXTRA> / rdf_tile_kernel_global: canonical float64 arithmetic per pair and
+//                  per periodic image; partially periodic cells, large image shares, nbins beyond the LDS histogram
+//   rdf_tile       rdf_tile_kernel_fast<ORTHO,CULL>: 32-bit fixed-point minimum image, f32 candidate bins with an
+//                  exact re-decision near every edge, slab-sorted tiles by LDS-DMA (the headline, half-cell cutoffs)
+//   rdf_tile_img   the same with IMG = true: cutoffs beyond half a cell height (sheared cells at the default
+//                  cutoff); pairs within reach of a cell face are parked and evaluated canonically, images included
+//   rdf_range      rdf_range_kernel_fast: 2-level (slab x y-bin) cell list for small cutoffs
+//   rdf_cell       rdf_cell_kernel: 3-D cell list, one lane per centre atom, for cutoffs far below the cell size
 //
-// Work decomposition: atoms are sorted by species once per call (the species
-// of an atom never change along a trajectory) and cut into species-pure tiles
-// of <= 256 atoms.  A workgroup owns ONE unordered tile pair (I <= J) and a
-// chunk of consecutive frames: every thread keeps one atom of tile I in
-// registers, tile J is staged in LDS and read by broadcast, and the pair's
-// species key is uniform per workgroup, so a single nbins-wide u32 histogram in
-// LDS serves the whole workgroup.  It is flushed with u64 global atomics once
-// per frame chunk.  Nothing but the 24*N bytes of a frame is read from HBM per
-// frame; every frame is re-read ~2*ntiles times from L2, never from HBM.
+// Common decomposition of the tile kernels: atoms are sorted by species once per call (the species of an atom never
+// change along a trajectory) and cut into species-pure tiles.  A workgroup owns ONE unordered tile pair (I <= J) and
+// a chunk of consecutive frames; tile J is staged in LDS and read by broadcast, and the pair's species key is uniform
+// per workgroup, so a single nbins-wide u32 histogram in LDS serves the whole workgroup.  It is flushed with u64
+// global atomics once per frame chunk.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
