@@ -28,7 +28,7 @@ ABI_VERSION = 1
 
 EXPORTS = [
     "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_destroy", "amof_last_error",
-    "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_last_kernel_seconds", "amof_last_kernel_launches",
+    "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_ctx_wait_stream", "amof_last_kernel_seconds", "amof_last_kernel_launches",
     "amof_last_path",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_bad_hist_by_cn",
@@ -92,6 +92,7 @@ def load_library():
         lib.amof_last_error.restype = ctypes.c_char_p
         lib.amof_ctx_set_stream.argtypes = [P, P]
         lib.amof_ctx_synchronize.argtypes = [P]
+        lib.amof_ctx_wait_stream.argtypes = [P, P]
         lib.amof_last_kernel_seconds.argtypes = [P, ctypes.c_int]
         lib.amof_last_kernel_seconds.restype = ctypes.c_double
         lib.amof_last_kernel_launches.argtypes = [P]
@@ -139,7 +140,11 @@ class _TrajHandle(object):
     def __init__(self, packed, frame_range=None):
         assert isinstance(packed, PackedTrajectory)
         f0, f1 = (0, packed.n_frames) if frame_range is None else frame_range
-        self.kinds, self.species = species_index(packed.numbers)
+        cached = getattr(packed, "_abi_species", None)     # numbers never change after construction
+        if cached is None:
+            cached = species_index(packed.numbers)
+            packed._abi_species = cached
+        self.kinds, self.species = cached
         pos = packed.pos
         cell = packed.cell if packed.cell.shape[0] == 1 else packed.cell[f0:f1]
         self.cell = np.ascontiguousarray(cell, dtype=np.float64)
@@ -242,6 +247,30 @@ class Context(object):
         self._check(self._lib.amof_ctx_synchronize(self._h))
 
     @_locked
+    def wait_stream(self, stream_ptr):
+        """Order this context's stream after the work queued so far on another HIP stream."""
+        self._check(self._lib.amof_ctx_wait_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
+
+    def _order_after_torch(self):
+        """device outputs (``out=`` tensors) were zeroed / last written by torch: run after that.  The "_dev" entry
+        points are synchronous like all others, so torch work queued afterwards needs no further ordering."""
+        import torch
+        self.wait_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _traj(self, packed, frame_range=None):
+        """``_TrajHandle`` of a trajectory this context may read.  A device-resident ``pos`` must live on this
+        context's GPU, and the context's (non-blocking) stream is ordered after torch's current stream on that
+        device, i.e. after whatever produced the tensor (generation kernels, a peer copy, ``.to()``)."""
+        th = self._traj(packed, frame_range)
+        if th.device_index is not None:
+            if th.device_index != self.device:
+                raise ValueError("trajectory positions live on cuda:%d but this context drives cuda:%d; use "
+                                 "device=%d or copy the trajectory" % (th.device_index, self.device, th.device_index))
+            import torch
+            self.wait_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        return th
+
+    @_locked
     def last_kernel_seconds(self, dominant=True):
         return self._lib.amof_last_kernel_seconds(self._h, 1 if dominant else 0)
 
@@ -261,11 +290,12 @@ class Context(object):
 
         ``out``: optional torch CUDA int64 tensor ``[S][S][nbins]`` to
         accumulate into on the device (stays resident for an RCCL merge)."""
-        th = _TrajHandle(packed, frame_range)
+        th = self._traj(packed, frame_range)
         vol = ctypes.c_double(0.0)
         if out is not None:
             assert out.is_cuda and out.is_contiguous() and out.numel() == th.S * th.S * nbins
-            self.use_torch_stream()
+            assert out.device.index == self.device and out.element_size() == 8
+            self._order_after_torch()
             rc = self._lib.amof_rdf_accumulate_dev(self._h, ctypes.byref(th.c), float(rmax), int(nbins),
                                                    ctypes.c_void_p(out.data_ptr()), ctypes.byref(vol))
             self._check(rc)
@@ -278,7 +308,7 @@ class Context(object):
 
     @_locked
     def cn_count(self, packed, cutoff, sets, frame_range=None, per_atom=False):
-        th = _TrajHandle(packed, frame_range)
+        th = self._traj(packed, frame_range)
         cutoff = np.ascontiguousarray(cutoff, dtype=np.float64).reshape(th.S, th.S)
         sets = np.ascontiguousarray(sets, dtype=np.int32).reshape(-1, 2)
         sums = np.zeros((th.n_frames, len(sets)), dtype=np.int64)
@@ -292,14 +322,17 @@ class Context(object):
 
     @_locked
     def bad_hist(self, packed, cutoff, triples, edges, frame_range=None, out=None):
-        th = _TrajHandle(packed, frame_range)
+        th = self._traj(packed, frame_range)
         cutoff = np.ascontiguousarray(cutoff, dtype=np.float64).reshape(th.S, th.S)
         triples = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 2)
         edges = np.ascontiguousarray(edges, dtype=np.float64)
         nb = len(edges) - 1
         if out is not None:
             hist_t, nang_t = out
-            self.use_torch_stream()
+            for x, n in ((hist_t, len(triples) * nb), (nang_t, len(triples))):
+                assert x.is_cuda and x.is_contiguous() and x.numel() == n and x.element_size() == 8
+                assert x.device.index == self.device
+            self._order_after_torch()
             rc = self._lib.amof_bad_hist_dev(self._h, ctypes.byref(th.c), ctypes.c_void_p(cutoff.ctypes.data),
                                              ctypes.c_void_p(triples.ctypes.data), len(triples),
                                              ctypes.c_void_p(edges.ctypes.data), nb,
@@ -318,7 +351,7 @@ class Context(object):
     @_locked
     def bad_hist_by_cn(self, packed, cutoff, triples, edges, cn_max=16, frame_range=None):
         """``(hist u64 [T][cn_max+1][nb], n_angles u64 [T][cn_max+1])`` keyed by neighbour count."""
-        th = _TrajHandle(packed, frame_range)
+        th = self._traj(packed, frame_range)
         cutoff = np.ascontiguousarray(cutoff, dtype=np.float64).reshape(th.S, th.S)
         triples = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 2)
         edges = np.ascontiguousarray(edges, dtype=np.float64)
@@ -335,7 +368,7 @@ class Context(object):
     @_locked
     def msd_window(self, packed, windows, unwrap=False, remove_com=True, atom_range=None):
         """``(sumsq [S][W] f64, kinds)``: raw sums of squared displacements."""
-        th = _TrajHandle(packed)
+        th = self._traj(packed)
         windows = np.ascontiguousarray(windows, dtype=np.int32)
         a0, a1 = (0, th.n_atoms) if atom_range is None else atom_range
         out = np.zeros((th.S, len(windows)), dtype=np.float64)
@@ -349,7 +382,7 @@ class Context(object):
     @_locked
     def msd_direct(self, packed):
         """``(msd [F][S+1] f64, kinds)``: column 0 = all atoms, then one per species."""
-        th = _TrajHandle(packed)
+        th = self._traj(packed)
         out = np.zeros((th.n_frames, th.S + 1), dtype=np.float64)
         self._check(self._lib.amof_msd_direct(self._h, ctypes.byref(th.c), ctypes.c_void_p(out.ctypes.data)))
         return out, th.kinds
@@ -489,8 +522,10 @@ def get_context(device=None):
             return ctx
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
-        if device >= max(device_count(), 1):
-            device = 0
+        n = device_count()
+        if n > 0 and device >= n:
+            raise RuntimeError("LOCAL_RANK=%d but only %d GPU(s) are visible: refusing to pile every rank onto "
+                               "cuda:0 (pass device= explicitly to share a GPU on purpose)" % (device, n))
     with _ctx_lock:
         ctx = _contexts.get(device)
         if ctx is None:

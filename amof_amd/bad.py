@@ -109,17 +109,28 @@ class Bad(CoreBad):
             triples.append((ia, ib))
 
         rank, world = (0, 1) if distributed is False else _dist.world()
+        merge = distributed is not False and _dist.merging(world)
         F = len(packed)
-        frame_range = _dist.shard_range(F, rank, world) if (world > 1 and distributed != 'local') else (0, F)
+        frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
         dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
         ctx = _hip.get_context(dev)
-        if triples:
-            hist, nang = ctx.bad_hist(packed, rcm, triples, theta_bins, frame_range=frame_range)
+        if triples and merge and _dist.device_collectives():
+            # counts stay in HBM from the kernels through ONE RCCL all-reduce (amof_bad_hist_dev)
+            import torch
+            T, nb = len(triples), bins + 1
+            both = torch.zeros(T * nb + T, dtype=torch.int64, device=torch.device("cuda", ctx.device))
+            ctx.bad_hist(packed, rcm, triples, theta_bins, frame_range=frame_range, out=(both[:T * nb], both[T * nb:]))
+            _dist.all_reduce_sum(both)
+            both = both.cpu().numpy().view(np.uint64)
+            hist, nang = both[:T * nb].reshape(T, nb), both[T * nb:]
         else:
-            hist, nang = np.zeros((0, bins + 1), dtype=np.uint64), np.zeros(0, dtype=np.uint64)
-        if world > 1:
-            hist = _dist.all_reduce_sum(hist)
-            nang = _dist.all_reduce_sum(nang)
+            if triples:
+                hist, nang = ctx.bad_hist(packed, rcm, triples, theta_bins, frame_range=frame_range)
+            else:
+                hist, nang = np.zeros((0, bins + 1), dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+            if merge:
+                hist = _dist.all_reduce_sum(hist)
+                nang = _dist.all_reduce_sum(nang)
         self.hist = hist
         self.n_angles = nang
         self.columns = names
@@ -191,8 +202,9 @@ class BadByCn(CoreBad):
             names.append("-".join([_symbol(C) for C in [B, A, B]]))
             triples.append((ia, ib))
         rank, world = (0, 1) if distributed is False else _dist.world()
+        merge = distributed is not False and _dist.merging(world)
         F = len(packed)
-        frame_range = _dist.shard_range(F, rank, world) if (world > 1 and distributed != 'local') else (0, F)
+        frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
         dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
         ctx = _hip.get_context(dev)
         if triples:
@@ -200,7 +212,7 @@ class BadByCn(CoreBad):
         else:
             hist = np.zeros((0, self.CN_MAX + 1, bins + 1), dtype=np.uint64)
             nang = np.zeros((0, self.CN_MAX + 1), dtype=np.uint64)
-        if world > 1:
+        if merge:
             hist = _dist.all_reduce_sum(hist)
             nang = _dist.all_reduce_sum(nang)
         if nang.size and nang[:, self.CN_MAX].any():

@@ -66,13 +66,14 @@ class CoordinationNumber(object):
         live = [s for s in sets if s is not None]
 
         rank, world = (0, 1) if distributed is False else _dist.world()
+        merge = distributed is not False and _dist.merging(world)
         F = len(packed)
-        frame_range = _dist.shard_range(F, rank, world) if (world > 1 and distributed != 'local') else (0, F)
+        frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
         dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
         ctx = _hip.get_context(dev)
         sums = ctx.cn_count(packed, rcm, live, frame_range=frame_range) if live else \
             np.zeros((frame_range[1] - frame_range[0], 0), dtype=np.int64)
-        if world > 1 and distributed != 'local':
+        if merge and distributed != 'local':
             sums = _dist.all_gather_rows(sums)
 
         data = {'Step': np.asarray(step)[:len(sums)] if distributed == 'local' else step}

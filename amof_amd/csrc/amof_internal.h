@@ -54,6 +54,7 @@ struct amof_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // host -> device staging that overlaps the kernels of the previous batch
     hipEvent_t ev_copy = nullptr;
+    hipEvent_t ev_order = nullptr;       // amof_ctx_wait_stream
     hipEvent_t ev_all0 = nullptr, ev_all1 = nullptr, ev_dom0 = nullptr, ev_dom1 = nullptr;
     bool ev_valid = false;
     int64_t dom_launches = 0;

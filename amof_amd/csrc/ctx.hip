@@ -310,7 +310,8 @@ int amof_ctx_create(int device, amof_ctx **out)
     }
     ctx->stream = ctx->own_stream;
     if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming) != hipSuccess) {
         amof_ctx_destroy(ctx);
         return AMOF_EHIP;
     }
@@ -336,6 +337,7 @@ void amof_ctx_destroy(amof_ctx *ctx)
     if (ctx->ev_dom0) (void)hipEventDestroy(ctx->ev_dom0);
     if (ctx->ev_dom1) (void)hipEventDestroy(ctx->ev_dom1);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -347,6 +349,16 @@ int amof_ctx_set_stream(amof_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return AMOF_EINVAL;
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return AMOF_OK;
+}
+
+int amof_ctx_wait_stream(amof_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return AMOF_EINVAL;
+    if ((hipStream_t)hip_stream == ctx->stream) return AMOF_OK;   // same queue: already ordered
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    AMOF_HIP_TRY(ctx, hipEventRecord(ctx->ev_order, (hipStream_t)hip_stream));
+    AMOF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
     return AMOF_OK;
 }
 

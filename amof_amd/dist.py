@@ -5,6 +5,8 @@ Frames are independent for RDF / BAD / CN, atoms are independent for MSD
 histograms (or of the S x W float64 MSD partial sums): one all-reduce.
 """
 
+import os
+
 import numpy as np
 
 
@@ -27,6 +29,13 @@ def world(group=None):
     return d.get_rank(group), d.get_world_size(group)
 
 
+def merging(world_size):
+    """True when results must be merged over the ranks.  ``AMOF_DIST_FORCE_MERGE=1`` also runs the whole sharding +
+    collective path in a one-rank group -- the only way to drive the real RCCL calls on a single-GPU test box
+    (RCCL refuses two ranks on one device)."""
+    return world_size > 1 or (os.environ.get("AMOF_DIST_FORCE_MERGE") == "1" and _dist() is not None)
+
+
 def shard_range(n, rank, world_size):
     """Contiguous shard ``[lo, hi)`` of ``n`` units: unit u goes to rank
     floor(u * G / n)."""
@@ -35,8 +44,18 @@ def shard_range(n, rank, world_size):
     return lo, min(hi, n)
 
 
+def device_collectives(group=None):
+    """True when the group's backend moves CUDA tensors (nccl = RCCL): results can then stay in HBM from the
+    kernel that produced them through the all-reduce (no D2H / H2D hop in between)."""
+    d = _dist()
+    return d is not None and d.get_backend(group) == "nccl"
+
+
 def all_reduce_sum(x, group=None):
     """Sum ``x`` over ranks and return it (same type as given).
+
+    A torch tensor is reduced in place where it lives (a CUDA tensor over RCCL: the device-resident merge of the
+    histograms written by the "_dev" entry points).
 
     numpy arrays travel through a CPU tensor (gloo) or, when the backend is
     nccl (= RCCL on ROCm), through a CUDA tensor on the current device.
@@ -76,6 +95,25 @@ def all_gather_rows(x, group=None):
     d = _dist()
     if d is None:
         return x
-    gathered = [None] * d.get_world_size(group)
+    world = d.get_world_size(group)
+    if d.get_backend(group) == "nccl" and x.dtype.kind in "iu" and x.dtype.itemsize == 8:
+        # two tensor all-gathers over RCCL (row counts, then the blocks padded to the largest count) instead of
+        # pickled objects
+        import torch
+        n = torch.tensor([x.shape[0]], dtype=torch.int64).cuda()
+        counts = torch.empty(world, dtype=torch.int64, device=n.device)
+        d.all_gather_into_tensor(counts, n, group=group)
+        counts = counts.cpu().numpy()
+        rows = int(counts.max())
+        cols = int(np.prod(x.shape[1:]))
+        mine = torch.zeros((rows, cols), dtype=torch.int64)
+        mine[:x.shape[0]] = torch.from_numpy(np.ascontiguousarray(x).view(np.int64).reshape(x.shape[0], cols))
+        mine = mine.cuda()
+        full = torch.empty((world * rows, cols), dtype=torch.int64, device=mine.device)
+        d.all_gather_into_tensor(full, mine, group=group)
+        full = full.cpu().numpy().reshape(world, rows, cols)
+        out = np.concatenate([full[r, :counts[r]] for r in range(world)], axis=0)
+        return out.view(x.dtype).reshape((out.shape[0],) + x.shape[1:])
+    gathered = [None] * world
     d.all_gather_object(gathered, x, group=group)
     return np.concatenate(gathered, axis=0)

@@ -140,13 +140,14 @@ class WindowMsd(Msd):
         logger.info("Start computing msd at %s times on a trajectory of %s frames", len(window), len(packed))
 
         rank, world = (0, 1) if distributed is False else _dist.world()
+        merge = distributed is not False and _dist.merging(world)
         N, F = packed.n_atoms, len(packed)
-        atom_range = _dist.shard_range(N, rank, world) if world > 1 and distributed != 'local' else (0, N)
+        atom_range = _dist.shard_range(N, rank, world) if merge and distributed != 'local' else (0, N)
         dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
         ctx = _hip.get_context(dev)
         sumsq, kinds = ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
                                       atom_range=atom_range)
-        if world > 1 and distributed != 'local':
+        if merge and distributed != 'local':
             sumsq = _dist.all_reduce_sum(sumsq)
         self.sumsq = sumsq
         idx = {z: k for k, z in enumerate(kinds)}

@@ -84,10 +84,11 @@ class Rdf(object):
         atomic_numbers_unique = list(set(packed.numbers))
         N_species = len(atomic_numbers_unique)
         rank, world = (0, 1) if distributed is False else _dist.world()
+        merge = distributed is not False and _dist.merging(world)
 
         # min over ALL frames of the three cell lengths, halved (amof/rdf.py:74)
         rmax_half_cell = np.min(packed.cell_lengths()) / 2
-        if distributed == 'local' and world > 1:
+        if distributed == 'local' and merge:
             rmax_half_cell = _dist.all_reduce_min(rmax_half_cell)
         if isinstance(rmax, str) and rmax == 'half_cell':
             rmax = rmax_half_cell
@@ -104,18 +105,31 @@ class Rdf(object):
             raise ValueError("rmax // dr gives no bin")
 
         F_local = len(packed)
-        if world > 1 and distributed != 'local':
+        if merge and distributed != 'local':
             frame_range = _dist.shard_range(F_local, rank, world)
         else:
             frame_range = (0, F_local)
         dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
         ctx = _hip.get_context(dev)
-        hist, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range)
         n_frames = frame_range[1] - frame_range[0]
-        if world > 1:
-            hist = _dist.all_reduce_sum(hist)
-            tot = _dist.all_reduce_sum(np.array([vol_sum, float(n_frames)]))
+        if merge and _dist.device_collectives():
+            # the histogram stays in HBM from the kernels through the RCCL all-reduce (amof_rdf_accumulate_dev)
+            import torch
+            S = len(_hip.species_index(packed.numbers)[0])
+            out = torch.zeros((S, S, bins), dtype=torch.int64, device=torch.device("cuda", ctx.device))
+            _, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range, out=out)
+            tot = torch.tensor([vol_sum, float(n_frames)], dtype=torch.float64).to(out.device)
+            _dist.all_reduce_sum(out)
+            _dist.all_reduce_sum(tot)
+            hist = out.cpu().numpy().view(np.uint64)
+            tot = tot.cpu().numpy()
             vol_sum, n_frames = float(tot[0]), int(round(tot[1]))
+        else:
+            hist, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range)
+            if merge:
+                hist = _dist.all_reduce_sum(hist)
+                tot = _dist.all_reduce_sum(np.array([vol_sum, float(n_frames)]))
+                vol_sum, n_frames = float(tot[0]), int(round(tot[1]))
         self.hist = hist                      # integer ordered-pair counts [S][S][bins]
         self.kinds = kinds
         self.n_frames = n_frames

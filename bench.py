@@ -11,15 +11,24 @@ that is already resident in HBM (BASELINE.json configs[2], the headline
 config: 3x3x4 ZIF-4 supercell = 9792 atoms, 5000 frames, Gaussian random walk
 sigma = 0.05 A/frame/axis wrapped into a constant orthorhombic cell).
 
-N > 1 (weak scaling): every rank owns its own block of 5000 frames (frames
-shard embarrassingly); the only data-path collective is the RCCL all-reduce of
-the integer RDF histograms at the end of each step.  MSD couples frames, so
-each rank's block is its own time series (no collective).
+N > 1 -- STRONG scaling of the same job: every rank
+generates the same 5000-frame trajectory (same seed) in its own HBM; RDF (and
+BAD / CN) shard the FRAMES, one RCCL all-reduce of the integer histograms that
+never leave HBM in between; MSD shards the ATOMS, one all-reduce of the S x W
+float64 sums.  ``value`` = 5000 frames / step time, whatever N is.
+``--scaling weak`` instead gives every rank its own 5000-frame block.
 
-Rank 0 prints ONE JSON line (see the keys below).  ``roofline`` is computed for
-the dominant kernel (the RDF tile kernel) from HIP events recorded inside the
-library on the launching stream; ``cpu_baseline`` times the CPU oracle on a
-bounded sample on this box's host cores (N = 1 only).
+After the RDF+MSD steps the same K steps are repeated with
+``Bad({'Zn-N': 2.5}, dtheta=0.05)`` added (BASELINE configs[3]) and reported
+under ``configs3`` -- never in ``value``, so that the metric means the same
+work at every N.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is computed for the dominant kernel
+(the RDF tile kernel) from HIP events recorded inside the library on the
+launching stream; ``cpu_baseline`` times the CPU oracle on a bounded sample on
+this box's host cores (N = 1 only); ``verified`` says whether the timed results
+themselves were tied to the oracle after the timed region (frames sampled by
+leave-one-out for RDF, an atom slice for MSD).
 """
 
 import argparse
@@ -35,42 +44,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VALU_PEAK = 78.6e12    # flop/s, vector FP64 (half the 157.3 TF FP32 vector rate)
+CLOCK_HZ = 2.4e9            # nominal engine clock
+N_SIMD = 1024               # 256 CUs x 4 SIMDs
 
 
 def make_trajectory(device, reps, n_frames, sigma, seed):
     """Synthetic trajectory generated directly in HBM (torch), float64."""
-    import torch
-    from amof_amd.frames import PackedTrajectory
-    from amof_amd.io import read_extxyz
-    base = read_extxyz(os.path.join(ROOT, "tests", "golden", "ZIF-4.xyz"), 0)
-    pos, num = [], []
-    for a in range(reps[0]):
-        for b in range(reps[1]):
-            for c in range(reps[2]):
-                pos.append(base.positions + a * base.cell[0] + b * base.cell[1] + c * base.cell[2])
-                num.append(base.numbers)
-    pos0 = np.concatenate(pos)
-    numbers = np.concatenate(num)
-    lengths = np.diag(base.cell) * np.array(reps)          # constant orthorhombic cell
-    cell = np.diag(lengths)
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    n = len(numbers)
-    L = torch.tensor(lengths, dtype=torch.float64, device=device)
-    traj = torch.empty((n_frames, n, 3), dtype=torch.float64, device=device)
-    cur = torch.tensor(pos0, dtype=torch.float64, device=device)   # unwrapped position of the last frame
-    chunk = 250
-    for f0 in range(0, n_frames, chunk):
-        f1 = min(f0 + chunk, n_frames)
-        steps = torch.randn((f1 - f0, n, 3), dtype=torch.float64, device=device, generator=g) * sigma
-        if f0 == 0:
-            steps[0] = 0.0                                  # frame 0 is the base structure
-        walk = cur + torch.cumsum(steps, dim=0)
-        cur = walk[-1].clone()
-        traj[f0:f1] = walk - torch.floor(walk / L) * L     # wrapped into the cell
-        del steps, walk
-    return PackedTrajectory(traj, cell, numbers)
+    from tests import helpers as H
+    return H.device_walk(device, reps, n_frames, sigma, seed)
 
 
 def cpu_baseline(packed, rmax, nbins, window, rdf_frames):
@@ -140,6 +121,133 @@ def cpu_baseline(packed, rmax, nbins, window, rdf_frames):
     }
 
 
+def verify(packed, ctx, rdf, msd, frames):
+    """Tie the TIMED results to the oracle (run after the timed region, on rank 0, which holds the whole
+    trajectory in strong-scaling mode).  RDF: for sampled frames k,  H[0,k) + oracle(k) + H[k+1,F) must equal the
+    timed histogram bit for bit (the two big partial launches run at the bench's own launch geometry).  MSD: the
+    GPU sums of the first 272-atom replica equal the numpy restatement (rtol 1e-9) and the atom slices of the whole
+    system add up to the timed sums."""
+    from oracle import clib, numpy_oracle as no
+    from tests import helpers as H
+    import torch
+    F, N = packed.n_frames, packed.n_atoms
+    kinds, sp = H.species_of(packed.numbers)
+    nb = len(rdf.data)
+    out = {"rdf_frames": [int(k) for k in frames], "rdf": True, "msd": True}
+    pos_s = packed.pos[torch.as_tensor(np.asarray(frames), device=packed.pos.device)].cpu().numpy()
+    timed = np.asarray(rdf.hist).view(np.uint64)
+    for q, k in enumerate(frames):
+        h_cpu, _ = clib.rdf_hist(pos_s[q:q + 1], packed.cell, sp, len(kinds), rdf.rmax, nb, cell_list=True)
+        acc = h_cpu.copy()
+        if k > 0:
+            acc += ctx.rdf_accumulate(packed, rdf.rmax, nb, frame_range=(0, k))[0]
+        if k + 1 < F:
+            acc += ctx.rdf_accumulate(packed, rdf.rmax, nb, frame_range=(k + 1, F))[0]
+        out["rdf"] = out["rdf"] and bool(np.array_equal(acc, timed))
+    window = np.asarray(msd.data["Time"].values, dtype=np.int64)       # timestep = 1
+    a1 = min(272, N)
+    mask = np.zeros(N, dtype=bool)
+    mask[:a1] = True
+    pos_h = packed.pos.cpu().numpy()
+    elements, ref = no.window_msd_fast(pos_h, packed.cell, packed.numbers, packed.masses, window, atom_subset=mask)
+    del pos_h
+    sumsq, k2 = ctx.msd_window(packed, window, atom_range=(0, a1))
+    worst = 0.0
+    for e, r in zip(elements, ref):
+        n_e = int((packed.numbers[:a1] == e).sum())
+        got = sumsq[k2.index(int(e))] / n_e / (F - window)
+        worst = max(worst, float(np.max(np.abs(got - r) / np.maximum(np.abs(r), 1e-300))))
+    parts = sumsq.copy()
+    step = max(1, (N - a1 + 2) // 3)
+    for b in range(a1, N, step):
+        parts += ctx.msd_window(packed, window, atom_range=(b, min(b + step, N)))[0]
+    dev = float(np.max(np.abs(parts - msd.sumsq) / np.maximum(np.abs(msd.sumsq), 1e-300)))
+    out["msd_slice_max_rel_dev"] = worst
+    out["msd_slices_vs_timed_max_rel_dev"] = dev
+    out["msd"] = bool(worst < 1e-9 and dev < 1e-11)
+    out["ok"] = bool(out["rdf"] and out["msd"])
+    return out
+
+
+def supplementary(device, local_rank, ctx):
+    """The other single-GPU configs of BASELINE.json, timed by the same process (never `value`)."""
+    import torch
+    from amof_amd.rdf import Rdf
+    from amof_amd.cn import CoordinationNumber
+    from amof_amd.frames import PackedTrajectory
+    from tests import helpers as H
+    out = {}
+    # configs[1]: 2x2x2 = 2176 atoms, 1000 frames, partial Zn-N RDF with rmax = 10 A + CoordinationNumber
+    p1 = make_trajectory(device, (2, 2, 2), 1000, 0.05, 11)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r1 = Rdf.from_trajectory(p1, dr=0.01, rmax=10.0, device=local_rank, distributed=False)
+        t_r = time.perf_counter() - t0
+        k_r, path_r = ctx.last_kernel_seconds(dominant=False), ctx.last_path()
+        t0 = time.perf_counter()
+        c1 = CoordinationNumber.from_trajectory(p1, {'Zn-N': 2.5}, device=local_rank, distributed=False)
+        t_c = time.perf_counter() - t0
+        k_c, path_c = ctx.last_kernel_seconds(dominant=False), ctx.last_path()
+    alg1 = p1.n_frames * (24 * p1.n_atoms + 72)
+    pairs1 = float(np.asarray(r1.hist).sum()) / 2.0
+    out["configs1"] = {
+        "workload": "configs[1]: %d-atom ZIF-4 2x2x2, %d frames, Rdf(dr=0.01, rmax=10 -> %d bins; column 'Zn-N') + "
+                    "CoordinationNumber({'Zn-N': 2.5})" % (p1.n_atoms, p1.n_frames, len(r1.data)),
+        "frames_per_s": p1.n_frames / (t_r + t_c), "rdf_wall_s": t_r, "cn_wall_s": t_c,
+        "rdf_kernel_s": k_r, "cn_kernel_s": k_c, "rdf_path": path_r, "cn_path": path_c,
+        "pairs_in_range_per_s": pairs1 / k_r,
+        "roofline_rdf": {"bound": "hbm", "achieved": alg1 / k_r / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": alg1 / k_r / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg1},
+        "roofline_cn": {"bound": "hbm", "achieved": alg1 / k_c / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": alg1 / k_c / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg1},
+        "cn_first_frame": float(c1.data['Zn-N'].values[0]),
+    }
+    del p1, r1, c1
+    # configs[4]: 7x7x8 = 106 624 atoms in a sheared cell, 2000 frames (5.1 GB), cell-list RDF at rmax = 10 A
+    base = H.replicate(H.zif4_frame(), (7, 7, 8))
+    shear = np.eye(3) + np.array([[0, 0.15, 0.10], [0, 0, 0.20], [0, 0, 0]])
+    cell = base.cell @ shear
+    F4 = 2000
+    g = torch.Generator(device=device)
+    g.manual_seed(44)
+    frac0 = torch.tensor(np.linalg.solve(base.cell.T, base.positions.T).T, dtype=torch.float64, device=device)
+    C = torch.tensor(cell, dtype=torch.float64, device=device)
+    Cinv = torch.linalg.inv(C)
+    pos4 = torch.empty((F4, len(base.numbers), 3), dtype=torch.float64, device=device)
+    cur = frac0 @ C
+    for f0 in range(0, F4, 50):
+        f1 = min(f0 + 50, F4)
+        steps = torch.randn((f1 - f0, len(base.numbers), 3), dtype=torch.float64, device=device, generator=g) * 0.05
+        if f0 == 0:
+            steps[0] = 0.0
+        walk = cur + torch.cumsum(steps, dim=0)
+        cur = walk[-1].clone()
+        s = walk @ Cinv
+        pos4[f0:f1] = (s - torch.floor(s)) @ C
+        del steps, walk, s
+    p4 = PackedTrajectory(pos4, cell, base.numbers)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r4 = Rdf.from_trajectory(p4, dr=0.01, rmax=10.0, device=local_rank, distributed=False)
+        t4 = time.perf_counter() - t0
+        k4_dom, k4_all, path4 = ctx.last_kernel_seconds(True), ctx.last_kernel_seconds(False), ctx.last_path()
+    alg4 = F4 * (24 * p4.n_atoms + 72)
+    out["configs4"] = {
+        "workload": "configs[4]: %d-atom sheared (triclinic) ZIF-4 7x7x8, %d frames, Rdf(dr=0.01, rmax=10 -> %d bins)"
+                    % (p4.n_atoms, F4, len(r4.data)),
+        "frames_per_s": F4 / t4, "wall_s": t4, "kernel_s_all": k4_all, "kernel_s_dominant": k4_dom, "path": path4,
+        "pairs_in_range_per_s": float(np.asarray(r4.hist).sum()) / 2.0 / k4_dom,
+        "roofline": {"kernel": path4, "bound": "hbm", "achieved": alg4 / k4_dom / 1e9, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": alg4 / k4_dom / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg4,
+                     "incl_cell_sort_frac": alg4 / k4_all / 1e9 / HBM_PEAK_GBPS},
+    }
+    del p4, r4, pos4
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,11 +255,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=5000)
     ap.add_argument("--reps", type=str, default="3,3,4")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = one shared trajectory sharded over the ranks (default); weak = a block per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rdf-frames", type=int, default=24)
-    ap.add_argument("--with-bad", action="store_true", help="BASELINE configs[3]: add Bad({'Zn-N': 2.5}, dtheta=0.05) to the step")
+    ap.add_argument("--no-bad", action="store_true", help="skip the configs[3] leg (RDF+BAD+MSD steps after the timed ones)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the supplementary configs[1] / configs[4] legs (N = 1)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle spot checks of the timed results")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--all-on-device", type=int, default=None, help="rehearsal: put every rank on this GPU")
+    ap.add_argument("--dump-hist", type=str, default=None, help="rank 0 saves the merged RDF histogram (npy) here")
     args = ap.parse_args()
 
     import torch
@@ -159,6 +272,7 @@ def main():
     from amof_amd import _hip
     from amof_amd.rdf import Rdf
     from amof_amd.msd import WindowMsd
+    from amof_amd.bad import Bad
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,29 +292,34 @@ def main():
 
     reps = tuple(int(x) for x in args.reps.split(","))
     F = args.frames
-    packed = make_trajectory(device, reps, F, 0.05, 20261003 + rank)
+    strong = world == 1 or args.scaling == "strong"
+    # strong scaling: the SAME trajectory on every rank (same seed), sharded by the classes; weak: own block per rank
+    packed = make_trajectory(device, reps, F, 0.05, 20261003 + (0 if strong else rank))
+    torch.cuda.synchronize()                        # generation finished before anything is timed
     N = packed.n_atoms
     ctx = _hip.get_context(local_rank)
-    mode = 'local' if world > 1 else False
+    mode = False if world == 1 else (None if strong else 'local')
 
-    def step():
+    def step(with_bad, rec):
+        t0 = time.perf_counter()
         rdf = Rdf.from_trajectory(packed, device=local_rank, distributed=mode)
-        t_rdf = ctx.last_kernel_seconds(dominant=True)
-        t_rdf_all = ctx.last_kernel_seconds(dominant=False)
+        t1 = time.perf_counter()
+        rec["rdf_dom"].append(ctx.last_kernel_seconds(dominant=True))
+        rec["rdf_all"].append(ctx.last_kernel_seconds(dominant=False))
+        t2 = time.perf_counter()
         msd = WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=local_rank, distributed=mode)
-        t_msd_dom = ctx.last_kernel_seconds(dominant=True)
-        t_msd_all = ctx.last_kernel_seconds(dominant=False)
-        if args.with_bad:
-            from amof_amd.bad import Bad
+        t3 = time.perf_counter()
+        rec["msd_dom"].append(ctx.last_kernel_seconds(dominant=True))
+        rec["msd_all"].append(ctx.last_kernel_seconds(dominant=False))
+        rec["rdf_wall"].append(t1 - t0)
+        rec["msd_wall"].append(t3 - t2)
+        bad = None
+        if with_bad:
+            t4 = time.perf_counter()
             bad = Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=local_rank, distributed=mode)
-            k_bad.append(ctx.last_kernel_seconds(dominant=False))
-            assert "N-Zn-N" in bad.data.columns
-        return rdf, msd, t_rdf, t_msd_dom, t_msd_all, t_rdf_all
-
-    k_bad = []
-    for _ in range(args.warmup):
-        step()
-    k_bad.clear()
+            rec["bad_wall"].append(time.perf_counter() - t4)
+            rec["bad_all"].append(ctx.last_kernel_seconds(dominant=False))
+        return rdf, msd, bad
 
     def fence():
         torch.cuda.synchronize()
@@ -208,70 +327,139 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    k_rdf, k_msd_dom, k_msd_all, k_rdf_all = [], [], [], []
-    for _ in range(args.steps):
-        rdf, msd, a, b, c, d = step()
-        k_rdf.append(a); k_msd_dom.append(b); k_msd_all.append(c); k_rdf_all.append(d)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(with_bad):
+        keys = ("rdf_dom", "rdf_all", "msd_dom", "msd_all", "rdf_wall", "msd_wall", "bad_wall", "bad_all")
+        rec = {k: [] for k in keys}
+        for _ in range(args.warmup):
+            step(with_bad, rec)
+        rec = {k: [] for k in keys}
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step(with_bad, rec)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        mean = {k: (float(np.mean(v)) if v else None) for k, v in rec.items()}
+        return res, elapsed, mean
+
+    (rdf, msd, _), elapsed, mean = timed(False)
+    cfg3 = None
+    if not args.no_bad:
+        (rdf3, msd3, bad3), elapsed3, mean3 = timed(True)
+        cfg3 = (bad3, elapsed3, mean3)
+        assert "N-Zn-N" in bad3.data.columns
+
+    per_rank = {"rank": rank, "device": local_rank, "rdf_frames": list(_rdf_range(F, rank, world, strong)),
+                "kernel_s": {k: mean[k] for k in ("rdf_dom", "rdf_all", "msd_all")},
+                "wall_s": {k: mean[k] for k in ("rdf_wall", "msd_wall")}}
+    if cfg3:
+        per_rank["kernel_s"]["bad_all"] = cfg3[2]["bad_all"]
+        per_rank["wall_s"]["bad_wall"] = cfg3[2]["bad_wall"]
+    ranks = [per_rank]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, per_rank)
 
     if rank == 0:
-        total_frames = world * F * args.steps
-        fps = total_frames / elapsed
+        frames_per_step = F if strong else world * F
+        fps = frames_per_step * args.steps / elapsed
         rmax, nbins = rdf.rmax, len(rdf.data)
-        t_rdf = float(np.mean(k_rdf))
-        alg_bytes = F * (24 * N + 72)                      # 24N+72 bytes per frame per pass
-        pairs = F * N * (N - 1) / 2.0                      # unordered pair evaluations per launch
-        in_range = float(rdf.hist.sum()) / 2.0 / world if world > 1 else float(rdf.hist.sum()) / 2.0
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied),
-        # recorded under profiles/ for this exact workload; null for any other size
+        t_rdf = mean["rdf_dom"]
+        f_lo, f_hi = _rdf_range(F, rank, world, strong)
+        f_loc = f_hi - f_lo
+        alg_bytes = f_loc * (24 * N + 72)                  # 24N+72 bytes per frame per pass (this rank's launch)
+        pairs = f_loc * N * (N - 1) / 2.0                  # unordered pair evaluations per launch
+        in_range = float(np.asarray(rdf.hist).sum()) / 2.0 * (f_loc / float(frames_per_step))
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by
+        # profiles/tools/pmc_traffic.py), recorded under profiles/ for this exact workload; null for any other size
         traffic = {}
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile) and (N, F) == (9792, 5000):
+        if os.path.exists(tfile) and (N, F, world) == (9792, 5000, 1):
             with open(tfile) as fh:
                 traffic = json.load(fh).get("cfg3", {})
+        # the bound that applies to the all-pairs kernel is VALU issue: cycles a SIMD spends per
+        # wave-level pair (64 pairs), measured live; beside it the same quantity predicted from the kernel's own
+        # disassembly weighted with the per-instruction issue costs measured on the box (profiles/tools/valu_model.py,
+        # regenerated by build()), and the share of the pairs the slab culling leaves (geometry, computed here)
+        lz = float(np.max(packed.cell_lengths()))
+        visited = min(1.0, (2.0 * rmax) / lz + 3.0 / 256.0) if 2.0 * rmax * 1.05 < lz else 1.0
+        valu = {"simd_cycles_per_wave_pair_all_pairs": t_rdf * N_SIMD * CLOCK_HZ / (pairs / 64.0),
+                "visited_fraction_geometric": visited,
+                "simd_cycles_per_visited_wave_pair": t_rdf * N_SIMD * CLOCK_HZ / (pairs / 64.0) / visited}
+        mfile = os.path.join(ROOT, "profiles", "valu_model.json")
+        if os.path.exists(mfile):
+            with open(mfile) as fh:
+                model = json.load(fh)
+            valu["model"] = model.get("rdf_tile_kernel_fast")
+            if valu["model"] and valu["model"].get("issue_cycles_per_visited_wave_pair"):
+                valu["issue_slot_utilisation"] = (valu["model"]["issue_cycles_per_visited_wave_pair"] /
+                                                  valu["simd_cycles_per_visited_wave_pair"])
+        msd_bytes = alg_bytes if world == 1 else F * (24 * N + 72)      # every rank reads all frames for the COM
         out = {
             "metric": "frames/s (RDF+MSD, 10k-atom ZIF-4)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2] headline: %d-atom ZIF-4 %dx%dx%d supercell, %d frames per GPU, "
+            "config": {"workload": "configs[2] headline: %d-atom ZIF-4 %dx%dx%d supercell, %d frames%s, "
                                    "Rdf(dr=0.01, rmax=half_cell -> %.4f A, %d bins) + WindowMsd(delta_time=100, W=%d)"
-                                   % (N, reps[0], reps[1], reps[2], F, rmax, nbins, len(msd.data)),
-                       "n_atoms": N, "frames_per_gpu": F, "rdf_bins": nbins, "msd_windows": len(msd.data),
-                       "parallelism": "frames x%d, RCCL all-reduce of u64 histograms" % world},
+                                   % (N, reps[0], reps[1], reps[2], F, "" if strong else " per GPU", rmax, nbins,
+                                      len(msd.data)),
+                       "n_atoms": N, "frames_total": frames_per_step, "rdf_bins": nbins, "msd_windows": len(msd.data),
+                       "parallelism": ("RDF frames sharded x%d + RCCL all-reduce of the u64 histograms in HBM; MSD atoms "
+                                       "sharded x%d + all-reduce of the f64 sums" % (world, world)) if strong else
+                                      ("own %d-frame block per rank x%d, RCCL all-reduce of the u64 histograms" % (F, world))},
             "roofline": {"kernel": "rdf_tile_kernel_fast", "bound": "hbm", "achieved": alg_bytes / t_rdf / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / t_rdf / 1e9 / HBM_PEAK_GBPS,
                          "traffic": traffic.get("rdf_tile_kernel_fast"), "launch_seconds": t_rdf,
-                         "algorithmic_bytes": alg_bytes,
+                         "algorithmic_bytes": alg_bytes, "frames_in_launch": f_loc,
                          "note": "all-pairs RDF at half-cell rmax does N(N-1)/2 = 4.8e7 pair evaluations per 235 kB "
                                  "frame: VALU-issue bound, not HBM bound (SURVEY 8d, DESIGN 4.1); the honest HBM "
-                                 "fraction is tiny by construction -- see pair_evals_per_s"},
+                                 "fraction is tiny by construction and north_star's >= 50 % HBM target does not apply "
+                                 "to this kernel -- see valu_issue and pair_evals_per_s"},
             "pair_evals_per_s": pairs / t_rdf, "pairs_in_range_per_s": in_range / t_rdf,
-            # supplementary, the bound that actually applies: SIMD cycles spent per wave-level
-            # pair (64 pairs) at the nominal 2.4 GHz, all N(N-1)/2 pairs counted although ~1/3 are culled;
-            # the instruction mix of the inner loop sums to ~70 issue cycles per visited wave-pair
-            "valu_issue": {"simd_cycles_per_wave_pair": t_rdf * 1024 * 2.4e9 / (pairs / 64.0),
-                           "model_cycles_per_visited_wave_pair": 70.0, "visited_fraction": 0.67},
+            "valu_issue": valu,
             "roofline_msd": {"kernel": "msd pipeline (com + delta_transpose + msd_comb + reduce)", "bound": "hbm",
-                             "achieved": alg_bytes / float(np.mean(k_msd_all)) / 1e9, "peak": HBM_PEAK_GBPS,
-                             "unit": "GB/s", "frac": alg_bytes / float(np.mean(k_msd_all)) / 1e9 / HBM_PEAK_GBPS,
-                             "traffic": traffic.get("msd_pipeline"), "pipeline_seconds": float(np.mean(k_msd_all)),
-                             "msd_window_kernel_seconds": float(np.mean(k_msd_dom))},
-            "kernel_seconds_per_step": {"rdf_tile": t_rdf, "rdf_all_incl_quantize": float(np.mean(k_rdf_all)),
-                                        "msd_all": float(np.mean(k_msd_all))},
+                             "achieved": msd_bytes / mean["msd_all"] / 1e9, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": msd_bytes / mean["msd_all"] / 1e9 / HBM_PEAK_GBPS,
+                             "traffic": traffic.get("msd_pipeline"), "pipeline_seconds": mean["msd_all"],
+                             "msd_window_kernel_seconds": mean["msd_dom"], "algorithmic_bytes": msd_bytes},
+            "kernel_seconds_per_step": {"rdf_tile": t_rdf, "rdf_all_incl_quantize": mean["rdf_all"],
+                                        "msd_all": mean["msd_all"]},
+            "host_seconds_per_step": {"rdf_wall_minus_kernels": mean["rdf_wall"] - mean["rdf_all"],
+                                      "msd_wall_minus_kernels": mean["msd_wall"] - mean["msd_all"]},
+            "per_rank": ranks,
         }
-        if args.with_bad:
-            out["metric"] = "frames/s (RDF+BAD+MSD, 10k-atom ZIF-4)"
-            out["config"]["workload"] += " + Bad({'Zn-N': 2.5}, dtheta=0.05) [configs[3]]"
-            out["kernel_seconds_per_step"]["bad_all"] = float(np.mean(k_bad))
-            args.no_cpu_baseline = True         # the CPU leg times RDF+MSD only
+        if cfg3:
+            bad3, elapsed3, mean3 = cfg3
+            out["configs3"] = {
+                "workload": "configs[3]: the same trajectory, Rdf + WindowMsd + Bad({'Zn-N': 2.5}, dtheta=0.05) per step",
+                "value": frames_per_step * args.steps / elapsed3, "unit": "frames/s",
+                "ms_per_step": 1e3 * elapsed3 / args.steps,
+                "kernel_seconds_per_step": {"rdf_all": mean3["rdf_all"], "msd_all": mean3["msd_all"],
+                                            "bad_all": mean3["bad_all"]},
+                "bad_wall_s": mean3["bad_wall"],
+                "roofline_bad": {"kernel": "bad pipeline (quantize + bad_fast)", "bound": "hbm",
+                                 "achieved": alg_bytes / mean3["bad_all"] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": alg_bytes / mean3["bad_all"] / 1e9 / HBM_PEAK_GBPS,
+                                 "algorithmic_bytes": alg_bytes},
+                "n_angles": [int(x) for x in np.asarray(bad3.n_angles)],
+            }
+        if args.dump_hist:
+            np.save(args.dump_hist, np.asarray(rdf.hist).view(np.uint64))
+        if not args.no_verify and strong:
+            try:
+                out["verification"] = verify(packed, ctx, rdf, msd, [0, F // 3 + 1, F - 1][:3 if F > 2 else 1])
+                out["verified"] = out["verification"]["ok"]
+            except Exception as exc:        # the checker failing to run is not a pass
+                out["verification"] = {"error": repr(exc)}
+                out["verified"] = False
+        else:
+            out["verified"] = None
         if world == 1 and not args.no_cpu_baseline:
             window = np.arange(0, (F // 2), 100)
             out["cpu_baseline"] = cpu_baseline(packed, rmax, nbins, window, args.cpu_rdf_frames)
@@ -295,10 +483,23 @@ def main():
             t0 = time.perf_counter()
             pack_trajectory(frames)
             out["pack_atoms_list_frames_per_s"] = nfr / (time.perf_counter() - t0)
+            del host, frames
+        if world == 1 and not args.no_extra:
+            del packed
+            torch.cuda.empty_cache()
+            try:
+                out["supplementary"] = supplementary(device, local_rank, ctx)
+            except Exception as exc:
+                out["supplementary"] = {"error": repr(exc)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _rdf_range(F, rank, world, strong):
+    from amof_amd import dist as adist
+    return adist.shard_range(F, rank, world) if (strong and world > 1) else (0, F)
 
 
 if __name__ == "__main__":

@@ -80,6 +80,12 @@ const char *amof_last_error(const amof_ctx *ctx);
  * stream).  NULL restores the context's own stream. */
 int amof_ctx_set_stream(amof_ctx *ctx, void *hip_stream);
 int amof_ctx_synchronize(amof_ctx *ctx);
+/* Order the context's stream after everything queued so far on another stream of the same device
+ * (hipEventRecord + hipStreamWaitEvent; NULL = the legacy default stream).  A caller that hands over
+ * a device-resident `pos` produced by work still pending on its own stream (a torch tensor, say)
+ * calls this first: the library's kernels otherwise run on the context's non-blocking stream with
+ * no ordering against the producer. */
+int amof_ctx_wait_stream(amof_ctx *ctx, void *hip_stream);
 
 /* Seconds spent inside kernels of the last call, measured with HIP events on
  * the context's stream around the dominant kernel's launches:

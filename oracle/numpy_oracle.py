@@ -219,10 +219,23 @@ def window_msd(pos, cell, numbers, masses, window, pbc=True, unwrap=False, atom_
     return elements, out
 
 
-def window_msd_fast(pos, cell, numbers, masses, window, pbc=True, unwrap=False):
+def window_msd_fast(pos, cell, numbers, masses, window, pbc=True, unwrap=False, atom_subset=None):
     """Vectorised equivalent of :func:`window_msd` (cumsum instead of the
     reference's running sums) for larger parity cases; validated against the
-    loop version in tests/test_oracle_msd.py."""
+    loop version in tests/test_oracle_msd.py.
+
+    ``atom_subset`` (boolean mask, not with ``unwrap``): the centre of mass
+    uses every atom, the per-element sums only the selected ones -- headline-
+    sized parity cases check a slice of the atoms."""
+    if atom_subset is not None:
+        if unwrap:
+            raise ValueError("atom_subset is not supported together with unwrap")
+        pos = np.asarray(pos, dtype=np.float64)
+        masses = np.asarray(masses, dtype=np.float64)
+        com = np.einsum('n,fnc->fc', masses, pos) / masses.sum()
+        sel = np.asarray(atom_subset, dtype=bool)
+        sub = pos[:, sel] - com[:, None, :]
+        return _window_msd_centered(sub, cell, np.asarray(numbers)[sel], window, pbc)
     pos = np.array(pos, dtype=np.float64)
     F = len(pos)
     cell = np.asarray(cell, dtype=np.float64).reshape(-1, 3, 3)
@@ -241,6 +254,32 @@ def window_msd_fast(pos, cell, numbers, masses, window, pbc=True, unwrap=False):
         pos = pos[0][None] + np.cumsum(deltas(pos), axis=0)
     pos = pos - (np.einsum('n,fnc->fc', masses, pos) / masses.sum())[:, None, :]
     u = np.cumsum(deltas(pos), axis=0)
+    out = []
+    for x in elements:
+        ux = u[:, numbers == x]
+        n = ux.shape[1]
+        vals = []
+        for m in window:
+            m = int(m)
+            if F - m - 1 >= 1:
+                diff = ux[m + 1:] - ux[1:F - m]
+                vals.append((diff ** 2).sum() / n / (F - m))
+            else:
+                vals.append(0.0)
+        out.append(np.array(vals))
+    return elements, out
+
+
+def _window_msd_centered(pos, cell, numbers, window, pbc=True):
+    """tail of :func:`window_msd_fast` for positions whose centre of mass is already removed"""
+    F = len(pos)
+    cell = np.asarray(cell, dtype=np.float64).reshape(-1, 3, 3)
+    cells = [cell[k if len(cell) > 1 else 0] for k in range(F)]
+    d = np.zeros_like(pos)
+    for k in range(F - 1):
+        d[k + 1] = wrap_positions(pos[k + 1] - pos[k], cells[k], pbc=pbc, center=(0., 0., 0.))
+    u = np.cumsum(d, axis=0)
+    elements = list(set(numbers))
     out = []
     for x in elements:
         ux = u[:, numbers == x]

@@ -61,3 +61,32 @@ def random_gas(N, cell, numbers, seed, F=1):
     # uniform in the cell, then displaced by whole lattice vectors (still uniform modulo the cell)
     P = (rng.uniform(0, 1, size=(F, N, 3)) + rng.integers(-1, 2, size=(F, N, 3))) @ cell
     return PackedTrajectory(P, cell, numbers)
+
+
+def device_walk(device, reps, n_frames, sigma, seed, base=None):
+    """Synthetic ZIF-4 supercell trajectory generated directly in HBM (torch, float64): Gaussian random walk,
+    sigma per frame and axis, wrapped each frame into the constant orthorhombic cell.  The headline workload of
+    bench.py (BASELINE.json configs[2]/[3]) and of tests/test_gpu_headline.py.  Returns a PackedTrajectory whose
+    ``pos`` is a CUDA tensor; the caller synchronises (or relies on the library's stream ordering)."""
+    import torch
+    base = zif4_frame() if base is None else base
+    rep = replicate(base, reps)
+    lengths = np.diag(base.cell) * np.array(reps)          # constant orthorhombic cell
+    cell = np.diag(lengths)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = len(rep.numbers)
+    L = torch.tensor(lengths, dtype=torch.float64, device=device)
+    traj = torch.empty((n_frames, n, 3), dtype=torch.float64, device=device)
+    cur = torch.tensor(rep.positions, dtype=torch.float64, device=device)   # unwrapped position of the last frame
+    chunk = 250
+    for f0 in range(0, n_frames, chunk):
+        f1 = min(f0 + chunk, n_frames)
+        steps = torch.randn((f1 - f0, n, 3), dtype=torch.float64, device=device, generator=g) * sigma
+        if f0 == 0:
+            steps[0] = 0.0                                  # frame 0 is the base structure
+        walk = cur + torch.cumsum(steps, dim=0)
+        cur = walk[-1].clone()
+        traj[f0:f1] = walk - torch.floor(walk / L) * L     # wrapped into the cell
+        del steps, walk
+    return PackedTrajectory(traj, cell, rep.numbers)

@@ -64,11 +64,13 @@ def test_two_ranks_equal_single_process(tmp_path):
 def _worker_rccl(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK="0", AMOF_DIST_FORCE_MERGE="1")     # one rank, but every collective really runs
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from amof_amd import dist as adist
+    assert adist.merging(1) and adist.device_collectives()
     for mode in (None, "local"):
         res = _run_all(_build(), mode)
         for k, df in res.items():
@@ -78,8 +80,9 @@ def _worker_rccl(rank, world, port, out_dir):
 
 
 def test_rccl_backend_single_rank(tmp_path):
-    # the code path the 8-GPU bench takes (backend "nccl" = RCCL: CUDA-tensor all-reduce, object
-    # all-gather), with the one rank a single-GPU box allows
+    # the code path the 8-GPU bench takes (backend "nccl" = RCCL: histograms accumulated by the "_dev" entry points
+    # into CUDA tensors and all-reduced in place, tensor all-gather of the CN rows), with the one rank a
+    # single-GPU box allows (AMOF_DIST_FORCE_MERGE=1 runs the merge path although world_size is 1)
     import pandas as pd
     port = 31600 + os.getpid() % 2000
     mp.spawn(_worker_rccl, args=(1, port, str(tmp_path)), nprocs=1, join=True)
