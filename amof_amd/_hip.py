@@ -261,7 +261,7 @@ class Context(object):
         """``_TrajHandle`` of a trajectory this context may read.  A device-resident ``pos`` must live on this
         context's GPU, and the context's (non-blocking) stream is ordered after torch's current stream on that
         device, i.e. after whatever produced the tensor (generation kernels, a peer copy, ``.to()``)."""
-        th = self._traj(packed, frame_range)
+        th = _TrajHandle(packed, frame_range)
         if th.device_index is not None:
             if th.device_index != self.device:
                 raise ValueError("trajectory positions live on cuda:%d but this context drives cuda:%d; use "

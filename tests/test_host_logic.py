@@ -151,3 +151,21 @@ def test_simps_restatement_and_rdf_integration_cn():
     r = np.arange(3000) * 0.001
     rho, rc = 0.05, 2.5
     assert get_coordination_number(r, np.ones_like(r), rc, rho) == pytest.approx(rho * 4 / 3 * np.pi * rc ** 3, rel=2e-3)
+
+
+def test_traj_handle_of_a_host_trajectory_needs_no_gpu():
+    """Context._traj (argument marshalling for the C ABI) on host arrays: no device check, no stream ordering"""
+    from amof_amd import _hip
+    from tests import helpers as H
+
+    class FakeCtx(object):
+        device = 0
+
+        def wait_stream(self, ptr):
+            raise AssertionError("host-resident positions need no stream ordering")
+
+    packed = H.random_walk(H.zif4_frame(), 4, 0.05, 3)
+    th = _hip.Context._traj(FakeCtx(), packed, (1, 3))
+    assert th.c.n_frames == 2 and th.c.n_atoms == 272 and th.c.pos_on_device == 0 and th.S == 4
+    assert th.kinds == [1, 6, 7, 30]
+    assert packed._abi_species[1] is th.species          # cached on the trajectory
