@@ -134,17 +134,22 @@ def species_index(numbers):
     return [int(z) for z in uniq], inverse.astype(np.int32).reshape(-1)
 
 
+def packed_species(packed):
+    """:func:`species_index` of a PackedTrajectory, computed once per trajectory (numbers never change)."""
+    cached = getattr(packed, "_abi_species", None)
+    if cached is None:
+        cached = species_index(packed.numbers)
+        packed._abi_species = cached
+    return cached
+
+
 class _TrajHandle(object):
     """Keeps the numpy buffers behind an ``AmofTraj`` alive."""
 
     def __init__(self, packed, frame_range=None):
         assert isinstance(packed, PackedTrajectory)
         f0, f1 = (0, packed.n_frames) if frame_range is None else frame_range
-        cached = getattr(packed, "_abi_species", None)     # numbers never change after construction
-        if cached is None:
-            cached = species_index(packed.numbers)
-            packed._abi_species = cached
-        self.kinds, self.species = cached
+        self.kinds, self.species = packed_species(packed)
         pos = packed.pos
         cell = packed.cell if packed.cell.shape[0] == 1 else packed.cell[f0:f1]
         self.cell = np.ascontiguousarray(cell, dtype=np.float64)

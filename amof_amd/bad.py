@@ -76,7 +76,7 @@ class Bad(CoreBad):
                     device=None, distributed=None):
         """compute bond-angle distributions (reference amof/bad.py:116-160)"""
         packed = pack_trajectory(trajectory)
-        atomic_numbers_unique = list(set(packed.numbers))
+        atomic_numbers_unique = packed.unique_numbers()
 
         cutoff_dict = amatom.format_cutoff(nb_set_and_cutoff)
         elements_present_unique = list(set([_data.atomic_numbers[i] for nb_set in nb_set_and_cutoff.keys()
@@ -90,9 +90,8 @@ class Bad(CoreBad):
         bins = int(180 // dtheta)       # Python float floor-division (amof/bad.py:142)
         theta_bins = np.arange(bins + 2) * dtheta
         theta = np.arange(bins + 1) * dtheta + dtheta / 2
-        self.data = pd.DataFrame({"theta": theta})
 
-        kinds, _ = _hip.species_index(packed.numbers)
+        kinds, _ = _hip.packed_species(packed)
         lut = {z: k for k, z in enumerate(kinds)}
         rcm = amatom.cutoff_matrix(cutoff_dict, kinds)
 
@@ -135,14 +134,13 @@ class Bad(CoreBad):
         self.n_angles = nang
         self.columns = names
 
-        cols = {}
+        cols = {"theta": theta}
         db = np.array(np.diff(theta_bins), float)
         for k, aba_str in enumerate(names):
             if nang[k] != 0:            # columns without any angle are omitted (amof/bad.py:159)
                 n = hist[k].astype(np.int64)
                 cols[aba_str] = n / db / n.sum()      # numpy.histogram(density=True)
-        if cols:
-            self.data = pd.concat([self.data, pd.DataFrame(cols)], axis=1)
+        self.data = pd.DataFrame(cols)
 
     def write_to_file(self, filename):
         filename = _path.append_suffix(filename, 'bad')
@@ -178,7 +176,7 @@ class BadByCn(CoreBad):
                     device=None, distributed=None):
         """compute bond-angle distributions by cn (reference amof/bad.py:240-301)"""
         packed = pack_trajectory(trajectory)
-        atomic_numbers_unique = list(set(packed.numbers))
+        atomic_numbers_unique = packed.unique_numbers()
         cutoff_dict = amatom.format_cutoff(nb_set_and_cutoff)
         elements_present_unique = list(set([_data.atomic_numbers[i] for nb_set in nb_set_and_cutoff.keys()
                                             for i in nb_set.split('-')]))
@@ -190,7 +188,7 @@ class BadByCn(CoreBad):
         bins = int(180 // dtheta)
         theta_bins = np.arange(bins + 2) * dtheta
         theta = np.arange(bins + 1) * dtheta + dtheta / 2
-        kinds, _ = _hip.species_index(packed.numbers)
+        kinds, _ = _hip.packed_species(packed)
         lut = {z: k for k, z in enumerate(kinds)}
         rcm = amatom.cutoff_matrix(cutoff_dict, kinds)
         names, triples = [], []

@@ -53,7 +53,7 @@ class CoordinationNumber(object):
         packed = pack_trajectory(trajectory)
         logger.info("Start computing coordination number for %s frames", len(packed))
         cutoff_dict = amatom.format_cutoff(nb_set_and_cutoff)
-        kinds, _ = _hip.species_index(packed.numbers)
+        kinds, _ = _hip.packed_species(packed)
         lut = {z: k for k, z in enumerate(kinds)}
         rcm = amatom.cutoff_matrix(cutoff_dict, kinds)
         names, sets, present = [], [], []
@@ -80,7 +80,7 @@ class CoordinationNumber(object):
         k = 0
         for name, s, has_a in zip(names, sets, present):
             a = _data.atomic_numbers[name.split('-')[0]]
-            n_a = int((packed.numbers == a).sum())
+            n_a = packed.species_counts().get(a, 0)
             if s is not None:
                 col = sums[:, k].astype(np.float64) / n_a   # np.mean of integer counts (amof/cn.py:73)
                 k += 1

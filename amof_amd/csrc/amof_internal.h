@@ -211,6 +211,18 @@ void timing_end(amof_ctx *ctx);
 void timing_dom_begin(amof_ctx *ctx, const char *path);
 void timing_dom_end(amof_ctx *ctx, int64_t launches);
 
+// ---------------------------------------------------------------- LDS-DMA --
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// One wave copies 16 B per ACTIVE lane from per-lane global addresses to LDS at dst_wave + 16 * lane
+// (dst_wave wave-uniform), without passing through registers (global_load_lds_dwordx4).  Completion is
+// tracked by vmcnt: s_waitcnt vmcnt(0) + a barrier before anyone reads the data.
+__device__ __forceinline__ void dma16(const void *src_lane, void *dst_wave)
+{
+    __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst_wave, 16, 0, 0);
+}
+
 // ------------------------------------------------------- device arithmetic --
 // Canonical minimum-image pair vector (see oracle/amof_oracle.c header and
 // DESIGN.md "canonical arithmetic").  g points at a geometry record.

@@ -27,8 +27,6 @@ namespace amof {
 
 constexpr int MSD_THREADS = 256;
 constexpr int MSD_GEOM = 24;  // cell[9], full inverse[9], pbc[3], pad
-constexpr int TR_F = 32;      // frames per transpose tile
-constexpr int TR_A = 64;      // atoms per transpose tile
 constexpr int MSD_GROUP = 4;  // atoms per msd workgroup
 
 // ase.geometry.wrap_positions(d, cell, center=(0,0,0), eps=1e-7) ([3P-memory],
@@ -93,57 +91,94 @@ __global__ __launch_bounds__(MSD_THREADS) void com_kernel(const double *__restri
 }
 
 // D_T[3a+c][k] = wrap((pos[k][a]-com[k]) - (pos[k-1][a]-com[k-1]); cell[k-1]),  D_T[.][0] = 0
-__global__ __launch_bounds__(MSD_THREADS) void delta_transpose_kernel(const double *__restrict__ pos,
-                                                                      const double *__restrict__ com,
-                                                                      const double *__restrict__ geom,
-                                                                      int n_cells, int64_t N, int F, int64_t Fp,
-                                                                      double *__restrict__ DT)
+// for the atoms a in [a_begin, a_end) only (atom-sharded calls transpose just their share).
+// Tile = TF frames x TA atoms.  A thread owns one atom and FPT = TF TA / THREADS CONSECUTIVE frames: it loads
+// the FPT + 1 rows it needs once (every load in flight before the first use), removes the centre of mass once per
+// row, wraps the FPT differences and parks them in the LDS tile; the tile leaves transposed, two frames (16 B) per
+// lane, TF frames of a column as one contiguous run.  ORTHO: every cell is diagonal -- the zero terms of the
+// general formula are dropped, which leaves the bits unchanged (x + (+-0) = x).
+template <bool ORTHO>
+__device__ __forceinline__ void wrap_delta_t(const double *__restrict__ g, double dx, double dy, double dz,
+                                             double &ox, double &oy, double &oz)
 {
-    __shared__ double tile[TR_F][3 * TR_A + 1];
-    const int k0 = blockIdx.y * TR_F;
-    const int64_t a0 = (int64_t)blockIdx.x * TR_A;
-    // all eight items of a thread are loaded before any is wrapped: the kernel is latency bound otherwise
-    constexpr int ITEMS = TR_F * TR_A / MSD_THREADS;
-    double x1v[ITEMS], y1v[ITEMS], z1v[ITEMS], x0v[ITEMS], y0v[ITEMS], z0v[ITEMS];
+    if (!ORTHO) {
+        wrap_delta(g, dx, dy, dz, ox, oy, oz);
+        return;
+    }
+    const double shift = 0.0 - 0.5 - 1e-7;
+    double fr[3] = {dx * g[9], dy * g[13], dz * g[17]};
 #pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const int idx = threadIdx.x + it * MSD_THREADS;
-        const int k = k0 + idx / TR_A;
-        const int64_t a = a0 + idx % TR_A;
-        x1v[it] = y1v[it] = z1v[it] = x0v[it] = y0v[it] = z0v[it] = 0.0;
-        if (k < F && a < N && k >= 1) {
-            const double *p1 = pos + ((size_t)k * N + a) * 3;
-            const double *p0 = pos + ((size_t)(k - 1) * N + a) * 3;
-            x1v[it] = p1[0]; y1v[it] = p1[1]; z1v[it] = p1[2];
-            x0v[it] = p0[0]; y0v[it] = p0[1]; z0v[it] = p0[2];
+    for (int k = 0; k < 3; k++) {
+        if (g[18 + k] != 0.0) {
+            double t = fr[k] - shift;
+            t = t - floor(t);
+            fr[k] = t + shift;
+        }
+    }
+    ox = fr[0] * g[0];
+    oy = fr[1] * g[4];
+    oz = fr[2] * g[8];
+}
+
+template <int TF, int TA, int THREADS, bool ORTHO>
+__global__ __launch_bounds__(THREADS) void delta_transpose_kernel(const double *__restrict__ pos,
+                                                                  const double *__restrict__ com,
+                                                                  const double *__restrict__ geom,
+                                                                  int n_cells, int64_t N, int F, int64_t Fp,
+                                                                  int64_t a_begin, int64_t a_end,
+                                                                  double *__restrict__ DT)
+{
+    constexpr int KG = THREADS / TA;      // frame groups of the workgroup
+    constexpr int FPT = TF / KG;          // consecutive frames per thread
+    static_assert(THREADS % TA == 0 && TF % KG == 0 && TF % 2 == 0, "tile shape");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double (*tile)[3 * TA + 1] = reinterpret_cast<double (*)[3 * TA + 1]>(lds_raw);   // [TF][3 TA + 1]
+    const int k0 = blockIdx.y * TF;
+    const int64_t a0 = a_begin + (int64_t)blockIdx.x * TA;
+    const int al = threadIdx.x % TA, kg = threadIdx.x / TA;
+    const int64_t a = a0 + al;
+    const int kb = k0 + kg * FPT;         // this thread's frames: kb .. kb + FPT - 1 (row kb - 1 is needed too)
+    const bool atom_ok = a < a_end;
+    double px[FPT + 1], py[FPT + 1], pz[FPT + 1];
+#pragma unroll
+    for (int j = 0; j <= FPT; j++) {
+        const int k = kb - 1 + j;
+        px[j] = py[j] = pz[j] = 0.0;
+        if (atom_ok && k >= 0 && k < F) {
+            const double *p = pos + ((size_t)k * N + a) * 3;
+            px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
+        }
+    }
+    if (com) {
+#pragma unroll
+        for (int j = 0; j <= FPT; j++) {
+            const int k = kb - 1 + j;
+            if (k >= 0 && k < F) {
+                px[j] -= com[3 * k]; py[j] -= com[3 * k + 1]; pz[j] -= com[3 * k + 2];
+            }
         }
     }
 #pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const int idx = threadIdx.x + it * MSD_THREADS;
-        const int kl = idx / TR_A, al = idx % TR_A;
-        const int k = k0 + kl;
-        const int64_t a = a0 + al;
+    for (int j = 1; j <= FPT; j++) {
+        const int k = kb - 1 + j;
         double dx = 0.0, dy = 0.0, dz = 0.0;
-        if (k < F && a < N && k >= 1) {
-            double x1 = x1v[it], y1 = y1v[it], z1 = z1v[it];
-            double x0 = x0v[it], y0 = y0v[it], z0 = z0v[it];
-            if (com) {
-                x1 -= com[3 * k]; y1 -= com[3 * k + 1]; z1 -= com[3 * k + 2];
-                x0 -= com[3 * (k - 1)]; y0 -= com[3 * (k - 1) + 1]; z0 -= com[3 * (k - 1) + 2];
-            }
+        if (atom_ok && k >= 1 && k < F) {
             const double *g = geom + (size_t)(n_cells == 1 ? 0 : k - 1) * MSD_GEOM;
-            wrap_delta(g, x1 - x0, y1 - y0, z1 - z0, dx, dy, dz);
+            wrap_delta_t<ORTHO>(g, px[j] - px[j - 1], py[j] - py[j - 1], pz[j] - pz[j - 1], dx, dy, dz);
         }
+        const int kl = kg * FPT + j - 1;
         tile[kl][3 * al] = dx;
         tile[kl][3 * al + 1] = dy;
         tile[kl][3 * al + 2] = dz;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < TR_F * 3 * TR_A; idx += MSD_THREADS) {
-        const int cl = idx / TR_F, kl = idx % TR_F;
+#pragma unroll 3
+    for (int idx = threadIdx.x; idx < (TF / 2) * 3 * TA; idx += THREADS) {
+        const int cl = idx / (TF / 2), kl = 2 * (idx % (TF / 2));
         const int64_t col = 3 * a0 + cl;
-        if (col < 3 * N) DT[(size_t)col * Fp + k0 + kl] = tile[kl][cl];
+        // (k0 + kl is even and Fp a multiple of 32: the pair is inside the column or wholly outside)
+        if (col < 3 * a_end && k0 + kl < Fp)
+            *reinterpret_cast<double2 *>(DT + (size_t)col * Fp + k0 + kl) = make_double2(tile[kl][cl], tile[kl + 1][cl]);
     }
 }
 
@@ -266,13 +301,37 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__
 // computed and dropped.  Same column load and prefix sum as msd_group_kernel.
 constexpr int COMB_B = 10;
 
+// One comb task: the COMB_B base entries u[r + d (J0 + i)] and their WT - 1 successors, every pair (i, e = i + w),
+// w = 1 .. WT - 1, from registers.  `lim` = number of valid comb entries from J0 on; m0 = 0 for the task that holds
+// time origin k = 0, which the reference never evaluates (amof/msd.py:200: k starts at m + 1), else 1.
+// (Measured and rejected on the MI355X: keeping the lane-mask compares next to their uses and splitting off the
+// origin task -- 22 % fewer instructions, yet 10 % slower: the kernel is bound by dependency stalls at 2-3 waves per
+// SIMD, not by issue; 512-thread workgroups whose halves split the windows -- 4 waves per SIMD but spills, 0.84 ms.)
+template <int WT>
+__device__ __forceinline__ void comb_task(const double *__restrict__ ub, int d, int lim, double m0, double (&acc)[WT])
+{
+    constexpr int NV = COMB_B + WT - 1;
+    double v[NV];
+#pragma unroll
+    for (int e = 0; e < NV; e++) v[e] = e < lim ? ub[(size_t)d * e] : 0.0;
+#pragma unroll
+    for (int e = 1; e < NV; e++) {
+        if (e < lim) {
+#pragma unroll
+            for (int i = (e - WT + 1 > 0 ? e - WT + 1 : 0); i <= (e - 1 < COMB_B - 1 ? e - 1 : COMB_B - 1); i++) {
+                const double dd = v[e] - v[i];
+                acc[e - i] = fma(i == 0 ? dd * m0 : dd, dd, acc[e - i]);
+            }
+        }
+    }
+}
+
 template <int WT>
 __global__ __launch_bounds__(MSD_THREADS) void msd_comb_kernel(const double *__restrict__ DT, int64_t Fp, int F,
                                                                const int32_t *__restrict__ perm,
                                                                const MsdGroup *__restrict__ groups, int d, int W,
                                                                int Wstride, double *__restrict__ partial)
 {
-    constexpr int NV = COMB_B + WT - 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double *u = reinterpret_cast<double *>(lds_raw);  // [F]
     __shared__ double red[MSD_THREADS / 64];
@@ -297,21 +356,60 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_kernel(const double *__r
         for (int t = tid; t < ntask; t += MSD_THREADS) {
             const int r = t % d, J0 = (t / d) * COMB_B;
             const int lim = (F - r + d - 1) / d - J0;   // valid comb entries of this task (from J0 on)
-            const double m0 = t == 0 ? 0.0 : 1.0;        // origin k = 0 is skipped (amof/msd.py:200: k starts at m+1)
-            double v[NV];
-            const double *ub = u + r + (size_t)d * J0;
+            comb_task<WT>(u + r + (size_t)d * J0, d, lim, t == 0 ? 0.0 : 1.0, acc);
+        }
+    }
 #pragma unroll
-            for (int e = 0; e < NV; e++) v[e] = e < lim ? ub[(size_t)d * e] : 0.0;
+    for (int w = 0; w < WT; w++) {
+        if (w < W) {
+            const double tot = block_sum(acc[w], red);
+            if (tid == 0) partial[(size_t)blockIdx.x * Wstride + w] = tot;
+        }
+    }
+}
+
+// The same with the column loads off the critical path: two LDS buffers, the next column streams in by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave instruction, no registers) while the current one is scanned and
+// combed -- one barrier per column hands the buffers over.  Used when two columns fit (2 Fp doubles).
+template <int WT>
+__global__ __launch_bounds__(MSD_THREADS) void msd_comb_db_kernel(const double *__restrict__ DT, int64_t Fp, int F,
+                                                                  const int32_t *__restrict__ perm,
+                                                                  const MsdGroup *__restrict__ groups, int d, int W,
+                                                                  int Wstride, double *__restrict__ partial)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *ubuf = reinterpret_cast<double *>(lds_raw);  // [2][Fp]
+    __shared__ double red[MSD_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const MsdGroup gr = groups[blockIdx.x];
+    const int nq = (F + d - 1) / d;                    // longest comb
+    const int ntask = d * ((nq + COMB_B - 1) / COMB_B);
+    const int ncol = 3 * gr.count;
+    const int ngran = (int)(Fp / 2);                   // 16-byte granules per column (Fp is a multiple of 32)
+    // column c -> buffer b: wave w moves the KiB blocks w, w + 4, ...; lanes beyond the column stay idle
+    auto issue = [&](int c, int b) {
+        const int64_t atom = perm[gr.start + c / 3];
+        const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
+        unsigned char *dst = reinterpret_cast<unsigned char *>(ubuf + (size_t)b * Fp);
+        for (int blk = wave; blk * 64 < ngran; blk += MSD_THREADS / 64) {
+            const int gran = blk * 64 + lane;
+            if (gran < ngran) dma16(col + 2 * gran, dst + (size_t)blk * 1024);
+        }
+    };
+    double acc[WT];
 #pragma unroll
-            for (int e = 1; e < NV; e++) {
-                if (e < lim) {
-#pragma unroll
-                    for (int i = (e - WT + 1 > 0 ? e - WT + 1 : 0); i <= (e - 1 < COMB_B - 1 ? e - 1 : COMB_B - 1); i++) {
-                        const double dd = v[e] - v[i];
-                        acc[e - i] = fma(i == 0 ? dd * m0 : dd, dd, acc[e - i]);
-                    }
-                }
-            }
+    for (int w = 0; w < WT; w++) acc[w] = 0.0;
+    if (ncol > 0) issue(0, 0);
+    for (int c = 0; c < ncol; c++) {
+        double *u = ubuf + (size_t)(c & 1) * Fp;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of column c has landed
+        __syncthreads();                                    // everyone's has; column c - 1 is fully consumed
+        if (c + 1 < ncol) issue(c + 1, (c + 1) & 1);        // streams in behind the scan and the comb arithmetic
+        lds_scan(u, F, red, 0.0);
+        for (int t = tid; t < ntask; t += MSD_THREADS) {
+            const int r = t % d, J0 = (t / d) * COMB_B;
+            const int lim = (F - r + d - 1) / d - J0;   // valid comb entries of this task (from J0 on)
+            comb_task<WT>(u + r + (size_t)d * J0, d, lim, t == 0 ? 0.0 : 1.0, acc);
         }
     }
 #pragma unroll
@@ -553,11 +651,11 @@ __global__ __launch_bounds__(MSD_THREADS) void com_T_final_kernel(const double *
 __global__ __launch_bounds__(MSD_THREADS) void delta_T_kernel(const double *__restrict__ UT,
                                                               const double *__restrict__ com,
                                                               const double *__restrict__ geom, int n_cells,
-                                                              int64_t N, int64_t Fp, int F,
+                                                              int64_t N, int64_t Fp, int F, int64_t a_begin,
                                                               double *__restrict__ DT)
 {
     const int k = blockIdx.y * MSD_THREADS + threadIdx.x;
-    const size_t a = blockIdx.x;
+    const size_t a = (size_t)a_begin + blockIdx.x;
     if (k >= F) return;
     double dx = 0.0, dy = 0.0, dz = 0.0;
     if (k >= 1) {
@@ -700,20 +798,33 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     AMOF_TRY(ensure(ctx, SLOT_AUX5, groups.size() * (size_t)W * sizeof(double), &d_part));
     AMOF_TRY(ensure(ctx, SLOT_OUT0, (size_t)S * W * sizeof(double), &d_out));
 
-    dim3 tgrid((unsigned)((N + TR_A - 1) / TR_A), (unsigned)((F + TR_F - 1) / TR_F));
+    // transposition tile: 32 frames x 64 atoms, 1024 threads (two consecutive frames per thread).  Measured on the
+    // MI355X for the headline shape (profiles/r02/msd_transpose_shapes.txt): 0.52 ms = 4.5 TB/s of read + write; a
+    // flat copy of the same bytes (torch) takes 0.46 ms.  Four or eight frames per thread: 0.57 / 1.18 ms.
+    auto transpose = [&](const double *com_dev, int64_t a0, int64_t a1) -> hipError_t {
+        constexpr int TF = 32, TA = 64, TH = 1024;
+        auto go = [&](auto kern) -> hipError_t {
+            const size_t lds = (size_t)TF * (3 * TA + 1) * sizeof(double);
+            hipError_t e = allow_max_lds((const void *)kern);
+            if (e != hipSuccess) return e;
+            dim3 grid((unsigned)((a1 - a0 + TA - 1) / TA), (unsigned)((F + TF - 1) / TF));
+            hipLaunchKernelGGL(kern, grid, dim3(TH), lds, ctx->stream, pos_dev, com_dev, (const double *)d_geom,
+                               (int)t->n_cells, N, (int)F, Fp, a0, a1, (double *)d_DT);
+            return hipGetLastError();
+        };
+        return hg.all_ortho ? go(delta_transpose_kernel<TF, TA, TH, true>) : go(delta_transpose_kernel<TF, TA, TH, false>);
+    };
     if (!unwrap) {
         if (remove_com) {
             hipLaunchKernelGGL(com_kernel, dim3((unsigned)F), dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
                                (const double *)d_mass, N, total_mass, (double *)d_com);
         }
-        hipLaunchKernelGGL(delta_transpose_kernel, tgrid, dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
-                           (const double *)d_com, (const double *)d_geom, (int)t->n_cells, N, (int)F, Fp,
-                           (double *)d_DT);
+        // only the atoms of this call's range are transposed (atom-sharded ranks each do their share)
+        AMOF_HIP_TRY(ctx, transpose((const double *)d_com, atom_begin, atom_end));
     } else {
+        // the unwrapped centre of mass needs every atom: all columns are transposed and scanned
         AMOF_TRY(ensure(ctx, SLOT_AUX4, dt_bytes, &d_UT));
-        hipLaunchKernelGGL(delta_transpose_kernel, tgrid, dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
-                           (const double *)nullptr, (const double *)d_geom, (int)t->n_cells, N, (int)F, Fp,
-                           (double *)d_DT);
+        AMOF_HIP_TRY(ctx, transpose((const double *)nullptr, 0, N));
         hipLaunchKernelGGL(scan_column_kernel, dim3((unsigned)(3 * N)), dim3(MSD_THREADS), 0, ctx->stream,
                            (const double *)d_DT, pos_dev, Fp, (int)F, (double *)d_UT);
         if (remove_com) {
@@ -727,9 +838,9 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
                                dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_cpart, nblk, Fp, (int)F, total_mass,
                                (double *)d_com);
         }
-        hipLaunchKernelGGL(delta_T_kernel, dim3((unsigned)N, (unsigned)((F + MSD_THREADS - 1) / MSD_THREADS)),
+        hipLaunchKernelGGL(delta_T_kernel, dim3((unsigned)(atom_end - atom_begin), (unsigned)((F + MSD_THREADS - 1) / MSD_THREADS)),
                            dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_UT, (const double *)d_com,
-                           (const double *)d_geom, (int)t->n_cells, N, Fp, (int)F, (double *)d_DT);
+                           (const double *)d_geom, (int)t->n_cells, N, Fp, (int)F, atom_begin, (double *)d_DT);
     }
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_dom_begin(ctx, "msd_global");
@@ -749,13 +860,20 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
                                (const int32_t *)d_win, (int)W, (double *)d_part);
             return hipGetLastError();
         };
-        auto launch_comb = [&](auto kern) -> hipError_t {
-            const size_t lds = (size_t)F * sizeof(double);
-            hipError_t e = allow_max_lds((const void *)kern);
+        // two column buffers (the next column streams in behind the arithmetic) when they fit twice per CU
+        const bool db = 2 * (size_t)Fp * sizeof(double) <= 80 * 1024 && !getenv("AMOF_MSD_NODB");
+        auto launch_comb = [&](auto kern, auto kern_db) -> hipError_t {
+            const size_t lds = db ? 2 * (size_t)Fp * sizeof(double) : (size_t)F * sizeof(double);
+            hipError_t e = db ? allow_max_lds((const void *)kern_db) : allow_max_lds((const void *)kern);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
-                               (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
-                               comb_d, (int)std::min(W, 32), (int)W, (double *)d_part);
+            if (db)
+                hipLaunchKernelGGL(kern_db, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
+                                   (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
+                                   comb_d, (int)std::min(W, 32), (int)W, (double *)d_part);
+            else
+                hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
+                                   (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
+                                   comb_d, (int)std::min(W, 32), (int)W, (double *)d_part);
             return hipGetLastError();
         };
         // windows 32 .. W-1 in further passes of up to 32 (each re-reads the columns)
@@ -770,15 +888,15 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         };
         ctx->last_path = comb_d > 0 ? "msd_comb" : "msd_group";
         hipError_t e;
-        if (comb_d > 0 && W <= 4) e = launch_comb(msd_comb_kernel<4>);
-        else if (comb_d > 0 && W <= 8) e = launch_comb(msd_comb_kernel<8>);
-        else if (comb_d > 0 && W <= 12) e = launch_comb(msd_comb_kernel<12>);
-        else if (comb_d > 0 && W <= 16) e = launch_comb(msd_comb_kernel<16>);
-        else if (comb_d > 0 && W <= 20) e = launch_comb(msd_comb_kernel<20>);
-        else if (comb_d > 0 && W <= 24) e = launch_comb(msd_comb_kernel<24>);
-        else if (comb_d > 0 && W <= 28) e = launch_comb(msd_comb_kernel<28>);
+        if (comb_d > 0 && W <= 4) e = launch_comb(msd_comb_kernel<4>, msd_comb_db_kernel<4>);
+        else if (comb_d > 0 && W <= 8) e = launch_comb(msd_comb_kernel<8>, msd_comb_db_kernel<8>);
+        else if (comb_d > 0 && W <= 12) e = launch_comb(msd_comb_kernel<12>, msd_comb_db_kernel<12>);
+        else if (comb_d > 0 && W <= 16) e = launch_comb(msd_comb_kernel<16>, msd_comb_db_kernel<16>);
+        else if (comb_d > 0 && W <= 20) e = launch_comb(msd_comb_kernel<20>, msd_comb_db_kernel<20>);
+        else if (comb_d > 0 && W <= 24) e = launch_comb(msd_comb_kernel<24>, msd_comb_db_kernel<24>);
+        else if (comb_d > 0 && W <= 28) e = launch_comb(msd_comb_kernel<28>, msd_comb_db_kernel<28>);
         else if (comb_d > 0) {
-            e = launch_comb(msd_comb_kernel<32>);
+            e = launch_comb(msd_comb_kernel<32>, msd_comb_db_kernel<32>);
             for (int w0 = 32; w0 < W && e == hipSuccess; w0 += 32) {
                 const int wn = std::min(32, (int)W - w0);
                 if (wn <= 8) e = launch_comb_hi(msd_comb_hi_kernel<8>, w0, wn);

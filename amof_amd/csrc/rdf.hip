@@ -408,14 +408,11 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
 // centre atoms' slab range -- removes the same share of work from every wave.
 constexpr int FAST_SUB = 128;
 
-typedef __attribute__((address_space(1))) const void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
-
 // One wave copies 64 x 16 B from per-lane global addresses to 1 KiB of LDS at `dst`
 // (wave-uniform), without passing through registers (LDS-DMA, global_load_lds_dwordx4).
 __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
 {
-    __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst_wave, 16, 0, 0);
+    dma16(src_lane, dst_wave);
 }
 
 template <bool ORTHO, bool CULL, bool IMG = false>

@@ -222,11 +222,32 @@ class PackedTrajectory(object):
         pos = torch.as_tensor(self.pos_host()).to(torch.device("cuda", device))
         return PackedTrajectory(pos, self.cell, self.numbers, self.masses, self.pbc)
 
+    # -- per-trajectory constants, computed once (``numbers`` is never modified after construction) --------------
+    def _const(self, key, make):
+        cache = self.__dict__.setdefault("_const_cache", {})
+        if key not in cache:
+            cache[key] = make()
+        return cache[key]
+
+    def unique_numbers(self):
+        """``list(set(atoms.get_atomic_numbers()))`` -- the reference's species order (amof/rdf.py:71,
+        amof/atom.py:44-46), which fixes DataFrame column order."""
+        return list(self._const("unique", lambda: list(set(self.numbers))))
+
+    def species_counts(self):
+        """``{atomic number: number of atoms}``"""
+        def make():
+            zs, counts = np.unique(self.numbers, return_counts=True)
+            return {int(z): int(c) for z, c in zip(zs, counts)}
+        return self._const("counts", make)
+
     def formula_count(self):
         """``{symbol: count}`` in order of first appearance (``atoms.symbols.formula._count``)."""
-        zs, first, counts = np.unique(self.numbers, return_index=True, return_counts=True)
-        order = np.argsort(first)
-        return {_data.chemical_symbols[int(zs[k])]: int(counts[k]) for k in order}
+        def make():
+            zs, first, counts = np.unique(self.numbers, return_index=True, return_counts=True)
+            order = np.argsort(first)
+            return {_data.chemical_symbols[int(zs[k])]: int(counts[k]) for k in order}
+        return dict(self._const("formula", make))
 
     def frame(self, k):
         """Materialise frame ``k`` as a :class:`Frame` (host copy)."""

@@ -82,7 +82,7 @@ class DirectMsd(Msd):
     def compute_msd(self, trajectory, step, parallel=False, device=None):
         packed = pack_trajectory(trajectory)
         logger.info("Start computing msd for %s frames", len(packed))
-        elements = list(set(packed.numbers))
+        elements = packed.unique_numbers()
         dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
         msd, kinds = _hip.get_context(dev).msd_direct(packed)
         self.data = pd.DataFrame({"Step": step})
@@ -134,7 +134,7 @@ class WindowMsd(Msd):
     def compute_msd(self, trajectory, window, time, parallel=False, unwrap=False, device=None, distributed=None):
         """compute the window MSD (reference amof/msd.py:207-268)"""
         packed = pack_trajectory(trajectory)
-        elements = list(set(packed.numbers))
+        elements = packed.unique_numbers()
         if unwrap == True:  # noqa: E712  (the reference compares with ==)
             logger.info("Unwrap trajectory before computing msd")
         logger.info("Start computing msd at %s times on a trajectory of %s frames", len(window), len(packed))
@@ -152,11 +152,11 @@ class WindowMsd(Msd):
         self.sumsq = sumsq
         idx = {z: k for k, z in enumerate(kinds)}
 
-        self.data = pd.DataFrame({"Time": time})
         denom = (F - np.asarray(window)).astype(np.float64)
+        counts = packed.species_counts()
+        cols = {"Time": time}
         for e in elements:
-            n_e = int((packed.numbers == e).sum())
-            self.data[_data.chemical_symbols[int(e)]] = sumsq[idx[int(e)]] / n_e / denom
+            cols[_data.chemical_symbols[int(e)]] = sumsq[idx[int(e)]] / counts[int(e)] / denom
         # formula-weighted total (amof/msd.py:263-268)
         if isinstance(trajectory, PackedTrajectory):
             formula_dict = packed.formula_count()
@@ -164,5 +164,6 @@ class WindowMsd(Msd):
             formula_dict = trajectory[0].symbols.formula._count
         acc = 0.0
         for k, v in formula_dict.items():
-            acc = acc + self.data[k].values * v
-        self.data['X'] = acc / sum(formula_dict.values())
+            acc = acc + cols[k] * v
+        cols['X'] = acc / sum(formula_dict.values())
+        self.data = pd.DataFrame(cols)

@@ -81,7 +81,7 @@ class Rdf(object):
     def compute_rdf(self, trajectory, dr, rmax, device=None, distributed=None):
         """compute rdf from a trajectory (reference amof/rdf.py:67-114)"""
         packed = pack_trajectory(trajectory)
-        atomic_numbers_unique = list(set(packed.numbers))
+        atomic_numbers_unique = packed.unique_numbers()
         N_species = len(atomic_numbers_unique)
         rank, world = (0, 1) if distributed is False else _dist.world()
         merge = distributed is not False and _dist.merging(world)
@@ -100,8 +100,8 @@ class Rdf(object):
         logger.info("Start computing rdf for %s frames with dr = %s and rmax = %s", len(packed), dr, rmax)
         bins = int(rmax // dr)          # Python float floor-division, as the reference (amof/rdf.py:82)
         r = np.arange(bins) * dr
-        self.data = pd.DataFrame({"r": r})
         if bins <= 0:
+            self.data = pd.DataFrame({"r": r})
             raise ValueError("rmax // dr gives no bin")
 
         F_local = len(packed)
@@ -115,7 +115,7 @@ class Rdf(object):
         if merge and _dist.device_collectives():
             # the histogram stays in HBM from the kernels through the RCCL all-reduce (amof_rdf_accumulate_dev)
             import torch
-            S = len(_hip.species_index(packed.numbers)[0])
+            S = len(_hip.packed_species(packed)[0])
             out = torch.zeros((S, S, bins), dtype=torch.int64, device=torch.device("cuda", ctx.device))
             _, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range, out=out)
             tot = torch.tensor([vol_sum, float(n_frames)], dtype=torch.float64).to(out.device)
@@ -137,26 +137,34 @@ class Rdf(object):
 
         natoms = packed.n_atoms
         mean_volume = vol_sum / n_frames
-        counts = {z: int((packed.numbers == z).sum()) for z in kinds}
+        counts = packed.species_counts()
         idx = {z: k for k, z in enumerate(kinds)}
 
-        # Total RDF
-        self.data["X-X"] = normalize_rdf(hist.sum(axis=(0, 1)), n_frames * natoms, natoms, mean_volume, rmax, bins)
-
-        # Partial RDFs (cartesian product of the species, reference order)
-        partial_rdf = [[None for y in atomic_numbers_unique] for x in atomic_numbers_unique]
-        cols = {}
+        # every column from ONE broadcast normalisation, one DataFrame construction (column order as the reference:
+        # r, X-X, the cartesian product of the species, then the A-X sums; amof/rdf.py:96-114)
+        ncount = np.array([n_frames * counts[z] for z in kinds], dtype=np.float64)
+        partial = normalize_rdf(hist, ncount[:, None, None], natoms, mean_volume, rmax, bins)      # [S][S][bins]
+        names = ["r", "X-X"]
+        table = np.empty((2 + N_species * N_species + N_species, bins), dtype=np.float64)   # one row per column
+        table[0] = r
+        table[1] = normalize_rdf(hist.sum(axis=(0, 1)), n_frames * natoms, natoms, mean_volume, rmax, bins)
+        sidx = [idx[int(z)] for z in atomic_numbers_unique]
+        syms = [_data.chemical_symbols[int(z)] for z in atomic_numbers_unique]
+        row = 2
         for i in range(N_species):
             for j in range(N_species):
-                za, zb = int(atomic_numbers_unique[i]), int(atomic_numbers_unique[j])
-                xx_str = _data.chemical_symbols[za] + "-" + _data.chemical_symbols[zb]
-                partial_rdf[i][j] = normalize_rdf(hist[idx[za], idx[zb]], n_frames * counts[za], natoms,
-                                                  mean_volume, rmax, bins)
-                cols[xx_str] = partial_rdf[i][j]
+                names.append(syms[i] + "-" + syms[j])
+                table[row] = partial[sidx[i], sidx[j]]
+                row += 1
         for i in range(N_species):
-            za = int(atomic_numbers_unique[i])
-            cols[_data.chemical_symbols[za] + "-X"] = sum([partial_rdf[i][j] for j in range(N_species)])
-        self.data = pd.concat([self.data, pd.DataFrame(cols)], axis=1)
+            # sum([...]) of the reference: 0 + g_A0 + g_A1 + ... in species order (amof/rdf.py:114)
+            acc = 0
+            for j in range(N_species):
+                acc = acc + partial[sidx[i], sidx[j]]
+            names.append(syms[i] + "-X")
+            table[row] = acc
+            row += 1
+        self.data = pd.DataFrame(table.T, columns=names)     # (a single float64 block: no per-column handling)
 
     def write_to_file(self, filename):
         filename = _path.append_suffix(filename, 'rdf')
