@@ -164,7 +164,7 @@ class BadByCn(CoreBad):
     (``{triple: {cn: density[theta]}}``), ``.theta`` and the integer counts ``.hist``.
     """
 
-    CN_MAX = 16
+    CN_MAX = 16      # first guess of the largest coordination number (slots of the device histogram); grows on demand
 
     def __init__(self):
         """default constructor"""
@@ -205,22 +205,29 @@ class BadByCn(CoreBad):
         frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
         dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
         ctx = _hip.get_context(dev)
-        if triples:
-            hist, nang = ctx.bad_hist_by_cn(packed, rcm, triples, theta_bins, cn_max=self.CN_MAX, frame_range=frame_range)
-        else:
-            hist = np.zeros((0, self.CN_MAX + 1, bins + 1), dtype=np.uint64)
-            nang = np.zeros((0, self.CN_MAX + 1), dtype=np.uint64)
+        # the last slot (cn_max) also collects every larger neighbour count: when it is populated, count again with
+        # more slots -- the reference has no limit on the coordination number (amof/bad.py:190-224)
+        cn_max = self.CN_MAX
+        while True:
+            if triples:
+                hist, nang = ctx.bad_hist_by_cn(packed, rcm, triples, theta_bins, cn_max=cn_max, frame_range=frame_range)
+            else:
+                hist = np.zeros((0, cn_max + 1, bins + 1), dtype=np.uint64)
+                nang = np.zeros((0, cn_max + 1), dtype=np.uint64)
+            full = float(nang[:, cn_max].any()) if nang.size else 0.0
+            if merge:
+                full = _dist.all_reduce_sum(np.array([full]))[0]     # every rank must take the same decision
+            if not full:
+                break
+            cn_max *= 4
         if merge:
             hist = _dist.all_reduce_sum(hist)
             nang = _dist.all_reduce_sum(nang)
-        if nang.size and nang[:, self.CN_MAX].any():
-            raise _hip.AmofError(_hip.AMOF_ECAPACITY, "a centre has %d or more neighbours; BadByCn.CN_MAX is %d"
-                                 % (self.CN_MAX, self.CN_MAX))
         self.hist, self.n_angles, self.columns, self.theta = hist, nang, names, theta
         db = np.array(np.diff(theta_bins), float)
         self.bad = {}
         for k, aba_str in enumerate(names):
-            cns = [c for c in range(2, self.CN_MAX) if nang[k, c] != 0]
+            cns = [c for c in range(2, cn_max) if nang[k, c] != 0]
             if not cns:
                 continue                          # no angle at all: triple omitted (amof/bad.py:282)
             num_angles_all = int(nang[k].sum())

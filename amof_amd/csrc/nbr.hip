@@ -49,8 +49,14 @@ struct NbrArgs {
     int32_t nb;
     unsigned long long *hist;  // [T][nb]
     unsigned long long *n_angles;
-    int32_t *flags;            // [0] zero-length vector, [1] neighbour overflow
+    int32_t *flags;            // [0] zero-length vector, [1] neighbour overflow, [2] largest neighbour count (count pass)
     int32_t cn_max;            // > 0: histograms keyed by the centre's neighbour count (BadByCn)
+    // big-list pass of bad_kernel (centres with more than AMOF_MAX_NEIGHBOURS neighbours): the unit vectors live in
+    // global scratch, [workgroup][3][ncap][BAD_TILE] doubles, instead of LDS
+    double *nbuf;
+    int32_t ncap;
+    int32_t count_only;        // 1: only find the largest neighbour count (flags[2])
+    int32_t global_hist;       // 1: more angle bins than LDS holds -- count with global atomics
 };
 
 // ------------------------------------------------------------------- CN ----
@@ -144,11 +150,13 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // unit vectors of the neighbours, [slot][lane] so that a lane's accesses
-    // never conflict with its neighbours'
-    double *ux = reinterpret_cast<double *>(lds_raw);
-    double *uy = ux + AMOF_MAX_NEIGHBOURS * BAD_TILE;
-    double *uz = uy + AMOF_MAX_NEIGHBOURS * BAD_TILE;
-    double *tjx = uz + AMOF_MAX_NEIGHBOURS * BAD_TILE;
+    // never conflict with its neighbours' (LDS; the big-list pass keeps them in global scratch)
+    double *lds_u = reinterpret_cast<double *>(lds_raw);
+    const int cap = a.nbuf ? a.ncap : AMOF_MAX_NEIGHBOURS;
+    double *ux = a.nbuf ? a.nbuf + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 * (size_t)cap * BAD_TILE : lds_u;
+    double *uy = ux + (size_t)cap * BAD_TILE;
+    double *uz = uy + (size_t)cap * BAD_TILE;
+    double *tjx = lds_u + 3 * AMOF_MAX_NEIGHBOURS * BAD_TILE;
     double *tjy = tjx + BAD_TILE;
     double *tjz = tjy + BAD_TILE;
     int *tja = reinterpret_cast<int *>(tjz + BAD_TILE);
@@ -163,7 +171,8 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
     const int f0 = blockIdx.y * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, a.F);
     const int nb = a.nb;
-    for (int k = tid; k < nb; k += BAD_TILE) hist[k] = 0u;
+    const bool direct = a.cn_max > 0 || a.global_hist;     // straight into global memory (no LDS histogram)
+    for (int k = tid; k < nb && !a.global_hist; k += BAD_TILE) hist[k] = 0u;
     unsigned long long nang = 0;
 
     for (int f = f0; f < f1; f++) {
@@ -220,10 +229,12 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
                             if (!(nv > 0.0)) { a.flags[0] = 1; continue; }
                             double qx = bx / nv, qy = by / nv, qz = bz / nv;
                             for (int h = 0; h < hits; h++) {
-                                if (n < AMOF_MAX_NEIGHBOURS) {
-                                    ux[n * BAD_TILE + tid] = qx;
-                                    uy[n * BAD_TILE + tid] = qy;
-                                    uz[n * BAD_TILE + tid] = qz;
+                                if (a.count_only) {
+                                    n++;
+                                } else if (n < cap) {
+                                    ux[(size_t)n * BAD_TILE + tid] = qx;
+                                    uy[(size_t)n * BAD_TILE + tid] = qy;
+                                    uz[(size_t)n * BAD_TILE + tid] = qz;
                                     n++;
                                 } else {
                                     a.flags[1] = 1;
@@ -234,17 +245,21 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
                 }
             }
         }
+        if (a.count_only) {
+            if (n > 0) atomicMax(&a.flags[2], n);
+            continue;
+        }
         // every unordered pair of neighbours of this centre -> one angle
         for (int u = 0; u < n; u++) {
-            const double ax = ux[u * BAD_TILE + tid], ay = uy[u * BAD_TILE + tid], az = uz[u * BAD_TILE + tid];
+            const double ax = ux[(size_t)u * BAD_TILE + tid], ay = uy[(size_t)u * BAD_TILE + tid], az = uz[(size_t)u * BAD_TILE + tid];
             for (int v = u + 1; v < n; v++) {
-                double dot = ax * ux[v * BAD_TILE + tid] + ay * uy[v * BAD_TILE + tid] + az * uz[v * BAD_TILE + tid];
+                double dot = ax * ux[(size_t)v * BAD_TILE + tid] + ay * uy[(size_t)v * BAD_TILE + tid] + az * uz[(size_t)v * BAD_TILE + tid];
                 if (dot > 1.0) dot = 1.0;
                 if (dot < -1.0) dot = -1.0;
                 double ang = (180.0 / M_PI) * acos(dot);
                 int k = hist_bin(a.edges, nb, ang);
-                if (a.cn_max > 0) {     // keyed by the number of B-neighbours of this centre
-                    const size_t slot = (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max);
+                if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
+                    const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
                     atomicAdd(&a.n_angles[slot], 1ull);
                     if (k >= 0) atomicAdd(&a.hist[slot * nb + k], 1ull);
                 } else {
@@ -256,12 +271,12 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
     }
     __syncthreads();
     unsigned long long *H = a.hist + (size_t)trip * nb;
-    for (int k = tid; k < nb && a.cn_max == 0; k += BAD_TILE) {
+    for (int k = tid; k < nb && !direct; k += BAD_TILE) {
         unsigned v = hist[k];
         if (v) atomicAdd(&H[k], (unsigned long long)v);
     }
     for (int off = 32; off > 0; off >>= 1) nang += __shfl_down(nang, off, 64);
-    if (tid == 0 && nang) atomicAdd(&a.n_angles[trip], nang);
+    if (tid == 0 && nang) atomicAdd(&a.n_angles[trip], nang);     // (nang stays 0 in the direct modes)
 }
 
 // --------------------------------------------------------------------------
@@ -440,7 +455,8 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
     const int cnt_c = min(NBRF_TILE, nA - c0);
     const bool has = tid < cnt_c;
     const int nb = a.nb;
-    for (int k = tid; k < nb; k += NBRF_TILE) hist[k] = 0u;
+    const bool direct = a.cn_max > 0 || a.global_hist;     // straight into global memory (no LDS histogram)
+    for (int k = tid; k < nb && !a.global_hist; k += NBRF_TILE) hist[k] = 0u;
     unsigned long long nang = 0;
     const int f0 = blockIdx.y * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
@@ -515,8 +531,8 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
                     if (dot < -1.0) dot = -1.0;
                     const double ang = (180.0 / M_PI) * acos(dot);
                     const int k = hist_bin(a.edges, nb, ang);
-                    if (a.cn_max > 0) {     // keyed by the number of B-neighbours of this centre
-                        const size_t slot = (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max);
+                    if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
+                        const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
                         atomicAdd(&a.n_angles[slot], 1ull);
                         if (k >= 0) atomicAdd(&a.hist[slot * nb + k], 1ull);
                     } else {
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
     }
     __syncthreads();
     unsigned long long *H = a.hist + (size_t)trip * nb;
-    for (int k = tid; k < nb && a.cn_max == 0; k += NBRF_TILE) {
+    for (int k = tid; k < nb && !direct; k += NBRF_TILE) {
         unsigned v = hist[k];
         if (v) atomicAdd(&H[k], (unsigned long long)v);
     }
@@ -817,20 +833,42 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
     void *d_work, *d_edges, *d_flags;
     AMOF_TRY(upload(ctx, SLOT_PAIRS, work.data(), work.size() * sizeof(int4), &d_work));
     AMOF_TRY(upload(ctx, SLOT_AUX3, edges, (size_t)(nb + 1) * sizeof(double), &d_edges));
-    AMOF_TRY(ensure(ctx, SLOT_FLAGS, 2 * sizeof(int32_t), &d_flags));
-    AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 2 * sizeof(int32_t), ctx->stream));
+    AMOF_TRY(ensure(ctx, SLOT_FLAGS, 4 * sizeof(int32_t), &d_flags));
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 4 * sizeof(int32_t), ctx->stream));
     NbrArgs &a = st.a;
     a.work = (const int4 *)d_work;
     a.edges = (const double *)d_edges;
     a.nb = nb;
-    a.hist = hist_dev;
-    a.n_angles = nang_dev;
     a.flags = (int32_t *)d_flags;
     a.cn_max = cn_max;
+    a.nbuf = nullptr;
+    a.ncap = 0;
+    a.count_only = 0;
+    a.global_hist = nb > AMOF_MAX_LDS_BINS - 16384 ? 1 : 0;      // (the reference has no limit on the bin count)
+    const size_t lds_bins = a.global_hist ? 0 : (size_t)nb;
     const size_t KC = (size_t)(cn_max > 0 ? cn_max + 1 : 1);   // histogram slots per triple
+    // every pass accumulates into scratch; the caller's buffers only ever receive a complete, valid result
+    const size_t hs_words = (size_t)T * KC * nb + (size_t)T * KC;
+    void *d_hs, *d_ns;
+    AMOF_TRY(ensure(ctx, SLOT_AUX7, hs_words * sizeof(unsigned long long), &d_hs));
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(d_hs, 0, hs_words * sizeof(unsigned long long), ctx->stream));
+    d_ns = (unsigned long long *)d_hs + (size_t)T * KC * nb;
+    a.hist = (unsigned long long *)d_hs;
+    a.n_angles = (unsigned long long *)d_ns;
+    auto read_flags = [&](int32_t (&fl)[4]) -> int {
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(fl, d_flags, sizeof fl, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return AMOF_OK;
+    };
+    auto clear_scratch = [&]() -> int {
+        AMOF_HIP_TRY(ctx, hipMemsetAsync(d_hs, 0, hs_words * sizeof(unsigned long long), ctx->stream));
+        AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 4 * sizeof(int32_t), ctx->stream));
+        return AMOF_OK;
+    };
     NbrFast nf;
     AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf));
-    bool done = false;
+    bool done = false, overflow = false;
+    int32_t flags[4] = {0, 0, 0, 0};
     if (nf.ok && t->n_frames > 0) {
         const int S = t->n_species;
         std::vector<int4> fwork;
@@ -843,17 +881,10 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         }
         void *d_fwork;
         AMOF_TRY(upload(ctx, SLOT_AUX6, fwork.data(), fwork.size() * sizeof(int4), &d_fwork));
-        // the fast kernels accumulate into scratch so that a fallback can start from a clean slate
-        void *d_hs, *d_ns;
-        AMOF_TRY(ensure(ctx, SLOT_AUX7, ((size_t)T * KC * nb + (size_t)T * KC) * sizeof(unsigned long long), &d_hs));
-        AMOF_HIP_TRY(ctx, hipMemsetAsync(d_hs, 0, ((size_t)T * KC * nb + (size_t)T * KC) * sizeof(unsigned long long), ctx->stream));
-        d_ns = (unsigned long long *)d_hs + (size_t)T * KC * nb;
         nf.fa.a = a;
         nf.fa.a.work = (const int4 *)d_fwork;
-        nf.fa.a.hist = (unsigned long long *)d_hs;
-        nf.fa.a.n_angles = (unsigned long long *)d_ns;
         size_t lds = NBRF_TILE * sizeof(uint4) + (size_t)AMOF_MAX_NEIGHBOURS * NBRF_TILE * sizeof(uint32_t) +
-                     (size_t)nb * sizeof(unsigned);
+                     lds_bins * sizeof(unsigned);
         int64_t launches = 0;
         for (int64_t fb = 0, cur = nf.FB0; fb < t->n_frames && !fwork.empty(); fb += cur, cur = std::min<int64_t>(2 * cur, nf.FB)) {
             const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
@@ -882,47 +913,86 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         timing_dom_end(ctx, launches);
         int32_t qflag = 0;
         AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nf.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
-        AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (!qflag) {
-            hipLaunchKernelGGL(add_u64_kernel, dim3(64), dim3(256), 0, ctx->stream, hist_dev,
-                               (const unsigned long long *)d_hs, (size_t)T * KC * nb);
-            hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, nang_dev,
-                               (const unsigned long long *)d_ns, (size_t)T * KC);
-            AMOF_HIP_TRY(ctx, hipGetLastError());
+        AMOF_TRY(read_flags(flags));
+        if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
+        if (qflag) {           // atoms absurdly far from the cell: redo with the exact kernel
+            AMOF_TRY(clear_scratch());
+        } else if (flags[1]) { // a centre has more than AMOF_MAX_NEIGHBOURS neighbours: big-list pass below
+            overflow = true;
+            AMOF_TRY(clear_scratch());
+        } else {
             done = true;
-        } else {   // atoms absurdly far from the cell: redo with the exact kernel
-            AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 2 * sizeof(int32_t), ctx->stream));
         }
     }
     AMOF_TRY(stager_need(st.stage, t->n_frames));   // (no-op unless the fast path was skipped)
-    if (!done && !work.empty() && t->n_frames > 0) {
-        unsigned chunks;
-        pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
-        dim3 grid((unsigned)work.size(), chunks);
-        size_t lds = (size_t)(3 * AMOF_MAX_NEIGHBOURS * BAD_TILE + 3 * BAD_TILE) * sizeof(double) +
-                     BAD_TILE * sizeof(int) + (size_t)nb * sizeof(unsigned);
-        const bool extra = st.max_img > 0, ortho = st.geom.all_ortho;
+    const bool extra = st.max_img > 0, ortho = st.geom.all_ortho;
+    const size_t lds_exact = (size_t)(3 * AMOF_MAX_NEIGHBOURS * BAD_TILE + 3 * BAD_TILE) * sizeof(double) +
+                             BAD_TILE * sizeof(int) + lds_bins * sizeof(unsigned);
+    auto launch_exact = [&](dim3 grid) -> hipError_t {
         auto launch = [&](auto kern) -> hipError_t {
             hipError_t e = allow_max_lds((const void *)kern);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, dim3(BAD_TILE), lds, ctx->stream, a);
+            hipLaunchKernelGGL(kern, grid, dim3(BAD_TILE), lds_exact, ctx->stream, a);
             return hipGetLastError();
         };
+        if (ortho && !extra) return launch(bad_kernel<true, false>);
+        if (ortho && extra) return launch(bad_kernel<true, true>);
+        if (!ortho && !extra) return launch(bad_kernel<false, false>);
+        return launch(bad_kernel<false, true>);
+    };
+    if (!done && !overflow && !work.empty() && t->n_frames > 0) {
+        unsigned chunks;
+        pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
         timing_dom_begin(ctx, "bad_exact");
-        hipError_t e;
-        if (ortho && !extra) e = launch(bad_kernel<true, false>);
-        else if (ortho && extra) e = launch(bad_kernel<true, true>);
-        else if (!ortho && !extra) e = launch(bad_kernel<false, false>);
-        else e = launch(bad_kernel<false, true>);
-        AMOF_HIP_TRY(ctx, e);
+        AMOF_HIP_TRY(ctx, launch_exact(dim3((unsigned)work.size(), chunks)));
         timing_dom_end(ctx, 1);
+        AMOF_TRY(read_flags(flags));
+        if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
+        if (flags[1]) {
+            overflow = true;
+            AMOF_TRY(clear_scratch());
+        }
+    }
+    if (overflow && !work.empty() && t->n_frames > 0) {
+        // Big-list pass.  The reference has no limit on the neighbours of a centre (amof/bad.py:87-100): find the
+        // largest neighbour count with a counting pass of the exact kernel, then run that kernel once more with its
+        // per-centre lists of unit vectors in global scratch, [workgroup][3][cap][BAD_TILE] doubles.
+        unsigned chunks;
+        pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
+        a.count_only = 1;
+        AMOF_HIP_TRY(ctx, launch_exact(dim3((unsigned)work.size(), chunks)));
+        AMOF_TRY(read_flags(flags));
+        a.count_only = 0;
+        const int64_t cap = std::max<int64_t>(flags[2], 1);
+        const size_t per_wg = (size_t)3 * (size_t)cap * BAD_TILE * sizeof(double);
+        const size_t budget = (size_t)2 << 30;
+        // fewer, longer frame chunks until the scratch of all workgroups fits the budget
+        int64_t max_wg = std::max<int64_t>(1, (int64_t)(budget / per_wg));
+        int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>(chunks, max_wg / (int64_t)work.size()));
+        a.frames_per_chunk = (int32_t)((t->n_frames + nchunks - 1) / nchunks);
+        nchunks = (t->n_frames + a.frames_per_chunk - 1) / a.frames_per_chunk;
+        void *d_nbuf;
+        AMOF_TRY(ensure(ctx, SLOT_AUX8, per_wg * work.size() * (size_t)nchunks, &d_nbuf));
+        a.nbuf = (double *)d_nbuf;
+        a.ncap = (int32_t)cap;
+        AMOF_TRY(clear_scratch());
+        timing_dom_begin(ctx, "bad_exact_biglist");
+        AMOF_HIP_TRY(ctx, launch_exact(dim3((unsigned)work.size(), (unsigned)nchunks)));
+        timing_dom_end(ctx, 1);
+        AMOF_TRY(read_flags(flags));
+        if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
+        if (flags[1]) return fail(ctx, AMOF_EHIP, "internal error: neighbour list overflow in the big-list pass");
+    }
+    // complete and valid: add to the caller's (device) buffers
+    if (T > 0 && t->n_frames > 0) {
+        hipLaunchKernelGGL(add_u64_kernel, dim3(64), dim3(256), 0, ctx->stream, hist_dev,
+                           (const unsigned long long *)d_hs, (size_t)T * KC * nb);
+        hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(64), 0, ctx->stream, nang_dev,
+                           (const unsigned long long *)d_ns, (size_t)T * KC);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
     }
     timing_end(ctx);
-    int32_t flags[2] = {0, 0};
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
     AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
-    if (flags[1]) return fail(ctx, AMOF_ECAPACITY, "an atom has more than %d neighbours within the cutoffs", AMOF_MAX_NEIGHBOURS);
     return AMOF_OK;
 }
 
@@ -932,7 +1002,6 @@ static int bad_check(amof_ctx *ctx, const amof_traj *t, const double *cutoff, co
     AMOF_TRY(validate_traj(ctx, t, false));
     if (!cutoff || T < 0 || (T > 0 && !triples) || !edges || !hist || !nang) return fail(ctx, AMOF_EINVAL, "NULL argument");
     if (nb <= 0) return fail(ctx, AMOF_EINVAL, "nb must be positive");
-    if (nb > AMOF_MAX_LDS_BINS - 16384) return fail(ctx, AMOF_ECAPACITY, "at most %d angle bins", AMOF_MAX_LDS_BINS - 16384);
     for (int k = 0; k < nb; k++)
         if (!(edges[k + 1] > edges[k])) return fail(ctx, AMOF_EINVAL, "edges must increase strictly");
     for (int k = 0; k < T; k++)
@@ -978,7 +1047,7 @@ extern "C" int amof_bad_hist_by_cn(amof_ctx *ctx, const amof_traj *t, const doub
 {
     if (!ctx) return AMOF_EINVAL;
     AMOF_TRY(bad_check(ctx, t, cutoff, triples, T, edges, nb, hist, n_angles));
-    if (cn_max < 1 || cn_max > AMOF_MAX_NEIGHBOURS) return fail(ctx, AMOF_EINVAL, "cn_max must be 1..%d", AMOF_MAX_NEIGHBOURS);
+    if (cn_max < 1 || cn_max > 65535) return fail(ctx, AMOF_EINVAL, "cn_max must be 1..65535");
     if (T == 0) return AMOF_OK;
     AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     void *d_hist, *d_nang;

@@ -42,10 +42,11 @@ extern "C" {
 
 #define AMOF_ABI_VERSION 1
 
-/* capacities (AMOF_ECAPACITY when exceeded) */
-#define AMOF_MAX_LDS_BINS 36864     /* histogram bins held in LDS per workgroup (u32) */
-#define AMOF_MAX_NEIGHBOURS 32      /* neighbours per centre atom in the BAD kernel */
-#define AMOF_MAX_IMAGES 4096        /* extra periodic images per frame */
+/* capacities */
+#define AMOF_MAX_LDS_BINS 36864     /* histogram bins held in LDS per workgroup (u32); more bins: global-memory kernels */
+#define AMOF_MAX_NEIGHBOURS 32      /* neighbours per centre atom the BAD kernels keep in LDS; a centre with more sends
+                                       the call through a second pass with lists in global memory (no error) */
+#define AMOF_MAX_IMAGES 4096        /* extra periodic images per frame (AMOF_ECAPACITY when exceeded) */
 
 typedef struct amof_ctx amof_ctx;
 
@@ -94,7 +95,7 @@ double amof_last_kernel_seconds(const amof_ctx *ctx, int which);
 /* number of launches of the dominant kernel in the last call */
 int64_t amof_last_kernel_launches(const amof_ctx *ctx);
 /* kernel family that produced the result of the last call, e.g. "rdf_tile", "rdf_tile_img", "rdf_cell", "rdf_range",
- * "rdf_exact", "cn_fast", "cn_exact", "bad_fast", "bad_exact", "msd_comb", "msd_group", "msd_comb_global", "msd_global",
+ * "rdf_exact", "cn_fast", "cn_exact", "bad_fast", "bad_exact", "bad_exact_biglist", "msd_comb", "msd_group", "msd_comb_global", "msd_global",
  * "msd_direct" (diagnostics and tests; "" before the first call) */
 const char *amof_last_path(const amof_ctx *ctx);
 
@@ -154,7 +155,7 @@ int amof_bad_hist_dev(amof_ctx *ctx, const amof_traj *traj, const double *cutoff
  * Bond-angle histograms split by the centre atom's number of B-neighbours.
  * Replaces BadByCn.bad_BAB (amof/bad.py:190-224): slot c (0..cn_max) of triple t holds the
  * angles of centres with exactly c B-neighbours (c = cn_max also collects any larger count;
- * cn_max <= AMOF_MAX_NEIGHBOURS).  hist[(t*(cn_max+1) + c)*nb + k], n_angles[t*(cn_max+1) + c].
+ * 1 <= cn_max <= 65535).  hist[(t*(cn_max+1) + c)*nb + k], n_angles[t*(cn_max+1) + c].
  */
 int amof_bad_hist_by_cn(amof_ctx *ctx, const amof_traj *traj, const double *cutoff,
                         const int32_t *triples, int32_t n_triples, const double *edges, int32_t nb,

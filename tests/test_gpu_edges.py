@@ -97,11 +97,54 @@ def test_undefined_angle_raises_like_ase(hip_ctx):
         hip_ctx.bad_hist(packed, rcm, [(1, 0)], np.arange(181.0))
 
 
-def test_neighbour_capacity_error(hip_ctx):
-    packed = H.random_gas(200, [6.0, 6.0, 6.0], np.ones(200, int), 5)
-    with pytest.raises(_hip.AmofError) as e:
-        hip_ctx.bad_hist(packed, [[2.9]], [(0, 0)], np.arange(181.0))
-    assert e.value.code == _hip.AMOF_ECAPACITY
+def test_more_neighbours_than_the_lds_lists_hold(hip_ctx):
+    """The reference has no limit on the neighbours of a centre (amof/bad.py:87-100).  A dense gas with ~100
+    neighbours per atom exceeds the 32-entry LDS lists of the BAD kernels: the call goes through the big-list pass
+    (lists in global memory) and still equals the oracle; BadByCn keys by the true neighbour count."""
+    packed = H.random_gas(200, [6.0, 6.0, 6.0], np.array([1, 8] * 100), 5, F=3)
+    kinds, sp = H.species_of(packed.numbers)
+    rcm = np.array([[2.9, 2.2], [2.2, 2.9]])
+    triples = [(0, 0), (1, 0), (0, -1), (-1, -1)]
+    edges = np.arange(181.0)
+    h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, 2, rcm, triples, edges)
+    h_gpu, a_gpu = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_exact_biglist"
+    assert np.array_equal(a_gpu, a_ref) and np.array_equal(h_gpu, h_ref)
+    pa = clib.cn_counts(packed.pos, packed.cell, sp, 2, rcm, [(0, 0), (0, 1)], per_atom=True)[1]
+    assert pa.max() > 32
+    # a non-periodic axis and a cutoff that needs further images take the exact kernel first, then the same pass
+    packed.pbc = np.array([True, True, False])
+    h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, 2, rcm, triples, edges, pbc=packed.pbc)
+    h_gpu, a_gpu = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_exact_biglist"
+    assert np.array_equal(a_gpu, a_ref) and np.array_equal(h_gpu, h_ref)
+    packed.pbc = np.array([True, True, True])
+    cn_max = 150
+    hb_ref, ab_ref = clib.bad_hist_by_cn(packed.pos, packed.cell, sp, 2, rcm, triples[:2], edges, cn_max)
+    hb_gpu, ab_gpu = hip_ctx.bad_hist_by_cn(packed, rcm, triples[:2], edges, cn_max=cn_max)
+    assert np.array_equal(ab_gpu, ab_ref) and np.array_equal(hb_gpu, hb_ref)
+    assert ab_ref[:, 33:].any() and not ab_ref[:, cn_max].any()
+    # the class retries with a larger cn_max instead of failing
+    from amof_amd.bad import BadByCn
+    from amof_amd.frames import Frame
+    frames = [Frame(packed.numbers, packed.pos[k], packed.cell_of(k)) for k in range(2)]
+    by = BadByCn.from_trajectory(frames, {'H-O': 2.9}, dtheta=1.0)
+    assert max(by.bad["O-H-O"]) > 16              # ~47 O within 2.9 A of an H in this gas
+
+
+def test_more_angle_bins_than_lds_holds(hip_ctx):
+    """dtheta = 0.005 degrees -> 36 000 bins (the LDS histogram holds 20 480): counted with global atomics"""
+    packed = H.random_walk(H.zif4_frame(), 3, 0.05, 12)
+    kinds, sp = H.species_of(packed.numbers)
+    rcm = np.zeros((4, 4))
+    rcm[kinds.index(30), kinds.index(7)] = rcm[kinds.index(7), kinds.index(30)] = 2.5
+    bins = int(180 // 0.005)
+    edges = np.arange(bins + 2) * 0.005
+    triples = [(kinds.index(30), kinds.index(7)), (kinds.index(7), kinds.index(30))]
+    h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, 4, rcm, triples, edges)
+    h_gpu, a_gpu = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert len(edges) - 1 > 20480 and hip_ctx.last_path() == "bad_fast"
+    assert np.array_equal(a_gpu, a_ref) and np.array_equal(h_gpu, h_ref)
 
 
 def test_many_bins_uses_global_histogram_path(hip_ctx):
