@@ -24,7 +24,7 @@ AMOF_ENOMEM = -4
 AMOF_EHIP = -5
 AMOF_ECAPACITY = -6
 AMOF_ENODEVICE = -7
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = [
     "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_destroy", "amof_last_error",
@@ -110,8 +110,8 @@ def load_library():
                                         ctypes.c_int64, ctypes.c_int64, P]
         lib.amof_msd_direct.argtypes = [P, TP, P]
         lib.amof_xyz_scan.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
-        lib.amof_xyz_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, P, P, P,
-                                      ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]
+        lib.amof_xyz_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                      P, P, P, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]
         lib.amof_cp2k_cell_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, P, ctypes.POINTER(ctypes.c_int64)]
         lib.amof_ingest_last_error.restype = ctypes.c_char_p
         if lib.amof_abi_version() != ABI_VERSION:

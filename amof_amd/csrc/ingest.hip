@@ -211,10 +211,10 @@ extern "C" int amof_xyz_scan(const char *path, int64_t *n_frames, int64_t *n_ato
     return AMOF_OK;
 }
 
-extern "C" int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, double *pos,
-                             char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads)
+extern "C" int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, int64_t n_atoms,
+                             double *pos, char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads)
 {
-    if (!path || !pos || count < 0 || step == 0) return ingest_fail(AMOF_EINVAL, "bad argument");
+    if (!path || !pos || count < 0 || step == 0 || n_atoms < 0) return ingest_fail(AMOF_EINVAL, "bad argument");
     Mapped m;
     int rc = m.open_file(path);
     if (rc) return rc;
@@ -222,6 +222,11 @@ extern "C" int amof_xyz_read(const char *path, int64_t first, int64_t count, int
     rc = index_frames(m, ix);
     if (rc) return rc;
     const int64_t F = (int64_t)ix.off.size(), N = ix.n_atoms;
+    // the caller sized pos / symbols for n_atoms per frame (amof_xyz_scan): a file rewritten in between must not
+    // make this call write past those buffers
+    if (F > 0 && N != n_atoms)
+        return ingest_fail(AMOF_EINVAL, "file has " + std::to_string(N) + " atoms per frame, caller expects " +
+                                            std::to_string(n_atoms) + " (file changed since amof_xyz_scan?)");
     for (int64_t k = 0; k < count; k++) {
         int64_t f = first + k * step;
         if (f < 0 || f >= F) return ingest_fail(AMOF_EINVAL, "frame " + std::to_string(f) + " out of range (file has " + std::to_string(F) + ")");

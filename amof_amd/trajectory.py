@@ -73,7 +73,7 @@ def read_xyz(path, index=None, n_threads=0):
     lattice = np.zeros((count, 9), dtype=np.float64)
     has = ctypes.c_int32(0)
     if count:
-        rc = lib.amof_xyz_read(bpath, first, count, step, ctypes.c_void_p(pos.ctypes.data),
+        rc = lib.amof_xyz_read(bpath, first, count, step, N, ctypes.c_void_p(pos.ctypes.data),
                                ctypes.c_void_p(symbols.ctypes.data), ctypes.c_void_p(lattice.ctypes.data),
                                ctypes.byref(has), int(n_threads))
         if rc:
@@ -139,11 +139,6 @@ class Trajectory(object):
             cell, pbc = np.zeros((1, 3, 3)), (False, False, False)
         out.traj = PackedTrajectory(pos, cell, numbers, pbc=pbc)
         return out
-
-    @classmethod
-    def from_lammps_data(cls, filename, atom_style):
-        raise NotImplementedError("LAMMPS data files are outside the accelerated path; read them with ASE and "
-                                  "hand the Atoms list to the analysis classes")
 
     @staticmethod
     def get_index_closest(myList, myNumber):
@@ -251,40 +246,40 @@ def write_xyz(path, packed, comment_lattice=True, fmt="%.10f"):
                 fh.write(("%s " + fmt + " " + fmt + " " + fmt + "\n") % (s, p[0], p[1], p[2]))
 
 
-def construct_step(**kwargs):
-    """Construct the ``Step`` column from various constructors.
+def _steps_from_slice(step):
+    return np.array(list(range(step.start or 0, step.stop, step.step or 1)))
 
-    Args:
-        delta_Step: int, number of simulation steps between two frames
-        first_frame: int, first step
-        last_frame: int, last step
-        number_of_frames: int
-        step: slice object or array
-    Return:
-        numpy array of steps (None when the arguments do not determine one,
-        like the reference)
+
+def construct_step(step=None, delta_Step=None, first_frame=None, last_frame=None, number_of_frames=None, **_ignored):
+    """The ``Step`` column of per-frame results (behaviour of reference amof/trajectory.py:244-283, pinned by
+    tests/golden/reference_construct_step.json; unknown keywords are ignored there too).
+
+    Rules, first match wins:
+      1. ``step`` given: a slice is expanded with range(), anything else becomes an array as is;
+      2. ``delta_Step`` with both ends: arange(first_frame, last_frame, delta_Step);
+         with ``number_of_frames`` and one end: that many steps of delta_Step (counted back from
+         ``last_frame`` when only the end is known);
+      3. no spacing but both ends and ``number_of_frames``: linspace.
+    Anything else yields None, as in the reference; an arithmetic failure is logged and raised as ValueError.
     """
-    delta_Step = kwargs.get('delta_Step', None)
-    first_frame = kwargs.get('first_frame', None)
-    last_frame = kwargs.get('last_frame', None)
-    number_of_frames = kwargs.get('number_of_frames', None)
-    step = kwargs.get('step', None)
+    have_first, have_last = first_frame is not None, last_frame is not None
     try:
         if step is not None:
-            if isinstance(step, slice):
-                return np.array(list(range(step.start or 0, step.stop, step.step or 1)))
-            return np.array(step)
-        elif delta_Step is not None:
-            if first_frame is not None and last_frame is not None:
+            return _steps_from_slice(step) if isinstance(step, slice) else np.array(step)
+        if delta_Step is not None:
+            if have_first and have_last:
                 return np.arange(first_frame, last_frame, delta_Step)
-            elif number_of_frames is not None:
-                if first_frame is None and last_frame is not None:
-                    first_frame = last_frame - number_of_frames * delta_Step
-                if first_frame is not None:
-                    return np.arange(first_frame, first_frame + number_of_frames * delta_Step, delta_Step)
-        elif number_of_frames is not None:
-            if first_frame is not None and last_frame is not None:
-                return np.linspace(first_frame, last_frame, number_of_frames)
+            if number_of_frames is None:
+                return None
+            span = number_of_frames * delta_Step
+            if have_last:                              # (only the end is known here)
+                first_frame = last_frame - span
+            elif not have_first:
+                return None
+            return np.arange(first_frame, first_frame + span, delta_Step)
+        if number_of_frames is not None and have_first and have_last:
+            return np.linspace(first_frame, last_frame, number_of_frames)
+        return None
     except Exception:
         logger.exception("Cannot construct step from provided args")
         raise ValueError

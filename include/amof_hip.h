@@ -40,7 +40,7 @@ extern "C" {
 #define AMOF_ECAPACITY (-6)  /* a documented kernel capacity was exceeded */
 #define AMOF_ENODEVICE (-7)  /* no usable GPU */
 
-#define AMOF_ABI_VERSION 1
+#define AMOF_ABI_VERSION 2
 
 /* capacities */
 #define AMOF_MAX_LDS_BINS 36864     /* histogram bins held in LDS per workgroup (u32); more bins: global-memory kernels */
@@ -198,7 +198,8 @@ int amof_msd_direct(amof_ctx *ctx, const amof_traj *traj, double *msd /* host [F
  * Trajectory.from_traj / read_lammps_traj / read_cp2k_traj (amof/trajectory.py:37-60,193-228)
  * and np.genfromtxt on the CP2K cell log (amof/trajectory.py:217).
  *   amof_xyz_scan: number of frames and atoms per frame (all frames must agree).
- *   amof_xyz_read: frames first, first+step, ... (count of them) into pos[count][N][3];
+ *   amof_xyz_read: frames first, first+step, ... (count of them) into pos[count][N][3], N = n_atoms as
+ *       amof_xyz_scan reported it (AMOF_EINVAL if the file no longer agrees: nothing is written then);
  *       symbols[N][4] (NUL padded) from the first frame read; lattice[count][9] (may be NULL)
  *       receives extended-XYZ Lattice="..." when every frame carries one (*has_lattice = 1).
  *       n_threads <= 0: all hardware threads.  Numbers are parsed correctly rounded.
@@ -207,7 +208,7 @@ int amof_msd_direct(amof_ctx *ctx, const amof_traj *traj, double *msd /* host [F
  * Errors: negative code, message via amof_ingest_last_error() (thread local).
  */
 int amof_xyz_scan(const char *path, int64_t *n_frames, int64_t *n_atoms);
-int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, double *pos,
+int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, int64_t n_atoms, double *pos,
                   char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads);
 int amof_cp2k_cell_read(const char *path, int64_t max_rows, double *cell, int64_t *n_rows);
 const char *amof_ingest_last_error(void);

@@ -39,7 +39,7 @@ int main(int argc, char **argv)
         std::vector<char> sym((size_t)N * 4 + 1);
         int32_t has = 0;
         for (int threads = 1; threads <= 3; threads += 2) {
-            rc = amof_xyz_read(path, 0, F, 1, pos.data(), sym.data(), lat.data(), &has, threads);
+            rc = amof_xyz_read(path, 0, F, 1, N, pos.data(), sym.data(), lat.data(), &has, threads);
             double s = 0;
             if (rc == 0)
                 for (size_t k = 0; k < (size_t)F * N * 3; k++) s += pos[k];
@@ -47,7 +47,7 @@ int main(int argc, char **argv)
                    (long long)N, (int)has, s, rc ? amof_ingest_last_error() : "");
         }
         if (F > 1) {   // strided subset
-            rc = amof_xyz_read(path, F - 1, (F + 1) / 2, -2, pos.data(), sym.data(), nullptr, &has, 2);
+            rc = amof_xyz_read(path, F - 1, (F + 1) / 2, -2, N, pos.data(), sym.data(), nullptr, &has, 2);
             printf("%s read(reverse stride) rc=%d %s\n", path, rc, rc ? amof_ingest_last_error() : "");
         }
     }

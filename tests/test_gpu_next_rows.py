@@ -1,0 +1,88 @@
+"""SURVEY 8f rows on the GPU: the RDF-integration coordination number (f3) against the oracle through the SAME host
+post-processing, and the file -> resident trajectory -> analysis chain of the native ingest (f1)."""
+
+import os
+
+import numpy as np
+import pytest
+
+from amof_amd import data as eldata
+from amof_amd import trajectory as T
+from amof_amd.cn import CoordinationNumber
+from amof_amd.rdf import CoordinationNumber as RdfCn
+from amof_amd.rdf import Rdf, get_coordination_number, normalize_rdf
+from oracle import clib
+from tests import helpers as H
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rdf_integration_cn_equals_oracle_histograms_through_the_same_host_code(zif4):
+    """rdf.CoordinationNumber (reference amof/rdf.py:135-227): per frame, the partial RDF at dr = 1e-4 is integrated
+    with Simpson's rule.  The only device work is the per-frame histogram: fed through the same normalize_rdf +
+    simps, the oracle's histogram must give the same numbers to rounding (they are bit-identical integers)."""
+    packed = H.random_walk(zif4, 4, 0.03, 31, cell_jitter=0.003)
+    sets = {'Zn-N': 2.5, 'C-H': 1.3, 'N-C': 1.7}
+    dr = 1e-4
+    got = RdfCn.from_trajectory(packed, sets, delta_Step=3, first_frame=10, dr=dr)
+    assert list(got.data.columns) == ["Step"] + list(sets) and list(got.data["Step"]) == [10, 13, 16, 19]
+    rmax = float(max(sets.values()))
+    bins = int(rmax // dr)
+    r = np.arange(bins) * dr
+    kinds, sp = H.species_of(packed.numbers)
+    natoms = packed.n_atoms
+    for k in range(packed.n_frames):
+        h, vol = clib.rdf_hist(packed.pos[k:k + 1], packed.cell[k:k + 1], sp, len(kinds), rmax, bins)
+        for name, cutoff in sets.items():
+            za, zb = (eldata.atomic_numbers[s] for s in name.split('-'))
+            n_a = int((packed.numbers == za).sum())
+            g = normalize_rdf(h[kinds.index(za), kinds.index(zb)], n_a, natoms, vol, rmax, bins)
+            want = get_coordination_number(r, g, cutoff, natoms / vol)
+            np.testing.assert_allclose(got.data[name].values[k], want, rtol=1e-12, atol=0)
+    # and the integral is what it claims to be: the counting CN, up to the integration error the reference warns of
+    cn = CoordinationNumber.from_trajectory(packed, {'Zn-N': 2.5})
+    np.testing.assert_allclose(got.data['Zn-N'].values, cn.data['Zn-N'].values, rtol=0.02)
+
+
+def test_files_to_resident_trajectory_to_analyses(tmp_path, hip_ctx):
+    """f1: an XYZ + CP2K .cell pair is read by the native reader (read_cp2k_traj), made resident (to_device) and
+    analysed; results equal the oracle on the arrays the files were written from."""
+    cellfile = os.path.join(GOLDEN, "toy_trajectory_200.cell")       # 200 rows of the reference's example log
+    cells = np.genfromtxt(cellfile)[:, 2:-1].reshape(-1, 3, 3)[:9]
+    # the fixture's atoms at the same fractional coordinates in the logged (slightly different, changing) cells
+    z = H.zif4_frame()
+    frac = np.linalg.solve(z.cell.T, z.positions.T).T
+    rng = np.random.default_rng(77)
+    pos = np.empty((9, 272, 3))
+    for k in range(9):
+        frac = frac + rng.normal(scale=0.002, size=frac.shape)
+        pos[k] = (frac - np.floor(frac)) @ cells[k]
+    from amof_amd.frames import PackedTrajectory
+    src = PackedTrajectory(pos, cells, z.numbers)
+    xyz = str(tmp_path / "traj-pos-1.xyz")
+    T.write_xyz(xyz, src, comment_lattice=False, fmt="%.17g")       # %.17g: the text round-trips every double
+    host = T.read_cp2k_traj(xyz, cellfile, slice(0, 9))
+    assert np.array_equal(host.pos, pos) and np.array_equal(host.cell, cells) and host.pbc.all()
+    dev = host.to_device(0)
+    assert dev.on_device
+    kinds, sp = H.species_of(z.numbers)
+    rdf = Rdf.from_trajectory(dev, dr=0.02)
+    assert hip_ctx.last_path().startswith("rdf_")
+    h_ref, vol_ref = clib.rdf_hist(pos, cells, sp, len(kinds), rdf.rmax, len(rdf.data))
+    assert np.array_equal(rdf.hist, h_ref)
+    n_zn = int((z.numbers == 30).sum())
+    want = normalize_rdf(h_ref[kinds.index(30), kinds.index(7)], 9 * n_zn, 272, vol_ref / 9, rdf.rmax, len(rdf.data))
+    np.testing.assert_allclose(rdf.data["Zn-N"].values, want, rtol=1e-14, atol=0)
+    cn = CoordinationNumber.from_trajectory(dev, {'Zn-N': 2.5, 'C-N': 1.6})
+    rcm = np.zeros((4, 4))
+    for a, b, c in ((30, 7, 2.5), (6, 7, 1.6)):
+        rcm[kinds.index(a), kinds.index(b)] = rcm[kinds.index(b), kinds.index(a)] = c
+    sums = clib.cn_counts(pos, cells, sp, 4, rcm, [(kinds.index(30), kinds.index(7)), (kinds.index(6), kinds.index(7))])
+    assert np.array_equal(cn.data['Zn-N'].values, sums[:, 0] / n_zn)
+    assert np.array_equal(cn.data['C-N'].values, sums[:, 1] / int((z.numbers == 6).sum()))
+    # the Trajectory mirror takes the same route
+    tr = T.Trajectory.from_traj(xyz, ":", format="xyz")
+    tr.set_cell(cells)
+    again = Rdf.from_trajectory(tr.get_traj().to_device(0), dr=0.02)
+    assert np.array_equal(again.hist, rdf.hist)

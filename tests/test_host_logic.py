@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.amof_abi_version() == 1
+    assert lib.amof_abi_version() == 2
 
 
 def test_struct_layout_matches_header():
@@ -169,3 +169,28 @@ def test_traj_handle_of_a_host_trajectory_needs_no_gpu():
     assert th.c.n_frames == 2 and th.c.n_atoms == 272 and th.c.pos_on_device == 0 and th.S == 4
     assert th.kinds == [1, 6, 7, 30]
     assert packed._abi_species[1] is th.species          # cached on the trajectory
+
+
+def test_simps_is_scipy_171_simps_even_avg():
+    """rdf.simps restates scipy 1.7.1's simps(y, x) (default even='avg'), which the reference pins
+    (requirements.txt:15) and calls at amof/rdf.py:226.  Pins: for an odd number of samples it is the composite
+    Simpson rule -- equal to the installed scipy.integrate.simpson; for an even number it is the average of
+    (Simpson on the first N-1 samples + trapezoid on the last interval) and (trapezoid on the first interval +
+    Simpson on the last N-1 samples), each built here from the odd-count rule."""
+    from scipy.integrate import simpson
+    from amof_amd.rdf import simps
+    rng = np.random.default_rng(5)
+    for n in (3, 5, 101, 2499):                 # odd counts, non-uniform abscissae
+        x = np.cumsum(rng.uniform(0.5, 1.5, n)) * 1e-3
+        y = np.sin(40 * x) + x ** 2 + rng.normal(scale=0.01, size=n)
+        np.testing.assert_allclose(simps(y, x), simpson(y, x=x), rtol=1e-13, atol=1e-16)
+    for n in (4, 6, 100, 2500):                 # even counts: scipy 1.7.1's even='avg'
+        x = np.cumsum(rng.uniform(0.5, 1.5, n)) * 1e-3
+        y = np.cos(25 * x) + rng.normal(scale=0.01, size=n)
+        first = simpson(y[:-1], x=x[:-1]) + 0.5 * (x[-1] - x[-2]) * (y[-1] + y[-2])
+        last = 0.5 * (x[1] - x[0]) * (y[1] + y[0]) + simpson(y[1:], x=x[1:])
+        np.testing.assert_allclose(simps(y, x), 0.5 * (first + last), rtol=1e-13, atol=1e-16)
+    assert simps([1.0], [0.0]) == 0.0
+    # exact for cubics on an odd number of uniform samples
+    x = np.linspace(0, 2, 41)
+    np.testing.assert_allclose(simps(x ** 3 - x, x), 2.0, rtol=1e-14)

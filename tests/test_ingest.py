@@ -128,3 +128,26 @@ def test_errors(tmp_path):
     nolat.write_text("1\ncomment\nH 0 0 0\n")
     with pytest.raises(ValueError, match="Lattice"):
         T.read_lammps_traj(str(nolat), ":")
+
+
+def test_xyz_read_refuses_a_file_that_changed_since_the_scan(tmp_path):
+    """amof_xyz_read is told how many atoms per frame the buffers were sized for (amof_xyz_scan's answer): a file
+    rewritten in between must give an error, not a write past the buffers."""
+    import ctypes
+    from amof_amd import _hip
+    lib = _hip.load_library()
+    packed = H.random_walk(H.zif4_frame(), 3, 0.1, 6)
+    path = str(tmp_path / "live.xyz")
+    T.write_xyz(path, packed)
+    F, N = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert lib.amof_xyz_scan(path.encode(), ctypes.byref(F), ctypes.byref(N)) == 0 and (F.value, N.value) == (3, 272)
+    # the dump is replaced by one with more atoms per frame before the read
+    bigger = H.random_walk(H.replicate(H.zif4_frame(), (2, 1, 1)), 3, 0.1, 6)
+    T.write_xyz(path, bigger)
+    pos = np.full((3, 272, 3), -7.0)
+    sym = np.zeros((272, 4), dtype=np.uint8)
+    has = ctypes.c_int32(0)
+    rc = lib.amof_xyz_read(path.encode(), 0, 3, 1, 272, ctypes.c_void_p(pos.ctypes.data), ctypes.c_void_p(sym.ctypes.data),
+                           None, ctypes.byref(has), 2)
+    assert rc == _hip.AMOF_EINVAL and b"atoms per frame" in lib.amof_ingest_last_error()
+    assert (pos == -7.0).all()                                   # nothing was written
