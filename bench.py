@@ -383,21 +383,29 @@ def main():
                 traffic = json.load(fh).get("cfg3", {})
         # the bound that applies to the all-pairs kernel is VALU issue: cycles a SIMD spends per
         # wave-level pair (64 pairs), measured live; beside it the same quantity predicted from the kernel's own
-        # disassembly weighted with the per-instruction issue costs measured on the box (profiles/tools/valu_model.py,
-        # regenerated by build()), and the share of the pairs the slab culling leaves (geometry, computed here)
+        # executed instruction counts (SQ counters) weighted with the per-instruction issue costs measured on the box,
+        # and the share of the pairs the slab culling leaves (geometry, computed here)
         lz = float(np.max(packed.cell_lengths()))
         visited = min(1.0, (2.0 * rmax) / lz + 3.0 / 256.0) if 2.0 * rmax * 1.05 < lz else 1.0
         valu = {"simd_cycles_per_wave_pair_all_pairs": t_rdf * N_SIMD * CLOCK_HZ / (pairs / 64.0),
                 "visited_fraction_geometric": visited,
                 "simd_cycles_per_visited_wave_pair": t_rdf * N_SIMD * CLOCK_HZ / (pairs / 64.0) / visited}
         mfile = os.path.join(ROOT, "profiles", "valu_model.json")
-        if os.path.exists(mfile):
+        if os.path.exists(mfile) and (N, F, world) == (9792, 5000, 1):
+            # instruction counts of this very launch shape from the SQ counters (profiles/tools/collect_pmc.sh ->
+            # pmc_to_json.py), priced with the issue costs measured on the box, against the LIVE kernel time
             with open(mfile) as fh:
-                model = json.load(fh)
-            valu["model"] = model.get("rdf_tile_kernel_fast")
-            if valu["model"] and valu["model"].get("issue_cycles_per_visited_wave_pair"):
-                valu["issue_slot_utilisation"] = (valu["model"]["issue_cycles_per_visited_wave_pair"] /
-                                                  valu["simd_cycles_per_visited_wave_pair"])
+                model = json.load(fh).get("rdf_tile_kernel_fast")
+            if model:
+                lo, hi = model["valu_issue_cycles_per_simd"]
+                live_cycles = t_rdf * CLOCK_HZ
+                valu["pmc"] = {"valu_instructions_per_launch": model["valu_instructions_per_launch"],
+                               "valu_instructions_per_visited_wave_pair":
+                                   model["valu_instructions_per_launch"] / (pairs / 64.0 * visited),
+                               "by_class": model["by_class"], "other_valu": model["other_valu"],
+                               "lane_utilisation": model["lane_utilisation"],
+                               "issue_slot_utilisation_in_pmc_run": model["issue_slot_utilisation"]}
+                valu["issue_slot_utilisation"] = [lo / live_cycles, hi / live_cycles]
         msd_bytes = alg_bytes if world == 1 else F * (24 * N + 72)      # every rank reads all frames for the COM
         out = {
             "metric": "frames/s (RDF+MSD, 10k-atom ZIF-4)",

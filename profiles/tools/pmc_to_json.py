@@ -1,0 +1,130 @@
+"""Condense the raw rocprofv3 --pmc CSVs of profiles/tools/collect_pmc.sh into the JSON files bench.py reads.
+
+    python profiles/tools/pmc_to_json.py gpurun_out/r02/pmc profiles/r02
+
+Writes, next to a per-kernel table of every counter (``pmc_<workload>.json``, mean per launch):
+
+* ``profiles/traffic.json`` -- HBM-side bytes per launch of the headline kernels.  gfx950 corrections as prescribed by
+  MI355X_MICROARCH.md (HBM section): FETCH_SIZE is reported in KB and tallies 128-B requests at 64 B -> x 1024 x 2;
+  WRITE_SIZE (KB) is taken as is -> x 1024.  Infinity-Cache hits are included in both.
+* ``profiles/valu_model.json`` -- for the all-pairs RDF tile kernel: VALU instructions per launch by class, the issue
+  cycles they need at the per-instruction costs measured on this box (profiles/r01/ubench_valu_issue.txt), and the
+  share of the kernel's SIMD cycles that is (issue-slot utilisation).  Instructions outside the counted classes
+  (moves, selects, compares, fract, shifts) are priced twice: at the full rate and at the compare rate -- a low and a
+  high figure.  Kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+N_SIMD = 1024
+N_XCC = 8           # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs: cycles of the launch = value / 8
+src, dst = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def short(name):
+    name = name.replace("void amof::", "").replace("amof::", "")
+    return re.sub(r"\(.*$", "", name).strip()
+
+
+def load(workload):
+    acc = defaultdict(lambda: defaultdict(list))
+    for path in glob.glob(os.path.join(src, workload + "_g*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                name = row.get("Kernel_Name", "")
+                if "amof" not in name:
+                    continue
+                acc[short(name)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    # the first launch of a run includes cold caches; every run does RUN_ONCE_REPS identical calls: keep the mean
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"launches_seen": max(len(v) for v in cs.values())}
+            for k, cs in acc.items()}
+
+
+# issue cycles per wave instruction, measured (profiles/r01/ubench_valu_issue.txt, cycles @ 2.4 GHz)
+UB = {}
+with open(os.path.join(root, "profiles", "r01", "ubench_valu_issue.txt")) as fh:
+    for line in fh:
+        m = re.match(r"(\w+)\s+.*=\s*([\d.]+) cycles", line)
+        if m:
+            UB[m.group(1)] = float(m.group(2))
+
+os.makedirs(dst, exist_ok=True)
+tables = {}
+for wl in ("rdf", "msd", "bad", "cn", "cfg4"):
+    t = load(wl)
+    if t:
+        tables[wl] = t
+        with open(os.path.join(dst, "pmc_%s.json" % wl), "w") as fh:
+            json.dump(t, fh, indent=1, sort_keys=True)
+
+
+def traffic(table, pick):
+    tot = 0.0
+    for k, c in table.items():
+        if pick(k) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            tot += c["FETCH_SIZE"] * 1024.0 * 2.0 + c["WRITE_SIZE"] * 1024.0
+    return tot or None
+
+
+out = {"_comment": "HBM-side bytes per launch on the headline workload (9792 atoms x 5000 frames), derived by "
+                   "profiles/tools/pmc_to_json.py from the separate FETCH_SIZE / WRITE_SIZE passes of "
+                   "profiles/tools/collect_pmc.sh (raw per-kernel means: profiles/r02/pmc_*.json). gfx950 correction per "
+                   "MI355X_MICROARCH.md: FETCH_SIZE (KB) tallies 128-B requests at 64 B -> doubled; WRITE_SIZE (KB) as "
+                   "is. Infinity-Cache hits are included.", "cfg3": {}}
+if "rdf" in tables:
+    out["cfg3"]["rdf_tile_kernel_fast"] = traffic(tables["rdf"], lambda k: k.startswith("rdf_tile_kernel_fast"))
+    out["cfg3"]["quantize_kernel"] = traffic(tables["rdf"], lambda k: k.startswith("quantize"))
+if "msd" in tables:
+    out["cfg3"]["msd_pipeline"] = traffic(tables["msd"], lambda k: True)
+    out["cfg3"]["msd_kernels"] = {k: traffic(tables["msd"], lambda q, k=k: q == k) for k in tables["msd"]}
+if "bad" in tables:
+    out["cfg3"]["bad_pipeline"] = traffic(tables["bad"], lambda k: True)
+if "cn" in tables:
+    out["cfg3"]["cn_pipeline"] = traffic(tables["cn"], lambda k: True)
+if "cfg4" in tables:
+    out["cfg4_64_frames"] = {k: traffic(tables["cfg4"], lambda q, k=k: q == k) for k in tables["cfg4"]}
+with open(os.path.join(root, "profiles", "traffic.json"), "w") as fh:
+    json.dump(out, fh, indent=1)
+
+model = {}
+for wl, prefix in (("rdf", "rdf_tile_kernel_fast"), ("cfg4", "rdf_cell_kernel")):
+    if wl not in tables:
+        continue
+    for k, c in tables[wl].items():
+        if not k.startswith(prefix) or "SQ_INSTS_VALU" not in c:
+            continue
+        cls = {"cvt": c.get("SQ_INSTS_VALU_CVT", 0.0), "trans_f32": c.get("SQ_INSTS_VALU_TRANS_F32", 0.0),
+               "add_f32": c.get("SQ_INSTS_VALU_ADD_F32", 0.0), "mul_f32": c.get("SQ_INSTS_VALU_MUL_F32", 0.0),
+               "fma_f32": c.get("SQ_INSTS_VALU_FMA_F32", 0.0), "int32": c.get("SQ_INSTS_VALU_INT32", 0.0),
+               "f64": c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
+                      c.get("SQ_INSTS_VALU_FMA_F64", 0.0)}
+        other = c["SQ_INSTS_VALU"] - sum(cls.values())
+        cost = {"cvt": UB["k_cvt_f32_i32"], "trans_f32": UB["k_sqrt32"], "add_f32": UB["k_add32"],
+                "mul_f32": UB["k_mul32"], "fma_f32": UB["k_fma32"], "int32": UB["k_subu32"], "f64": UB["k_add64"]}
+        known = sum(cls[x] * cost[x] for x in cls)
+        issue_lo = known + max(other, 0.0) * UB["k_mul32"]       # the remainder at the full rate ...
+        issue_hi = known + max(other, 0.0) * UB["k_cmp32"]       # ... or all of it at the compare / fract rate
+        gui = c.get("GRBM_GUI_ACTIVE")
+        cyc = gui / N_XCC if gui else None
+        model[prefix] = {
+            "kernel": k, "valu_instructions_per_launch": c["SQ_INSTS_VALU"], "by_class": cls, "other_valu": other,
+            "cycles_per_instruction_used": dict(cost, other_low=UB["k_mul32"], other_high=UB["k_cmp32"]),
+            "valu_issue_cycles_per_simd": [issue_lo / N_SIMD, issue_hi / N_SIMD],
+            "kernel_cycles": cyc,
+            "issue_slot_utilisation": [issue_lo / N_SIMD / cyc, issue_hi / N_SIMD / cyc] if cyc else None,
+            "lane_utilisation": (c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0))
+                                if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU") else None,
+            "wave_cycle_split": {x: c.get(x) for x in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                                       "SQ_ACTIVE_INST_ANY")},
+            "lds_instructions": c.get("SQ_INSTS_LDS"), "lds_atomics": c.get("SQ_INSTS_LDS_ATOMIC"),
+            "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"), "lds_active_cycles": c.get("SQ_LDS_IDX_ACTIVE"),
+        }
+with open(os.path.join(root, "profiles", "valu_model.json"), "w") as fh:
+    json.dump(model, fh, indent=1)
+print("wrote", sorted(tables), "->", dst, "; traffic.json, valu_model.json")
