@@ -4,7 +4,7 @@
 
     python examples/compute_structural_properties.py [out_dir]
 
-Only the imports differ from the reference script; ASE is replaced by the in-repo extended-XYZ
+Only the imports differ from the reference script; ASE is replaced by the native extended-XYZ
 reader because it is not installed here (a list of ase.Atoms works just as well).
 """
 
@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from amof_amd.io import read_extxyz                      # noqa: E402
+from amof_amd.trajectory import read_lammps_traj         # noqa: E402
 from amof_amd.rdf import Rdf                             # noqa: E402
 from amof_amd.bad import Bad                             # noqa: E402
 from amof_amd.cn import CoordinationNumber               # noqa: E402
@@ -25,7 +25,8 @@ from amof_amd.msd import WindowMsd                       # noqa: E402
 
 def main(out_dir):
     os.makedirs(out_dir, exist_ok=True)
-    traj = read_extxyz(os.path.join(ROOT, "tests", "golden", "ZIF-4.xyz"))      # one frame, like the reference example
+    # one frame, like the reference example (native extended-XYZ reader; the Lattice= comment carries the cell)
+    traj = read_lammps_traj(os.path.join(ROOT, "tests", "golden", "ZIF-4.xyz"), ":")
 
     rdf = Rdf.from_trajectory(traj)                                              # reference :58
     print(rdf.data[["r", "X-X", "Zn-N"]].iloc[195:206].to_string())
@@ -40,7 +41,8 @@ def main(out_dir):
     print(cn.data.to_string())
 
     rng = np.random.default_rng(0)                                               # reference :110-118: 11 rattled frames
-    mock = [traj[0].copy() for _ in range(11)]
+    base = traj.frame(0)                                                         # an ase.Atoms-like Frame
+    mock = [base.copy() for _ in range(11)]
     for k in range(1, 11):
         mock[k].positions = mock[k - 1].positions + rng.normal(scale=0.5, size=mock[k].positions.shape)
     msd = WindowMsd.from_trajectory(mock, delta_time=1, timestep=1)

@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def zif4():
-    from amof_amd.io import read_extxyz
+    from tests.helpers import read_extxyz
     return read_extxyz(os.path.join(GOLDEN, "ZIF-4.xyz"), 0)
 
 

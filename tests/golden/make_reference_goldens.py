@@ -43,7 +43,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 from amof_amd import data as eldata                      # element tables (public facts)
 from amof_amd.frames import Frame                        # Atoms look-alike
-from amof_amd.io import read_extxyz
+from tests.helpers import read_extxyz
 from oracle import numpy_oracle as no                    # restated 3P behaviour
 
 

@@ -1,13 +1,49 @@
 """Shared builders for the parity tests (seeded synthetic trajectories)."""
 
 import os
+import re
 
 import numpy as np
 
+from amof_amd import data as _data
 from amof_amd.frames import Frame, PackedTrajectory
-from amof_amd.io import read_extxyz
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# Independent, pure-Python extended-XYZ reader (float() per field) for the fixtures: the yardstick the native
+# reader (amof_amd.trajectory.read_xyz) is compared with bit for bit in tests/test_ingest.py.
+def read_extxyz(path, index=None):
+    """Return a list of :class:`Frame` (or one frame if ``index`` is an int)."""
+    frames = []
+    with open(path, "r") as fh:
+        lines = fh.read().splitlines()
+    i = 0
+    while i < len(lines):
+        if not lines[i].strip():
+            i += 1
+            continue
+        n = int(lines[i].split()[0])
+        comment = lines[i + 1]
+        m = re.search(r'Lattice="([^"]*)"', comment)
+        if m is None:
+            raise ValueError("no Lattice= in comment line of %s" % path)
+        cell = np.array([float(x) for x in m.group(1).split()]).reshape(3, 3)
+        pbc = (True, True, True)
+        mp = re.search(r'pbc="([^"]*)"', comment)
+        if mp is not None:
+            pbc = tuple(t.upper().startswith("T") for t in mp.group(1).split())
+        symbols, pos = [], []
+        for line in lines[i + 2:i + 2 + n]:
+            w = line.split()
+            symbols.append(w[0])
+            pos.append([float(w[1]), float(w[2]), float(w[3])])
+        numbers = [_data.atomic_numbers[s] for s in symbols]
+        frames.append(Frame(numbers, np.array(pos), cell, pbc))
+        i += 2 + n
+    if isinstance(index, int):
+        return frames[index]
+    return frames
 
 
 def species_of(numbers):
