@@ -126,3 +126,117 @@ def device_walk(device, reps, n_frames, sigma, seed, base=None):
         traj[f0:f1] = walk - torch.floor(walk / L) * L     # wrapped into the cell
         del steps, walk
     return PackedTrajectory(traj, cell, rep.numbers)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# A second, stricter stand-in for ase.Atoms (ASE itself is not installed here).  Unlike amof_amd.frames.Frame --
+# written by the same hand as the code that consumes it -- this one copies the SHAPES of ASE 3.20's objects: the
+# cell is a Cell object (not an ndarray: `.array`, `__array__`, `.lengths()`, `.volume`), `get_cell()` returns
+# such an object, `pbc` is a bool ndarray, `positions` / `numbers` are properties over a private arrays dict,
+# `symbols.formula._count` is a plain dict in order of first appearance.  Nothing here inherits from the product.
+class CellLike(object):
+    def __init__(self, array):
+        self.array = np.array(array, dtype=float).reshape(3, 3)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.array if dtype is None else self.array.astype(dtype)
+
+    def __getitem__(self, item):
+        return self.array[item]
+
+    def __len__(self):
+        return 3
+
+    def copy(self):
+        return CellLike(self.array.copy())
+
+    def lengths(self):
+        return np.linalg.norm(self.array, axis=1)
+
+    def cellpar(self):
+        ang = []
+        for i in range(3):
+            j, k = (i + 1) % 3, (i + 2) % 3
+            ang.append(np.degrees(np.arccos(np.dot(self.array[j], self.array[k]) /
+                                            (np.linalg.norm(self.array[j]) * np.linalg.norm(self.array[k])))))
+        return np.array(list(self.lengths()) + ang)
+
+    @property
+    def volume(self):
+        return abs(np.linalg.det(self.array))
+
+
+class _FormulaLike(object):
+    def __init__(self, symbols):
+        self._count = {}
+        for s in symbols:
+            self._count[s] = self._count.get(s, 0) + 1
+
+
+class _SymbolsLike(object):
+    def __init__(self, numbers):
+        self.numbers = numbers
+
+    def __iter__(self):
+        return (_data.chemical_symbols[int(z)] for z in self.numbers)
+
+    @property
+    def formula(self):
+        return _FormulaLike(list(self))
+
+
+class AseLikeAtoms(object):
+    def __init__(self, numbers, positions, cell, pbc=True):
+        self.arrays = {"numbers": np.array(numbers, dtype=int), "positions": np.array(positions, dtype=float)}
+        self._cellobj = CellLike(cell)
+        self._pbc = np.zeros(3, bool)
+        self._pbc[:] = pbc
+
+    cell = property(lambda self: self._cellobj)
+    pbc = property(lambda self: self._pbc)
+    numbers = property(lambda self: self.arrays["numbers"])
+    positions = property(lambda self: self.arrays["positions"],
+                         lambda self, v: self.arrays["positions"].__setitem__(slice(None), v))
+    symbols = property(lambda self: _SymbolsLike(self.arrays["numbers"]))
+
+    def __len__(self):
+        return len(self.arrays["positions"])
+
+    def copy(self):
+        return AseLikeAtoms(self.numbers.copy(), self.positions.copy(), self.cell.array.copy(), self.pbc.copy())
+
+    def get_positions(self):
+        return self.arrays["positions"].copy()
+
+    def set_positions(self, newpositions):
+        self.arrays["positions"][:] = newpositions
+
+    def get_atomic_numbers(self):
+        return self.arrays["numbers"].copy()
+
+    def get_cell(self, complete=False):
+        return self._cellobj.copy()
+
+    def get_pbc(self):
+        return self._pbc.copy()
+
+    def get_cell_lengths_and_angles(self):
+        return self._cellobj.cellpar()
+
+    def get_volume(self):
+        return self._cellobj.volume
+
+    def get_masses(self):
+        return np.array([_data.atomic_masses[int(z)] for z in self.numbers])
+
+    def get_center_of_mass(self):
+        m = self.get_masses()
+        return np.dot(m, self.positions) / m.sum()
+
+    def translate(self, displacement):
+        self.arrays["positions"] += np.array(displacement)
+
+
+def as_ase_like(packed):
+    """the frames of a host PackedTrajectory as AseLikeAtoms objects"""
+    return [AseLikeAtoms(packed.numbers, packed.pos[k], packed.cell_of(k), packed.pbc) for k in range(packed.n_frames)]

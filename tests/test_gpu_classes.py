@@ -186,3 +186,25 @@ def test_several_contexts_from_one_process(resident):
     b1 = BadByCn.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=1.0, device=0, distributed=False)
     b2 = BadByCn.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=1.0, device=[0, 0], distributed=False)
     assert np.array_equal(b1.hist, b2.hist)
+
+
+def test_classes_take_ase_shaped_atoms_lists(zif4):
+    """the reference's calling convention -- a Python list of ase.Atoms -- with objects shaped like ASE's own
+    (tests.helpers.AseLikeAtoms: Cell object, property-backed arrays, symbols.formula._count); results equal the
+    packed-trajectory route, and the inputs are left untouched (the reference mutates them, amof/msd.py:230,237)"""
+    from amof_amd.bad import Bad
+    from amof_amd.msd import WindowMsd
+    packed = H.random_walk(zif4, 7, 0.06, 41, cell_jitter=0.004)
+    atoms = H.as_ase_like(packed)
+    before = [a.get_positions() for a in atoms]
+    cut = {'Zn-N': 2.5}
+    pairs = [(Rdf.from_trajectory(atoms, dr=0.02), Rdf.from_trajectory(packed, dr=0.02)),
+             (Bad.from_trajectory(atoms, cut, dtheta=0.5), Bad.from_trajectory(packed, cut, dtheta=0.5)),
+             (CoordinationNumber.from_trajectory(atoms, cut), CoordinationNumber.from_trajectory(packed, cut)),
+             (WindowMsd.from_trajectory(atoms, delta_time=1, timestep=1),
+              WindowMsd.from_trajectory(packed, delta_time=1, timestep=1)),
+             (WindowMsd.from_trajectory(atoms, delta_time=1, timestep=1, unwrap=True),
+              WindowMsd.from_trajectory(packed, delta_time=1, timestep=1, unwrap=True))]
+    for a, b in pairs:
+        assert list(a.data.columns) == list(b.data.columns) and np.array_equal(a.data.values, b.data.values)
+    assert all(np.array_equal(a.get_positions(), p) for a, p in zip(atoms, before))

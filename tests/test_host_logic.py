@@ -194,3 +194,18 @@ def test_simps_is_scipy_171_simps_even_avg():
     # exact for cubics on an odd number of uniform samples
     x = np.linspace(0, 2, 41)
     np.testing.assert_allclose(simps(x ** 3 - x, x), 2.0, rtol=1e-14)
+
+
+def test_pack_trajectory_of_ase_shaped_objects():
+    """pack_trajectory sees real ASE shapes: a Cell object (not an ndarray), property-backed positions / numbers"""
+    from amof_amd.frames import pack_trajectory
+    from tests import helpers as H
+    packed = H.random_walk(H.zif4_frame(), 5, 0.05, 3, cell_jitter=0.01)
+    atoms = H.as_ase_like(packed)
+    assert not isinstance(atoms[0].cell, np.ndarray) and not isinstance(atoms[0].get_cell(), np.ndarray)
+    again = pack_trajectory(atoms)
+    assert np.array_equal(again.pos, packed.pos) and np.array_equal(again.cell, packed.cell)
+    assert np.array_equal(again.numbers, packed.numbers) and np.array_equal(again.masses, packed.masses)
+    assert again.pbc.all() and again.formula_count() == atoms[0].symbols.formula._count
+    const = pack_trajectory(H.as_ase_like(H.random_walk(H.zif4_frame(), 3, 0.05, 4)))
+    assert const.cell.shape == (1, 3, 3)                     # identical cells collapse to one record
