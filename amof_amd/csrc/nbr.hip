@@ -358,6 +358,11 @@ __device__ __forceinline__ void nbr_ranges(const uint32_t *__restrict__ st /* [Q
 }
 
 constexpr int NBRF_TILE = 256;
+constexpr int NBRF_NLIST = 16;     // neighbours per centre bad_fast_kernel keeps in LDS (more: big-list pass of the exact kernel)
+constexpr int NBRF_UVCAP = 768;    // unit vectors per centre tile and frame held in LDS for the flattened angle phase
+// (sized for three workgroups per CU at 3600 angle bins: 18 KB unit vectors -- the partner tile aliases them --
+//  + 16 KB lists + 14 KB histogram + 3.5 KB tables = 52.8 KB)
+static_assert(NBRF_NLIST <= AMOF_MAX_NEIGHBOURS, "the fast kernel's lists must not exceed the documented capacity");
 
 template <bool ORTHO>
 __global__ __launch_bounds__(NBRF_TILE) void cn_fast_kernel(NbrFastArgs fa)
@@ -439,15 +444,30 @@ __device__ __forceinline__ bool unit_vec(double x, double y, double z, double &u
     return true;
 }
 
+// One lane = one centre atom for the neighbour search (as in cn_fast_kernel); the angles are then formed by the
+// whole workgroup over FLATTENED work lists, because per-lane loops leave most lanes idle (in ZIF-4 every N has one
+// Zn neighbour and no angle, every Zn has four N and six angles) and chain dependent gathers (the old per-lane loop:
+// ~9 global round trips per frame, 8.1 ms per 5000 frames; this form: profiles/r02):
+//   2a  entries (centre c, neighbour slot u), all centres of the tile: gather the two positions once, canonical
+//       minimum-image vector, unit vector -> LDS;
+//   2b  every entry forms its angles with the later entries of the same centre from LDS -- no global loads.
+// Same arithmetic per angle as before (ase get_angles order), so the counts still equal the oracle's bit for bit.
 template <bool ORTHO>
 __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
 {
     const NbrArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    uint4 *tq = reinterpret_cast<uint4 *>(lds_raw);                       // [NBRF_TILE]
-    uint32_t *nlist = reinterpret_cast<uint32_t *>(tq + NBRF_TILE);       // [AMOF_MAX_NEIGHBOURS][NBRF_TILE]
-    unsigned *hist = nlist + AMOF_MAX_NEIGHBOURS * NBRF_TILE;             // [nb]
-    const int tid = threadIdx.x;
+    uint4 *tq = reinterpret_cast<uint4 *>(lds_raw);                       // [NBRF_TILE] (search phase only: aliases uv)
+    double *uvx = reinterpret_cast<double *>(lds_raw);                    // [NBRF_UVCAP] x 3 (angle phase only)
+    static_assert(3 * NBRF_UVCAP * sizeof(double) >= NBRF_TILE * sizeof(uint4), "partner tile must fit in the uv table");
+    double *uvy = uvx + NBRF_UVCAP, *uvz = uvy + NBRF_UVCAP;
+    uint32_t *nlist = reinterpret_cast<uint32_t *>(uvz + NBRF_UVCAP);     // [NBRF_NLIST][NBRF_TILE]
+    uint32_t *s_cidx = nlist + NBRF_NLIST * NBRF_TILE;                    // [NBRF_TILE] atom index of every centre
+    int *pref = reinterpret_cast<int *>(s_cidx + NBRF_TILE);              // [NBRF_TILE + 1] entries before centre c
+    unsigned short *ec = reinterpret_cast<unsigned short *>(pref + NBRF_TILE + 4);   // [NBRF_UVCAP] centre of entry e
+    unsigned *hist = reinterpret_cast<unsigned *>(ec + NBRF_UVCAP);       // [nb]
+    __shared__ int s_wtot[NBRF_TILE / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int4 w = a.work[blockIdx.x];          // (triple, first centre (species-relative), centre species, B)
     const int trip = w.x, c0 = w.y, sa = w.z, B = w.w;
     const int64_t segA = fa.sp_first[sa];
@@ -458,6 +478,22 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
     const bool direct = a.cn_max > 0 || a.global_hist;     // straight into global memory (no LDS histogram)
     for (int k = tid; k < nb && !a.global_hist; k += NBRF_TILE) hist[k] = 0u;
     unsigned long long nang = 0;
+    // one angle between two unit vectors -> histogram
+    auto count_angle = [&](double ax, double ay, double az, double bx, double by, double bz, int n_centre) {
+        double dot = ax * bx + ay * by + az * bz;
+        if (dot > 1.0) dot = 1.0;
+        if (dot < -1.0) dot = -1.0;
+        const double ang = (180.0 / M_PI) * acos(dot);
+        const int k = hist_bin(a.edges, nb, ang);
+        if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
+            const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n_centre, a.cn_max) : (size_t)trip;
+            atomicAdd(&a.n_angles[slot], 1ull);
+            if (k >= 0) atomicAdd(&a.hist[slot * nb + k], 1ull);
+        } else {
+            nang++;
+            if (k >= 0) atomicAdd(&hist[k], 1u);
+        }
+    };
     const int f0 = blockIdx.y * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, fa.nf);
     for (int fl = f0; fl < f1; fl++) {
@@ -502,7 +538,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
                         bool nbr = d < r_in;
                         if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, qc.idx, qj.w, rc);
                         if (nbr) {
-                            if (n < AMOF_MAX_NEIGHBOURS) nlist[n * NBRF_TILE + tid] = qj.w;
+                            if (n < NBRF_NLIST) nlist[n * NBRF_TILE + tid] = qj.w;
                             else a.flags[1] = 1;
                             n++;
                         }
@@ -510,10 +546,49 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
                 }
             }
         }
-        n = min(n, AMOF_MAX_NEIGHBOURS);
-        // every unordered pair of neighbours of this centre -> one angle, from the canonical
-        // minimum-image vectors of the original float64 positions
-        if (has && n >= 2) {
+        n = has ? min(n, NBRF_NLIST) : 0;
+        // entries before each centre: exclusive scan of n over the workgroup
+        int incl = n;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        __syncthreads();                       // the previous frame's angle phase has finished with pref / uv / ec
+        if (lane == 63) s_wtot[wave] = incl;
+        s_cidx[tid] = qc.idx;
+        __syncthreads();
+        int before = 0;
+        for (int q = 0; q < wave; q++) before += s_wtot[q];
+        pref[tid] = before + incl - n;
+        if (tid == NBRF_TILE - 1) pref[NBRF_TILE] = before + incl;
+        __syncthreads();
+        const int total = pref[NBRF_TILE];
+        if (total <= NBRF_UVCAP) {
+            // 2a: one unit vector per (centre, neighbour slot)
+            for (int e = tid; e < total; e += NBRF_TILE) {
+                int lo = 0, hi = NBRF_TILE;    // largest c with pref[c] <= e  (pref[NBRF_TILE] = total > e)
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (pref[mid] <= e) lo = mid;
+                    else hi = mid;
+                }
+                const int c = lo, u = e - pref[c];
+                const double *pn = p + (size_t)nlist[u * NBRF_TILE + c] * 3, *pc = p + (size_t)s_cidx[c] * 3;
+                double vx, vy, vz, ax = 0.0, ay = 0.0, az = 0.0;
+                pair_base<ORTHO>(geo, pn[0] - pc[0], pn[1] - pc[1], pn[2] - pc[2], vx, vy, vz);
+                if (!unit_vec(vx, vy, vz, ax, ay, az)) a.flags[0] = 1;     // (the call fails: results are discarded)
+                uvx[e] = ax; uvy[e] = ay; uvz[e] = az;
+                ec[e] = (unsigned short)c;
+            }
+            __syncthreads();
+            // 2b: entry e = (c, u) with every later entry (c, v > u) of the same centre
+            for (int e = tid; e < total; e += NBRF_TILE) {
+                const int c = ec[e], e_end = pref[c + 1], n_c = e_end - pref[c];
+                const double ax = uvx[e], ay = uvy[e], az = uvz[e];
+                for (int ev = e + 1; ev < e_end; ev++) count_angle(ax, ay, az, uvx[ev], uvy[ev], uvz[ev], n_c);
+            }
+        } else if (has && n >= 2) {
+            // more neighbours in this tile than the LDS table holds: per-centre loops straight from global memory
             const double *pc = p + (size_t)qc.idx * 3;
             const double cx = pc[0], cy = pc[1], cz = pc[2];
             for (int u = 0; u < n - 1; u++) {
@@ -526,19 +601,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
                     double wx, wy, wz, bx, by, bz;
                     pair_base<ORTHO>(geo, pv[0] - cx, pv[1] - cy, pv[2] - cz, wx, wy, wz);
                     if (!unit_vec(wx, wy, wz, bx, by, bz)) { a.flags[0] = 1; continue; }
-                    double dot = ax * bx + ay * by + az * bz;
-                    if (dot > 1.0) dot = 1.0;
-                    if (dot < -1.0) dot = -1.0;
-                    const double ang = (180.0 / M_PI) * acos(dot);
-                    const int k = hist_bin(a.edges, nb, ang);
-                    if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
-                        const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
-                        atomicAdd(&a.n_angles[slot], 1ull);
-                        if (k >= 0) atomicAdd(&a.hist[slot * nb + k], 1ull);
-                    } else {
-                        nang++;
-                        if (k >= 0) atomicAdd(&hist[k], 1u);
-                    }
+                    count_angle(ax, ay, az, bx, by, bz, n);
                 }
             }
         }
@@ -883,8 +946,9 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         AMOF_TRY(upload(ctx, SLOT_AUX6, fwork.data(), fwork.size() * sizeof(int4), &d_fwork));
         nf.fa.a = a;
         nf.fa.a.work = (const int4 *)d_fwork;
-        size_t lds = NBRF_TILE * sizeof(uint4) + (size_t)AMOF_MAX_NEIGHBOURS * NBRF_TILE * sizeof(uint32_t) +
-                     lds_bins * sizeof(unsigned);
+        size_t lds = 3 * (size_t)NBRF_UVCAP * sizeof(double) +
+                     (size_t)NBRF_NLIST * NBRF_TILE * sizeof(uint32_t) + NBRF_TILE * sizeof(uint32_t) +
+                     (NBRF_TILE + 4) * sizeof(int) + NBRF_UVCAP * sizeof(unsigned short) + lds_bins * sizeof(unsigned);
         int64_t launches = 0;
         for (int64_t fb = 0, cur = nf.FB0; fb < t->n_frames && !fwork.empty(); fb += cur, cur = std::min<int64_t>(2 * cur, nf.FB)) {
             const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
