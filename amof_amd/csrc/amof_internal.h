@@ -198,13 +198,21 @@ int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom,
                      QAtom *d_Q, uint32_t *d_start2, int32_t *d_flag);
 
 // 3-D cell sort for the cell-list RDF kernel: all atoms of a frame sorted by
-// key = ((cz * ny + cy) * nx + cx) * S + species (x fastest), d_start3[nf][nkeys + 1] = offsets.
+// key = ((cz * ny + cy) * nx + cx) * S + species (x fastest),
+// d_start3[nf][nkeys + 1] = offsets.
 // Q3[.].idx = species << CELL_SPECIES_SHIFT | atom index.  Scratch: d_keys u32 [nf][N],
 // d_cursor u32 [nf][nkeys].
 constexpr int CELL_SPECIES_SHIFT = 26;
 int launch_cell_sort(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_species,
                      int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q3, uint32_t *d_start3,
                      uint32_t *d_keys, uint32_t *d_cursor, int32_t *d_flag);
+
+// 3-D cell sort per species segment for the neighbour kernels (cell counters in LDS: at most CELL_LDS_MAX cells):
+// d_Q[nf][N] sorted by (species, cell), d_start3[nf][S * ncell + 1]
+constexpr int CELL_LDS_MAX = 16384;
+int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
+                          const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q,
+                          uint32_t *d_start3, int32_t *d_flag);
 
 void timing_begin(amof_ctx *ctx);
 void timing_end(amof_ctx *ctx);

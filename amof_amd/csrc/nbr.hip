@@ -305,7 +305,14 @@ struct NbrFastArgs {
     int32_t f_base, nf;
     float guard_rel;              // relative half-width of the "re-decide exactly" band
     float guard_abs;              // absolute part (fixed-point grid), Angstrom
+    // 3-D cell-list variant (CELL kernels): Q holds every atom of a frame sorted by (species, cell), x fastest
+    // (launch_cell_sort, species-major keys; record idx = species << CELL_SPECIES_SHIFT | atom), cells at least as
+    // thick as the largest cutoff, >= 3 per axis; start3[nf][S * ncells + 1] = offsets
+    const uint32_t *start3;
+    int32_t nx, ny, nz;
 };
+
+constexpr uint32_t NBR_IDX_MASK = (1u << CELL_SPECIES_SHIFT) - 1u;
 
 template <bool ORTHO>
 __device__ __forceinline__ float nbr_fast_dist(const float *sc, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj)
@@ -357,6 +364,60 @@ __device__ __forceinline__ void nbr_ranges(const uint32_t *__restrict__ st /* [Q
     }
 }
 
+// Cell-list neighbour search of one centre atom (lane): the 27 cells around its own, as 9 rows (dz, dy) of the
+// x-run cx-1 .. cx+1 (two index ranges when the run wraps), inside partner species sb's segment of the sorted
+// frame.  All 18 range bounds are loaded before any partner is gathered (dependent L2 round trips otherwise); the
+// pair test is the fast path's: f32 distance of the wrapped fixed-point differences, pairs inside the guard band
+// re-decided by the canonical float64 arithmetic.  found(atom index) is called for every neighbour.
+template <bool ORTHO, typename F>
+__device__ __forceinline__ void cell_neighbours(const NbrFastArgs &fa, const QAtom *__restrict__ Qf,
+                                                const uint32_t *__restrict__ st, const float *sc,
+                                                const double *__restrict__ geo, const double *__restrict__ p, bool has,
+                                                const QAtom &qc, uint32_t own_idx, int sb, double rc, F &&found)
+{
+    const int nx = fa.nx, ny = fa.ny, nz = fa.nz;
+    const uint32_t *__restrict__ sts = st + (size_t)sb * ((size_t)nx * ny * nz);
+    const float rcf = (float)rc;
+    const float g = rcf * fa.guard_rel + fa.guard_abs;
+    const float r_in = rcf - g, r_out = rcf + g;
+    const int cx = (int)__umulhi(qc.ux, (unsigned)nx), cy = (int)__umulhi(qc.uy, (unsigned)ny),
+              cz = (int)__umulhi(qc.uz, (unsigned)nz);
+    // x-run cx-1 .. cx+1 with periodic wrap (nx >= 3: three distinct cells)
+    int xa0 = cx - 1, xb0 = cx + 1, xa1 = 0, xb1 = -1;
+    if (xa0 < 0) { xa0 = nx - 1; xb0 = nx - 1; xa1 = 0; xb1 = cx + 1; }
+    else if (xb0 >= nx) { xb0 = nx - 1; xa1 = 0; xb1 = 0; }
+    int lo[18], hi[18];
+#pragma unroll
+    for (int row = 0; row < 9; row++) {
+        int cz2 = cz + row / 3 - 1, cy2 = cy + row % 3 - 1;
+        cz2 += cz2 < 0 ? nz : 0; cz2 -= cz2 >= nz ? nz : 0;
+        cy2 += cy2 < 0 ? ny : 0; cy2 -= cy2 >= ny ? ny : 0;
+        const int rowbase = (cz2 * ny + cy2) * nx;
+        lo[2 * row] = has ? (int)sts[rowbase + xa0] : 0;
+        hi[2 * row] = has ? (int)sts[rowbase + xb0 + 1] : 0;
+        lo[2 * row + 1] = has && xa1 <= xb1 ? (int)sts[rowbase + xa1] : 0;
+        hi[2 * row + 1] = has && xa1 <= xb1 ? (int)sts[rowbase + xb1 + 1] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 18; r++) {
+        for (int j = lo[r]; j < hi[r]; j += 2) {
+            // two partners per trip, both gathered before either is tested
+            const uint4 q0 = *reinterpret_cast<const uint4 *>(Qf + j);
+            const uint4 q1 = *reinterpret_cast<const uint4 *>(Qf + min(j + 1, hi[r] - 1));
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint4 qj = u == 0 ? q0 : q1;
+                const uint32_t idx_j = qj.w & NBR_IDX_MASK;
+                if (j + u >= hi[r] || idx_j == own_idx) continue;       // (no zero-shift self pair)
+                const float d = nbr_fast_dist<ORTHO>(sc, qc.ux, qc.uy, qc.uz, qj);
+                bool nbr = d < r_in;
+                if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, own_idx, idx_j, rc);
+                if (nbr) found(idx_j);
+            }
+        }
+    }
+}
+
 constexpr int NBRF_TILE = 256;
 constexpr int NBRF_NLIST = 16;     // neighbours per centre bad_fast_kernel keeps in LDS (more: big-list pass of the exact kernel)
 constexpr int NBRF_UVCAP = 768;    // unit vectors per centre tile and frame held in LDS for the flattened angle phase
@@ -364,7 +425,7 @@ constexpr int NBRF_UVCAP = 768;    // unit vectors per centre tile and frame hel
 //  + 16 KB lists + 14 KB histogram + 3.5 KB tables = 52.8 KB)
 static_assert(NBRF_NLIST <= AMOF_MAX_NEIGHBOURS, "the fast kernel's lists must not exceed the documented capacity");
 
-template <bool ORTHO>
+template <bool ORTHO, bool CELL = false>
 __global__ __launch_bounds__(NBRF_TILE) void cn_fast_kernel(NbrFastArgs fa)
 {
     const NbrArgs &a = fa.a;
@@ -394,12 +455,17 @@ __global__ __launch_bounds__(NBRF_TILE) void cn_fast_kernel(NbrFastArgs fa)
 #pragma unroll
         for (int k = 0; k < 9; k++) sc[k] = cell->sc[k];
         const QAtom qc = Qf[segA + c0 + min(tid, cnt_c - 1)];
-        const uint32_t s_first = Qf[segA + c0].uz >> 24, s_last = Qf[segA + c0 + cnt_c - 1].uz >> 24;
-        int rb[2], re[2];
-        nbr_ranges(fa.slab_start + ((size_t)fl * a.S + B) * (QSLABS + 1), s_first, s_last, rc, cell->gap_per_len, nB,
-                   rb[0], re[0], rb[1], re[1]);
+        const uint32_t own_idx = CELL ? (qc.idx & NBR_IDX_MASK) : qc.idx;
         int cnt = 0;
-        if (rc > 0.0) {
+        if (CELL) {
+            if (rc > 0.0)
+                cell_neighbours<ORTHO>(fa, Qf, fa.start3 + (size_t)fl * ((size_t)a.S * fa.nx * fa.ny * fa.nz + 1), sc, geo, p,
+                                       has, qc, own_idx, B, rc, [&](uint32_t) { cnt++; });
+        } else if (rc > 0.0) {
+            const uint32_t s_first = Qf[segA + c0].uz >> 24, s_last = Qf[segA + c0 + cnt_c - 1].uz >> 24;
+            int rb[2], re[2];
+            nbr_ranges(fa.slab_start + ((size_t)fl * a.S + B) * (QSLABS + 1), s_first, s_last, rc, cell->gap_per_len, nB,
+                       rb[0], re[0], rb[1], re[1]);
             for (int r = 0; r < 2; r++) {
                 for (int j0 = rb[r]; j0 < re[r]; j0 += NBRF_TILE) {
                     const int nj = min(NBRF_TILE, re[r] - j0);
@@ -421,7 +487,7 @@ __global__ __launch_bounds__(NBRF_TILE) void cn_fast_kernel(NbrFastArgs fa)
                 }
             }
         }
-        if (a.per_atom && has) a.per_atom[((size_t)f * a.n_sets + set) * (size_t)a.N + qc.idx] = cnt;
+        if (a.per_atom && has) a.per_atom[((size_t)f * a.n_sets + set) * (size_t)a.N + own_idx] = cnt;
         unsigned long long v = has ? (unsigned long long)cnt : 0ull;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         __syncthreads();
@@ -452,7 +518,7 @@ __device__ __forceinline__ bool unit_vec(double x, double y, double z, double &u
 //       minimum-image vector, unit vector -> LDS;
 //   2b  every entry forms its angles with the later entries of the same centre from LDS -- no global loads.
 // Same arithmetic per angle as before (ase get_angles order), so the counts still equal the oracle's bit for bit.
-template <bool ORTHO>
+template <bool ORTHO, bool CELL = false>
 __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
 {
     const NbrArgs &a = fa.a;
@@ -507,12 +573,23 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
 #pragma unroll
         for (int k = 0; k < 9; k++) sc[k] = cell->sc[k];
         const QAtom qc = Qf[segA + c0 + min(tid, cnt_c - 1)];
-        const uint32_t s_first = Qf[segA + c0].uz >> 24, s_last = Qf[segA + c0 + cnt_c - 1].uz >> 24;
+        const uint32_t own_idx = CELL ? (qc.idx & NBR_IDX_MASK) : qc.idx;
+        const uint32_t s_first = CELL ? 0u : Qf[segA + c0].uz >> 24, s_last = CELL ? 0u : Qf[segA + c0 + cnt_c - 1].uz >> 24;
         int n = 0;
+        auto found = [&](uint32_t idx_j) {
+            if (n < NBRF_NLIST) nlist[n * NBRF_TILE + tid] = idx_j;
+            else a.flags[1] = 1;
+            n++;
+        };
         for (int sb = 0; sb < a.S; sb++) {
             if (!(B < 0 || sb == B)) continue;
             const double rc = a.cutoff[sa * a.S + sb];
             if (!(rc > 0.0)) continue;
+            if (CELL) {
+                cell_neighbours<ORTHO>(fa, Qf, fa.start3 + (size_t)fl * ((size_t)a.S * fa.nx * fa.ny * fa.nz + 1), sc, geo, p,
+                                       has, qc, own_idx, sb, rc, found);
+                continue;
+            }
             const int64_t segB = fa.sp_first[sb];
             const int nB = (int)(fa.sp_first[sb + 1] - segB);
             const float rcf = (float)rc;
@@ -537,29 +614,27 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
                         const float d = nbr_fast_dist<ORTHO>(sc, qc.ux, qc.uy, qc.uz, qj);
                         bool nbr = d < r_in;
                         if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, qc.idx, qj.w, rc);
-                        if (nbr) {
-                            if (n < NBRF_NLIST) nlist[n * NBRF_TILE + tid] = qj.w;
-                            else a.flags[1] = 1;
-                            n++;
-                        }
+                        if (nbr) found(qj.w);
                     }
                 }
             }
         }
         n = has ? min(n, NBRF_NLIST) : 0;
-        // entries before each centre: exclusive scan of n over the workgroup
-        int incl = n;
+        // entries before each centre: exclusive scan over the workgroup of the neighbour counts of the centres that
+        // form angles at all (a centre with a single neighbour -- every N of ZIF-4 -- contributes nothing)
+        const int n_ent = n >= 2 ? n : 0;
+        int incl = n_ent;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off, 64);
             if (lane >= off) incl += t;
         }
         __syncthreads();                       // the previous frame's angle phase has finished with pref / uv / ec
         if (lane == 63) s_wtot[wave] = incl;
-        s_cidx[tid] = qc.idx;
+        s_cidx[tid] = own_idx;
         __syncthreads();
         int before = 0;
         for (int q = 0; q < wave; q++) before += s_wtot[q];
-        pref[tid] = before + incl - n;
+        pref[tid] = before + incl - n_ent;
         if (tid == NBRF_TILE - 1) pref[NBRF_TILE] = before + incl;
         __syncthreads();
         const int total = pref[NBRF_TILE];
@@ -589,7 +664,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
             }
         } else if (has && n >= 2) {
             // more neighbours in this tile than the LDS table holds: per-centre loops straight from global memory
-            const double *pc = p + (size_t)qc.idx * 3;
+            const double *pc = p + (size_t)own_idx * 3;
             const double cx = pc[0], cy = pc[1], cz = pc[2];
             for (int u = 0; u < n - 1; u++) {
                 const double *pu = p + (size_t)nlist[u * NBRF_TILE + tid] * 3;
@@ -702,7 +777,28 @@ struct NbrFast {
     void *d_Q = nullptr, *d_slab = nullptr, *d_cells = nullptr, *d_spfirst = nullptr, *d_qflag = nullptr;
     std::vector<int64_t> sp_first;
     NbrFastArgs fa;
+    // 3-D cell list (cutoffs far below the cell size): frames sorted by (species, cell) instead of slabs
+    bool cell = false;
+    int nk[3] = {0, 0, 0};
+    void *d_start3 = nullptr;
 };
+
+// quantise + sort one frame batch for the neighbour kernels (slab list or cell list) and point fa at it
+static int nbr_fast_batch(amof_ctx *ctx, const amof_traj *t, NbrSetup &st, NbrFast &nf, int64_t fb, int64_t nfr)
+{
+    const NbrArgs &a = st.a;
+    if (nf.cell)
+        AMOF_TRY(launch_quantize_cells(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst,
+                                       t->n_species, t->n_atoms, (int)fb, (int)nfr, nf.nk[0], nf.nk[1], nf.nk[2],
+                                       (QAtom *)nf.d_Q, (uint32_t *)nf.d_start3, (int32_t *)nf.d_qflag));
+    else
+        AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, t->n_species,
+                                 t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
+                                 (int32_t *)nf.d_qflag));
+    nf.fa.f_base = (int32_t)fb;
+    nf.fa.nf = (int32_t)nfr;
+    return AMOF_OK;
+}
 
 static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cutoff, NbrSetup &st, NbrFast &nf)
 {
@@ -744,20 +840,68 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     }
     nf.sp_first.assign(S + 1, 0);
     for (int x = 0; x < S; x++) nf.sp_first[x + 1] = nf.sp_first[x] + st.tiles.nsp[x];
-    int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / std::max<int64_t>(1, t->n_atoms * 16));
+    // 3-D cell list instead of the slab list when the cutoffs are far below the cell size: cells at least R thick
+    // (R = the largest cutoff), >= 3 per axis, reach 1 -- a centre meets the partners of 27 cells instead of a slab
+    // range (ZIF-4 3x3x4, Zn-N at 2.5 A: ~7 candidates per Zn instead of ~930)
+    {
+        bool cell_ok = t->n_atoms >= 256 && t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && !getenv("AMOF_NBR_NOCELL");
+        for (int x = 0; x < 3; x++) {
+            nf.nk[x] = (int)std::min(1024.0, floor(hmin[x] / (R * (1.0 + 1e-5))));
+            if (nf.nk[x] < 3) cell_ok = false;
+        }
+        if (cell_ok) {
+            // no point in cells emptier than ~2 atoms (thicker cells stay correct, the tables shrink)
+            while ((int64_t)nf.nk[0] * nf.nk[1] * nf.nk[2] > std::min<int64_t>(CELL_LDS_MAX, std::max<int64_t>(27, t->n_atoms / 2))) {
+                int big = 0;
+                for (int x = 1; x < 3; x++)
+                    if (nf.nk[x] > nf.nk[big]) big = x;
+                if (nf.nk[big] <= 3) { cell_ok = false; break; }     // (a tiny box with absurdly many atoms)
+                nf.nk[big]--;
+            }
+            // visited share of a partner species: 27 cells of the grid vs the slab range of a 256-centre tile
+            const double f3 = 27.0 / ((double)nf.nk[0] * nf.nk[1] * nf.nk[2]);
+            const double f1 = std::min(1.0, 2.0 * R / hmin[nf.axis] + 0.1);
+            if (!(f3 < 0.25 * f1) && !getenv("AMOF_NBR_FORCE_CELL")) cell_ok = false;
+            if ((int64_t)nf.nk[0] * nf.nk[1] * nf.nk[2] * S > 0x3fffffff) cell_ok = false;
+        }
+        nf.cell = cell_ok;
+    }
+    size_t per_frame = (size_t)t->n_atoms * sizeof(QAtom);
+    const int64_t nkeys = nf.cell ? (int64_t)nf.nk[0] * nf.nk[1] * nf.nk[2] * S : 0;
+    if (nf.cell) per_frame += (size_t)(nkeys + 1) * sizeof(uint32_t);
+    int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / (int64_t)std::max<size_t>(1, per_frame));
     nf.FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), std::max<int64_t>(1, t->n_frames));
     // host-resident input: batches of 512, 1024, 2048 ... frames, the copy of the next one overlaps this one's kernels
     nf.FB0 = st.stage.lazy ? std::min<int64_t>(nf.FB, 512) : nf.FB;
+    if (nf.cell) {
+        // the cell kernels read the fixed-point components in the cell's own axis order
+        for (int64_t k = 0; k < nc; k++) {
+            const double *c = t->cell + 9 * k;
+            NbrCell &r = cells[(size_t)k];
+            for (int q = 0; q < 9; q++) r.sc[q] = 0.f;
+            if (nf.ortho) {
+                for (int q = 0; q < 3; q++) r.sc[q] = (float)(c[4 * q] * two32);
+            } else {
+                for (int q = 0; q < 9; q++) r.sc[q] = (float)(c[q] * two32);
+            }
+        }
+    }
     AMOF_TRY(upload(ctx, SLOT_AUX4, cells.data(), cells.size() * sizeof(NbrCell), &nf.d_cells));
     AMOF_TRY(upload(ctx, SLOT_AUX5, nf.sp_first.data(), nf.sp_first.size() * sizeof(int64_t), &nf.d_spfirst));
     AMOF_TRY(ensure(ctx, SLOT_HISTU, (size_t)nf.FB * t->n_atoms * sizeof(QAtom), &nf.d_Q));
-    AMOF_TRY(ensure(ctx, SLOT_SELF, (size_t)nf.FB * S * (QSLABS + 1) * sizeof(uint32_t), &nf.d_slab));
+    if (nf.cell) {
+        AMOF_TRY(ensure(ctx, SLOT_SELF, (size_t)nf.FB * (nkeys + 1) * sizeof(uint32_t), &nf.d_start3));
+    } else {
+        AMOF_TRY(ensure(ctx, SLOT_SELF, (size_t)nf.FB * S * (QSLABS + 1) * sizeof(uint32_t), &nf.d_slab));
+    }
     AMOF_TRY(ensure(ctx, SLOT_SPEC, sizeof(int32_t), &nf.d_qflag));
     AMOF_HIP_TRY(ctx, hipMemsetAsync(nf.d_qflag, 0, sizeof(int32_t), ctx->stream));
     NbrFastArgs &fa = nf.fa;
     fa.a = st.a;
     fa.Q = (const QAtom *)nf.d_Q;
     fa.slab_start = (const uint32_t *)nf.d_slab;
+    fa.start3 = (const uint32_t *)nf.d_start3;
+    fa.nx = nf.nk[0]; fa.ny = nf.nk[1]; fa.nz = nf.nk[2];
     fa.cells = (const NbrCell *)nf.d_cells;
     fa.sp_first = (const int64_t *)nf.d_spfirst;
     // f32 chain error: fast_guard_rel (amof_internal.h); the fixed-point grid moves a distance by
@@ -835,17 +979,15 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         for (int64_t fb = 0, cur = nf.FB0; fb < t->n_frames && !fwork.empty(); fb += cur, cur = std::min<int64_t>(2 * cur, nf.FB)) {
             const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
             AMOF_TRY(stager_need(st.stage, fb + nfr));
-            AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, S,
-                                     t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
-                                     (int32_t *)nf.d_qflag));
-            nf.fa.f_base = (int32_t)fb;
-            nf.fa.nf = (int32_t)nfr;
+            AMOF_TRY(nbr_fast_batch(ctx, t, st, nf, fb, nfr));
             unsigned chunks;
             pick_chunks(nfr, fwork.size(), nf.fa.a.frames_per_chunk, chunks);
             dim3 grid((unsigned)fwork.size(), chunks);
-            if (launches == 0) timing_dom_begin(ctx, "cn_fast");
-            if (nf.ortho) hipLaunchKernelGGL(cn_fast_kernel<true>, grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
-            else hipLaunchKernelGGL(cn_fast_kernel<false>, grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
+            if (launches == 0) timing_dom_begin(ctx, nf.cell ? "cn_cell" : "cn_fast");
+            if (nf.cell && nf.ortho) hipLaunchKernelGGL((cn_fast_kernel<true, true>), grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
+            else if (nf.cell) hipLaunchKernelGGL((cn_fast_kernel<false, true>), grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
+            else if (nf.ortho) hipLaunchKernelGGL((cn_fast_kernel<true, false>), grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
+            else hipLaunchKernelGGL((cn_fast_kernel<false, false>), grid, dim3(NBRF_TILE), 0, ctx->stream, nf.fa);
             AMOF_HIP_TRY(ctx, hipGetLastError());
             launches++;
         }
@@ -953,23 +1095,21 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         for (int64_t fb = 0, cur = nf.FB0; fb < t->n_frames && !fwork.empty(); fb += cur, cur = std::min<int64_t>(2 * cur, nf.FB)) {
             const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
             AMOF_TRY(stager_need(st.stage, fb + nfr));
-            AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, S,
-                                     t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
-                                     (int32_t *)nf.d_qflag));
-            nf.fa.f_base = (int32_t)fb;
-            nf.fa.nf = (int32_t)nfr;
+            AMOF_TRY(nbr_fast_batch(ctx, t, st, nf, fb, nfr));
             unsigned chunks;
             pick_chunks(nfr, fwork.size(), nf.fa.a.frames_per_chunk, chunks);
             dim3 grid((unsigned)fwork.size(), chunks);
-            if (launches == 0) timing_dom_begin(ctx, "bad_fast");
+            if (launches == 0) timing_dom_begin(ctx, nf.cell ? "bad_cell" : "bad_fast");
+            auto launch = [&](auto kern) -> hipError_t {
+                hipError_t e2 = allow_max_lds((const void *)kern);
+                if (e2 == hipSuccess) hipLaunchKernelGGL(kern, grid, dim3(NBRF_TILE), lds, ctx->stream, nf.fa);
+                return e2;
+            };
             hipError_t e;
-            if (nf.ortho) {
-                e = allow_max_lds((const void *)bad_fast_kernel<true>);
-                if (e == hipSuccess) hipLaunchKernelGGL(bad_fast_kernel<true>, grid, dim3(NBRF_TILE), lds, ctx->stream, nf.fa);
-            } else {
-                e = allow_max_lds((const void *)bad_fast_kernel<false>);
-                if (e == hipSuccess) hipLaunchKernelGGL(bad_fast_kernel<false>, grid, dim3(NBRF_TILE), lds, ctx->stream, nf.fa);
-            }
+            if (nf.cell && nf.ortho) e = launch(bad_fast_kernel<true, true>);
+            else if (nf.cell) e = launch(bad_fast_kernel<false, true>);
+            else if (nf.ortho) e = launch(bad_fast_kernel<true, false>);
+            else e = launch(bad_fast_kernel<false, false>);
             AMOF_HIP_TRY(ctx, e);
             AMOF_HIP_TRY(ctx, hipGetLastError());
             launches++;

@@ -92,6 +92,80 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_kernel(const double *_
     }
 }
 
+// 3-D cell variant for the neighbour kernels (cutoffs far below the cell size): one workgroup per (species,
+// frame) counting-sorts the species segment by cell = (cz ny + cy) nx + cx (x fastest) with the counters in LDS,
+// positions read once (the quantised records wait in LDS between the counting and the placement pass, as in
+// quantize_kernel).  start3[fl][sp * ncell + c] = position, inside the frame's sorted array, of the first atom of
+// species sp in cell c; start3[fl][S * ncell] = N.  Record idx = species << CELL_SPECIES_SHIFT | atom.
+// Components are stored in the cell's own axis order (ux, uy, uz) = axes (0, 1, 2).
+__global__ __launch_bounds__(QUANT_THREADS) void quantize_cells_kernel(const double *__restrict__ pos,
+                                                                       const double *__restrict__ geom, int n_cells,
+                                                                       const int32_t *__restrict__ perm,
+                                                                       const int64_t *__restrict__ sp_first, int S,
+                                                                       int64_t N, int f0, int nx, int ny, int nz,
+                                                                       QAtom *__restrict__ Q, uint32_t *__restrict__ start3,
+                                                                       int32_t *flag, int cache_cap)
+{
+    extern __shared__ __align__(16) unsigned char qcache_raw[];
+    QAtom *cache = reinterpret_cast<QAtom *>(qcache_raw);                   // [cache_cap]
+    unsigned *cnt = reinterpret_cast<unsigned *>(cache + cache_cap);        // [ncell]
+    __shared__ unsigned wsum[QUANT_THREADS / 64];
+    const int sp = blockIdx.x, fl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = f0 + fl;
+    const int ncell = nx * ny * nz;
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const int64_t k0 = sp_first[sp], k1 = sp_first[sp + 1];
+    const bool cached = k1 - k0 <= (int64_t)cache_cap;
+    auto cell_of = [&](const QAtom &q) {
+        return (int)((__umulhi(q.uz, (unsigned)nz) * (unsigned)ny + __umulhi(q.uy, (unsigned)ny)) * (unsigned)nx +
+                     __umulhi(q.ux, (unsigned)nx));
+    };
+    for (int c = tid; c < ncell; c += QUANT_THREADS) cnt[c] = 0u;
+    __syncthreads();
+    for (int64_t k = k0 + tid; k < k1; k += QUANT_THREADS) {
+        QAtom q = quantize_atom(pos, g, N, f, perm[k], 0, 1, 2, flag);
+        q.idx |= (uint32_t)sp << CELL_SPECIES_SHIFT;
+        if (cached) cache[k - k0] = q;
+        atomicAdd(&cnt[cell_of(q)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the cell counters: one contiguous chunk per thread, chunk totals scanned by waves
+    const int chunk = (ncell + QUANT_THREADS - 1) / QUANT_THREADS;
+    const int c0 = min(tid * chunk, ncell), c1 = min(c0 + chunk, ncell);
+    unsigned s = 0;
+    for (int c = c0; c < c1; c++) s += cnt[c];
+    unsigned incl = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - s;
+    for (int w = 0; w < wv; w++) run += wsum[w];
+    uint32_t *st = start3 + (size_t)fl * ((size_t)S * ncell + 1) + (size_t)sp * ncell;
+    for (int c = c0; c < c1; c++) {
+        const unsigned v = cnt[c];
+        cnt[c] = run;                       // (cursor of the placement pass)
+        st[c] = (uint32_t)k0 + run;
+        run += v;
+    }
+    if (sp == S - 1 && tid == 0) start3[(size_t)fl * ((size_t)S * ncell + 1) + (size_t)S * ncell] = (uint32_t)N;
+    __syncthreads();
+    QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
+    for (int64_t k = k0 + tid; k < k1; k += QUANT_THREADS) {
+        QAtom q;
+        if (cached) {
+            q = cache[k - k0];
+        } else {
+            q = quantize_atom(pos, g, N, f, perm[k], 0, 1, 2, flag);
+            q.idx |= (uint32_t)sp << CELL_SPECIES_SHIFT;
+        }
+        const unsigned slot = atomicAdd(&cnt[cell_of(q)], 1u);
+        Qf[slot] = q;
+    }
+}
+
 // Two-level variant for small cutoffs in big cells: nz coarse slabs along `axis_z` (each at
 // least one cutoff thick) x 256 fine bins along `axis_y`.  Key = slab * 256 + ybin; the species
 // segment is counting-sorted by key and start2[(fl*S + sp)*(nz*256+1) + key] gives the offset
@@ -253,6 +327,24 @@ int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom,
     dim3 qgrid((unsigned)S, (unsigned)nf);
     hipLaunchKernelGGL(quantize2_kernel, qgrid, dim3(256), (size_t)nz * 256 * sizeof(unsigned), ctx->stream, pos_dev,
                        d_geom, n_cells, d_perm, d_spfirst, S, N, f0, axis_z, axis_y, nz, d_Q, d_start2, d_flag);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    return AMOF_OK;
+}
+
+int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
+                          const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q,
+                          uint32_t *d_start3, int32_t *d_flag)
+{
+    if (nf <= 0 || S <= 0) return AMOF_OK;
+    if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
+    const int64_t ncell = (int64_t)nx * ny * nz;
+    if (nx < 1 || ny < 1 || nz < 1 || ncell > CELL_LDS_MAX || N >= (1ll << CELL_SPECIES_SHIFT) || S > 64)
+        return fail(ctx, AMOF_EINVAL, "bad cell grid");
+    const int cache_cap = (int)std::min<int64_t>(N, 4608);
+    const size_t lds = (size_t)cache_cap * sizeof(QAtom) + (size_t)ncell * sizeof(unsigned);
+    AMOF_HIP_TRY(ctx, allow_max_lds((const void *)quantize_cells_kernel));
+    hipLaunchKernelGGL(quantize_cells_kernel, dim3((unsigned)S, (unsigned)nf), dim3(QUANT_THREADS), lds, ctx->stream, pos_dev,
+                       d_geom, n_cells, d_perm, d_spfirst, S, N, f0, nx, ny, nz, d_Q, d_start3, d_flag, cache_cap);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     return AMOF_OK;
 }

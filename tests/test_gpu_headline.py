@@ -191,7 +191,7 @@ def test_config3_bad_and_cn_at_9792_atoms(hip_ctx, traj544):
     edges = np.arange(bins + 2) * 0.05
     triples = [(n, zn), (zn, n)]          # Zn-N-Zn (centre N), N-Zn-N (centre Zn)
     full, nang = hip_ctx.bad_hist(packed, rcm, triples, edges)
-    assert hip_ctx.last_path() == "bad_fast"
+    assert hip_ctx.last_path() == "bad_cell"       # 3-D cell list: cutoff 2.5 A in a 46 x 46 x 74 A cell
     sample = [0, 67, 68, 271, 272, 543]
     pos_s = _host_frames(packed, sample)
     for q, k in enumerate(sample):
@@ -209,7 +209,7 @@ def test_config3_bad_and_cn_at_9792_atoms(hip_ctx, traj544):
     # CN: per-frame sums of the big launch vs the oracle on the sampled frames
     sets = [(zn, n), (n, zn)]
     sums = hip_ctx.cn_count(packed, rcm, sets)
-    assert hip_ctx.last_path() == "cn_fast"
+    assert hip_ctx.last_path() == "cn_cell"
     s_cpu = clib.cn_counts(pos_s, packed.cell, sp, len(kinds), rcm, sets)
     assert np.array_equal(sums[sample], s_cpu)
     # classes on top: columns and normalisation

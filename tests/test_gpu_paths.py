@@ -105,10 +105,16 @@ def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
     sets = [(zn, n), (n, zn), (c, n), (c, c), (h, c)]
     triples = [(zn, n), (n, -1), (-1, -1), (c, c), (c, -1)]
     edges = np.arange(int(180 // 0.5) + 2) * 0.5
-    s_fast, pa_fast = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
-    assert hip_ctx.last_path() == "cn_fast"
-    h_fast, a_fast = hip_ctx.bad_hist(packed, rcm, triples, edges)
-    assert hip_ctx.last_path() == "bad_fast"
+    with _env(AMOF_NBR_NOCELL="1"):                                  # 1-D slab list
+        s_fast, pa_fast = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+        assert hip_ctx.last_path() == "cn_fast"
+        h_fast, a_fast = hip_ctx.bad_hist(packed, rcm, triples, edges)
+        assert hip_ctx.last_path() == "bad_fast"
+    with _env(AMOF_NBR_FORCE_CELL="1"):                              # 3-D cell list (species-major cell sort)
+        s_cell, pa_cell = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+        assert hip_ctx.last_path() == "cn_cell"
+        h_cell, a_cell = hip_ctx.bad_hist(packed, rcm, triples, edges)
+        assert hip_ctx.last_path() == "bad_cell"
     with _env(AMOF_NBR_KERNEL="v1"):
         s_ex, pa_ex = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
         assert hip_ctx.last_path() == "cn_exact"
@@ -117,10 +123,42 @@ def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
     s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
     h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
     assert np.array_equal(s_fast, s_ref) and np.array_equal(pa_fast, pa_ref)
+    assert np.array_equal(s_cell, s_ref) and np.array_equal(pa_cell, pa_ref)
     assert np.array_equal(s_ex, s_ref) and np.array_equal(pa_ex, pa_ref)
     assert np.array_equal(a_fast, a_ref) and np.array_equal(h_fast, h_ref)
+    assert np.array_equal(a_cell, a_ref) and np.array_equal(h_cell, h_ref)
     assert np.array_equal(a_ex, a_ref) and np.array_equal(h_ex, h_ref)
     assert a_ref.sum() > 0
+
+
+def test_cell_list_neighbours_on_lattices_and_sheared_cells(hip_ctx):
+    """the 3-D cell-list CN / BAD kernels where the cell grid is tight: atoms exactly on cell faces (integer
+    lattice, cells a whole number of lattice constants thick), pairs exactly at the cutoff, a strongly sheared
+    cell, three cells per axis (every neighbour cell distinct only just), several species and an 'X' triple"""
+    a, n = 2.0, 9
+    g = np.arange(n) * a
+    pos = np.array([[x, y, z] for x in g for y in g for z in g], dtype=float)
+    numbers = np.where(np.arange(len(pos)) % 3 == 0, 30, np.where(np.arange(len(pos)) % 3 == 1, 7, 6))
+    edges = np.arange(int(180 // 1.0) + 2) * 1.0
+    for cell in (np.diag([n * a] * 3), np.array([[n * a, 0, 0], [4 * a, n * a, 0], [2 * a, 6 * a, n * a]])):
+        packed = PackedTrajectory(np.stack([pos, pos + 0.5, pos - 11.0]), cell, numbers)
+        kinds, sp = H.species_of(packed.numbers)
+        for rc in (a, np.nextafter(a, 9.0), a * np.sqrt(2.0), np.nextafter(a * np.sqrt(2.0), 9.0), 2.9):
+            rcm = np.full((3, 3), rc)
+            rcm[0, 0] = 0.0
+            sets = [(x, y) for x in range(3) for y in range(3)]
+            triples = [(2, 1), (1, -1), (-1, -1)]
+            with _env(AMOF_NBR_FORCE_CELL="1"):
+                s_cell, pa_cell = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+                path_cn = hip_ctx.last_path()
+                h_cell, a_cell = hip_ctx.bad_hist(packed, rcm, triples, edges)
+                path_bad = hip_ctx.last_path()
+            s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, 3, rcm, sets, per_atom=True)
+            h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, 3, rcm, triples, edges)
+            assert np.array_equal(s_cell, s_ref) and np.array_equal(pa_cell, pa_ref), (rc, path_cn)
+            assert np.array_equal(a_cell, a_ref) and np.array_equal(h_cell, h_ref), (rc, path_bad)
+            if np.array_equal(cell, np.diag(np.diag(cell))):
+                assert path_cn == "cn_cell" and path_bad in ("bad_cell", "bad_exact_biglist")
 
 
 def test_pairs_exactly_at_the_cutoff(hip_ctx):
