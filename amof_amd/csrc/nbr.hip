@@ -969,6 +969,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         std::vector<int4> fwork;
         for (int s2 = 0; s2 < n_sets; s2++) {
             int A = sets[2 * s2], B = sets[2 * s2 + 1];
+            if (!(cutoff[A * S + B] > 0.0) && !per_atom) continue;      // counts stay zero (per_atom still wants its zeros)
             for (int64_t c0 = 0; c0 < st.tiles.nsp[A]; c0 += NBRF_TILE) fwork.push_back(make_int4(s2, (int)c0, A, B));
         }
         void *d_fwork;
@@ -1081,6 +1082,11 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             int A = triples[2 * k], B = triples[2 * k + 1];
             for (int sa = 0; sa < S; sa++) {
                 if (!(A < 0 || sa == A)) continue;
+                // centres of a species that has no cutoff with any partner species of this triple find nothing
+                bool live = false;
+                for (int sb = 0; sb < S; sb++)
+                    if ((B < 0 || sb == B) && cutoff[sa * S + sb] > 0.0 && st.tiles.nsp[sb] > 0) live = true;
+                if (!live) continue;
                 for (int64_t c0 = 0; c0 < st.tiles.nsp[sa]; c0 += NBRF_TILE) fwork.push_back(make_int4(k, (int)c0, sa, B));
             }
         }
