@@ -306,7 +306,8 @@ constexpr int COMB_B = 10;
 // time origin k = 0, which the reference never evaluates (amof/msd.py:200: k starts at m + 1), else 1.
 // (Measured and rejected on the MI355X: keeping the lane-mask compares next to their uses and splitting off the
 // origin task -- 22 % fewer instructions, yet 10 % slower: the kernel is bound by dependency stalls at 2-3 waves per
-// SIMD, not by issue; 512-thread workgroups whose halves split the windows -- 4 waves per SIMD but spills, 0.84 ms.)
+// SIMD, not by issue; 512-thread workgroups whose halves split the windows -- 4 waves per SIMD but spills, 0.84 ms;
+// forcing 4 waves per SIMD by launch bounds (128 VGPRs, spills): 0.90 ms; COMB_B = 8 / 6 / 5: 0.77 / 1.00 / 0.88 ms.)
 template <int WT>
 __device__ __forceinline__ void comb_task(const double *__restrict__ ub, int d, int lim, double m0, double (&acc)[WT])
 {
