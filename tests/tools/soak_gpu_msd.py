@@ -59,6 +59,14 @@ while time.time() < t_end:
         if not np.allclose(got, r, rtol=1e-9, atol=1e-12):
             bad += 1
             print("MSD MISMATCH seed", seed, F, N, len(window), unwrap, float(err), flush=True)
+    if N >= 2:            # atom-sharded calls (what the ranks of a multi-GPU run make): the two ranges add up to the whole
+        cut = int(rng.integers(1, N))
+        parts = ctx.msd_window(packed, window, unwrap=unwrap, atom_range=(0, cut))[0] + \
+            ctx.msd_window(packed, window, unwrap=unwrap, atom_range=(cut, N))[0]
+        n += 1
+        if not np.allclose(parts, sumsq, rtol=1e-11, atol=1e-13):
+            bad += 1
+            print("MSD ATOM-RANGE MISMATCH seed", seed, F, N, cut, unwrap, flush=True)
     if n % 300 < 3:
         print("progress: %d comparisons, %d mismatches, worst relative error %.2e" % (n, bad, worst), flush=True)
 print("kernel families exercised:", dict(sorted(paths.items())))
