@@ -869,7 +869,7 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     size_t per_frame = (size_t)t->n_atoms * sizeof(QAtom);
     const int64_t nkeys = nf.cell ? (int64_t)nf.nk[0] * nf.nk[1] * nf.nk[2] * S : 0;
     if (nf.cell) per_frame += (size_t)(nkeys + 1) * sizeof(uint32_t);
-    int64_t FB = std::max<int64_t>(1, (int64_t)(1ll << 30) / (int64_t)std::max<size_t>(1, per_frame));
+    int64_t FB = std::max<int64_t>(1, (int64_t)(2ll << 30) / (int64_t)std::max<size_t>(1, per_frame));   // <= 2 GiB of scratch
     nf.FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), std::max<int64_t>(1, t->n_frames));
     // host-resident input: batches of 512, 1024, 2048 ... frames, the copy of the next one overlaps this one's kernels
     nf.FB0 = st.stage.lazy ? std::min<int64_t>(nf.FB, 512) : nf.FB;
