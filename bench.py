@@ -284,11 +284,16 @@ def main():
         local_rank = args.all_on_device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # AMOF_DIST_FORCE_MERGE=1 (rehearsal on one GPU): a one-rank group, every collective of the N > 1 path really runs
+    forced = world == 1 and os.environ.get("AMOF_DIST_FORCE_MERGE") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or forced:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     reps = tuple(int(x) for x in args.reps.split(","))
     F = args.frames
@@ -298,7 +303,7 @@ def main():
     torch.cuda.synchronize()                        # generation finished before anything is timed
     N = packed.n_atoms
     ctx = _hip.get_context(local_rank)
-    mode = False if world == 1 else (None if strong else 'local')
+    mode = False if (world == 1 and not forced) else (None if strong else 'local')
 
     def step(with_bad, rec):
         t0 = time.perf_counter()
@@ -323,7 +328,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -339,7 +344,7 @@ def main():
             res = step(with_bad, rec)
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if world > 1 or forced:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -360,7 +365,7 @@ def main():
         per_rank["kernel_s"]["bad_all"] = cfg3[2]["bad_all"]
         per_rank["wall_s"]["bad_wall"] = cfg3[2]["bad_wall"]
     ranks = [per_rank]
-    if world > 1:
+    if world > 1 or forced:
         ranks = [None] * world
         dist.all_gather_object(ranks, per_rank)
 
@@ -500,7 +505,7 @@ def main():
             except Exception as exc:
                 out["supplementary"] = {"error": repr(exc)}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 
