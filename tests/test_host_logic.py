@@ -56,6 +56,11 @@ def test_append_suffix():
     assert str(append_suffix("a/b", "rdf")) == "a/b.rdf"
     assert str(append_suffix("a/b.rdf", ".rdf")) == "a/b.rdf"
     assert str(append_suffix("a/b.msd", "rdf")) == "a/b.msd.rdf"
+    # outputs of the reference's own function on these inputs (amof/files/path.py:7-21, run in the build container)
+    for path, suffix, want in [("a", "rdf", "a.rdf"), ("a.rdf", "rdf", "a.rdf"), ("dir/a.v2", "msd", "dir/a.v2.msd"),
+                               ("a.tar.gz", "gz", "a.tar.gz"), ("a", "", "a"), ("a.b", "", "a.b"), ("y.", ".bad", "y..bad"),
+                               (".hidden", "rdf", ".hidden.rdf"), ("a.rdf.bak", "rdf", "a.rdf.bak.rdf"), ("", "cn", ".cn")]:
+        assert str(append_suffix(path, suffix)) == want, (path, suffix)
     assert str(append_suffix("x", "")) == "x"
 
 
