@@ -302,6 +302,19 @@ def main():
     packed = make_trajectory(device, reps, F, 0.05, 20261003 + (0 if strong else rank))
     torch.cuda.synchronize()                        # generation finished before anything is timed
     N = packed.n_atoms
+    same_traj = None
+    if strong and (world > 1 or forced):
+        # strong scaling shards ONE trajectory: every rank must have generated the same bits (same seed, same
+        # generator on identical GPUs) -- checked with a wrapping integer checksum, min == max over the ranks
+        chk = packed.pos.view(torch.int64).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        if args.backend != "nccl":
+            lo, hi = lo.cpu(), hi.cpu()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same_traj = bool(int(lo.item()) == int(hi.item()))
+        if not same_traj:
+            raise SystemExit("bench.py: the ranks generated different trajectories; strong scaling would merge unrelated frames")
     ctx = _hip.get_context(local_rank)
     mode = False if (world == 1 and not forced) else (None if strong else 'local')
 
@@ -422,7 +435,7 @@ def main():
                                    "Rdf(dr=0.01, rmax=half_cell -> %.4f A, %d bins) + WindowMsd(delta_time=100, W=%d)"
                                    % (N, reps[0], reps[1], reps[2], F, "" if strong else " per GPU", rmax, nbins,
                                       len(msd.data)),
-                       "n_atoms": N, "frames_total": frames_per_step, "rdf_bins": nbins, "msd_windows": len(msd.data),
+                       "n_atoms": N, "frames_total": frames_per_step, "trajectory_identical_on_all_ranks": same_traj, "rdf_bins": nbins, "msd_windows": len(msd.data),
                        "parallelism": ("RDF frames sharded x%d + RCCL all-reduce of the u64 histograms in HBM; MSD atoms "
                                        "sharded x%d + all-reduce of the f64 sums" % (world, world)) if strong else
                                       ("own %d-frame block per rank x%d, RCCL all-reduce of the u64 histograms" % (F, world))},
