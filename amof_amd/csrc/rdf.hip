@@ -1376,10 +1376,14 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                                          nullptr, (int32_t *)d_flag));
                 fa.f_base = (int32_t)fb;
                 fa.nf = (int32_t)nf;
-                int64_t want_chunks = (8 * 2048 + (int64_t)fpairs.size() - 1) / (int64_t)fpairs.size();
-                int64_t fpc = std::max<int64_t>(1, nf / std::max<int64_t>(1, want_chunks));
-                const char *fpc_env = getenv("AMOF_RDF_FPC");            // experiments: frames per chunk cap
-                fpc = std::min<int64_t>(fpc, fpc_env ? std::max(1, atoi(fpc_env)) : 16);
+                // frames per workgroup chunk: ~150k workgroups per launch (1280 run at a time: > 100 rounds, so that
+                // ramp-up and drain stay around 1 %), between 2 and 16 frames -- fewer frames flush the LDS histogram
+                // too often, more do not fit the 4 MiB L2 of an XCD.  Measured on cfg3 (profiles/r02/rdf_fpc_sweep.txt):
+                // 5000 frames 87.28 (16) -> 86.84 ms (8); a 625-frame shard 11.33 (10) -> 11.08 ms (2).
+                int64_t fpc = (nf * (int64_t)fpairs.size() + 75000) / 150000;
+                fpc = std::max<int64_t>(2, std::min<int64_t>(fpc, 16));
+                if (const char *fpc_env = getenv("AMOF_RDF_FPC")) fpc = std::max(1, atoi(fpc_env));     // experiments
+                fpc = std::min<int64_t>(fpc, std::max<int64_t>(1, nf));
                 if (nf >= 64) fpc = std::min<int64_t>(fpc, nf / 32);   // >= 32 chunks: every XCD gets >= 4
                 int64_t chunks = (nf + fpc - 1) / fpc;
                 fa.xcd_map = chunks >= 32 ? 1 : 0;
