@@ -128,8 +128,8 @@ class Bad(CoreBad):
             else:
                 hist, nang = np.zeros((0, bins + 1), dtype=np.uint64), np.zeros(0, dtype=np.uint64)
             if merge:
-                hist = _dist.all_reduce_sum(hist)
-                nang = _dist.all_reduce_sum(nang)
+                hist = _dist.all_reduce_sum(hist, device=ctx.device)
+                nang = _dist.all_reduce_sum(nang, device=ctx.device)
         self.hist = hist
         self.n_angles = nang
         self.columns = names
@@ -216,13 +216,13 @@ class BadByCn(CoreBad):
                 nang = np.zeros((0, cn_max + 1), dtype=np.uint64)
             full = float(nang[:, cn_max].any()) if nang.size else 0.0
             if merge:
-                full = _dist.all_reduce_sum(np.array([full]))[0]     # every rank must take the same decision
+                full = _dist.all_reduce_sum(np.array([full]), device=ctx.device)[0]     # every rank must take the same decision
             if not full:
                 break
             cn_max *= 4
         if merge:
-            hist = _dist.all_reduce_sum(hist)
-            nang = _dist.all_reduce_sum(nang)
+            hist = _dist.all_reduce_sum(hist, device=ctx.device)
+            nang = _dist.all_reduce_sum(nang, device=ctx.device)
         self.hist, self.n_angles, self.columns, self.theta = hist, nang, names, theta
         db = np.array(np.diff(theta_bins), float)
         self.bad = {}

@@ -74,7 +74,7 @@ class CoordinationNumber(object):
         sums = ctx.cn_count(packed, rcm, live, frame_range=frame_range) if live else \
             np.zeros((frame_range[1] - frame_range[0], 0), dtype=np.int64)
         if merge and distributed != 'local':
-            sums = _dist.all_gather_rows(sums)
+            sums = _dist.all_gather_rows(sums, device=ctx.device)
 
         data = {'Step': np.asarray(step)[:len(sums)] if distributed == 'local' else step}
         k = 0

@@ -51,7 +51,7 @@ def device_collectives(group=None):
     return d is not None and d.get_backend(group) == "nccl"
 
 
-def all_reduce_sum(x, group=None):
+def all_reduce_sum(x, group=None, device=None):
     """Sum ``x`` over ranks and return it (same type as given).
 
     A torch tensor is reduced in place where it lives (a CUDA tensor over RCCL: the device-resident merge of the
@@ -59,7 +59,9 @@ def all_reduce_sum(x, group=None):
 
     numpy arrays travel through a CPU tensor (gloo) or, when the backend is
     nccl (= RCCL on ROCm), through a CUDA tensor on the current device.
-    uint64 counts are reinterpreted as int64 (sums stay far below 2^63)."""
+    uint64 counts are reinterpreted as int64 (sums stay far below 2^63).
+    ``device``: GPU index for the staging tensor under nccl (default: torch's current device -- pass the
+    context's device when the caller may not have called ``torch.cuda.set_device``)."""
     d = _dist()
     if d is None:
         return x
@@ -69,7 +71,7 @@ def all_reduce_sum(x, group=None):
         t = torch.from_numpy(np.ascontiguousarray(x.view(np.int64) if was_u64 else x).copy())
         backend = d.get_backend(group)
         if backend == "nccl":
-            t = t.cuda()
+            t = t.cuda(device)
         d.all_reduce(t, op=d.ReduceOp.SUM, group=group)
         out = t.cpu().numpy()
         return out.view(np.uint64) if was_u64 else out
@@ -77,19 +79,19 @@ def all_reduce_sum(x, group=None):
     return x
 
 
-def all_reduce_min(value, group=None):
+def all_reduce_min(value, group=None, device=None):
     d = _dist()
     if d is None:
         return value
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64)
     if d.get_backend(group) == "nccl":
-        t = t.cuda()
+        t = t.cuda(device)
     d.all_reduce(t, op=d.ReduceOp.MIN, group=group)
     return float(t.cpu()[0])
 
 
-def all_gather_rows(x, group=None):
+def all_gather_rows(x, group=None, device=None):
     """Concatenate per-rank row blocks (numpy 2-D, possibly different row
     counts) in rank order."""
     d = _dist()
@@ -100,7 +102,7 @@ def all_gather_rows(x, group=None):
         # two tensor all-gathers over RCCL (row counts, then the blocks padded to the largest count) instead of
         # pickled objects
         import torch
-        n = torch.tensor([x.shape[0]], dtype=torch.int64).cuda()
+        n = torch.tensor([x.shape[0]], dtype=torch.int64).cuda(device)
         counts = torch.empty(world, dtype=torch.int64, device=n.device)
         d.all_gather_into_tensor(counts, n, group=group)
         counts = counts.cpu().numpy()
@@ -108,7 +110,7 @@ def all_gather_rows(x, group=None):
         cols = int(np.prod(x.shape[1:]))
         mine = torch.zeros((rows, cols), dtype=torch.int64)
         mine[:x.shape[0]] = torch.from_numpy(np.ascontiguousarray(x).view(np.int64).reshape(x.shape[0], cols))
-        mine = mine.cuda()
+        mine = mine.cuda(device)
         full = torch.empty((world * rows, cols), dtype=torch.int64, device=mine.device)
         d.all_gather_into_tensor(full, mine, group=group)
         full = full.cpu().numpy().reshape(world, rows, cols)

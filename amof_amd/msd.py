@@ -148,7 +148,7 @@ class WindowMsd(Msd):
         sumsq, kinds = ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
                                       atom_range=atom_range)
         if merge and distributed != 'local':
-            sumsq = _dist.all_reduce_sum(sumsq)
+            sumsq = _dist.all_reduce_sum(sumsq, device=ctx.device)
         self.sumsq = sumsq
         idx = {z: k for k, z in enumerate(kinds)}
 

@@ -85,11 +85,13 @@ class Rdf(object):
         N_species = len(atomic_numbers_unique)
         rank, world = (0, 1) if distributed is False else _dist.world()
         merge = distributed is not False and _dist.merging(world)
+        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        ctx = _hip.get_context(dev)
 
         # min over ALL frames of the three cell lengths, halved (amof/rdf.py:74)
         rmax_half_cell = np.min(packed.cell_lengths()) / 2
         if distributed == 'local' and merge:
-            rmax_half_cell = _dist.all_reduce_min(rmax_half_cell)
+            rmax_half_cell = _dist.all_reduce_min(rmax_half_cell, device=ctx.device)
         if isinstance(rmax, str) and rmax == 'half_cell':
             rmax = rmax_half_cell
         elif rmax > rmax_half_cell:
@@ -109,8 +111,6 @@ class Rdf(object):
             frame_range = _dist.shard_range(F_local, rank, world)
         else:
             frame_range = (0, F_local)
-        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
-        ctx = _hip.get_context(dev)
         n_frames = frame_range[1] - frame_range[0]
         if merge and _dist.device_collectives():
             # the histogram stays in HBM from the kernels through the RCCL all-reduce (amof_rdf_accumulate_dev)
@@ -127,8 +127,8 @@ class Rdf(object):
         else:
             hist, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range)
             if merge:
-                hist = _dist.all_reduce_sum(hist)
-                tot = _dist.all_reduce_sum(np.array([vol_sum, float(n_frames)]))
+                hist = _dist.all_reduce_sum(hist, device=ctx.device)
+                tot = _dist.all_reduce_sum(np.array([vol_sum, float(n_frames)]), device=ctx.device)
                 vol_sum, n_frames = float(tot[0]), int(round(tot[1]))
         self.hist = hist                      # integer ordered-pair counts [S][S][bins]
         self.kinds = kinds
