@@ -61,11 +61,19 @@ struct amof_ctx {
     std::string err;
     const char *last_path = "";   // kernel family of the last dominant launch (static strings)
     amof::DevBuf buf[amof::SLOT_COUNT];
+    // pinned staging ring for the small per-call tables (tile lists, geometry records, work lists ...): a pageable
+    // hipMemcpyAsync blocks the host ~40 us per table; from pinned memory it is queued in ~5 us.  The ring is reused
+    // from the start after every synchronisation of the context's stream (sync_stream): nothing queued before a
+    // synchronisation still reads it.
+    unsigned char *pin = nullptr;
+    size_t pin_cap = 0, pin_off = 0;
 };
 
 namespace amof {
 
 int fail(amof_ctx *ctx, int code, const char *fmt, ...);
+// hipStreamSynchronize(ctx->stream) + reuse of the pinned staging ring
+hipError_t sync_stream(amof_ctx *ctx);
 int ensure(amof_ctx *ctx, Slot s, size_t bytes, void **out);
 
 #define AMOF_HIP_TRY(ctx, expr)                                                              \
@@ -212,7 +220,7 @@ int launch_cell_sort(amof_ctx *ctx, const double *pos_dev, const double *d_geom,
 constexpr int CELL_LDS_MAX = 16384;
 int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                           const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q,
-                          uint32_t *d_start3, int32_t *d_flag);
+                          uint32_t *d_start3, int32_t *d_flag, int64_t max_species_atoms);
 
 void timing_begin(amof_ctx *ctx);
 void timing_end(amof_ctx *ctx);

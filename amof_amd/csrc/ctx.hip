@@ -28,7 +28,7 @@ int ensure(amof_ctx *ctx, Slot s, size_t bytes, void **out)
     if (b.cap < bytes) {
         if (b.p) {
             // the buffer may still be in use by work queued on the stream
-            AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            AMOF_HIP_TRY(ctx, sync_stream(ctx));
             AMOF_HIP_TRY(ctx, hipFree(b.p));
             b.p = nullptr;
             b.cap = 0;
@@ -45,10 +45,27 @@ int ensure(amof_ctx *ctx, Slot s, size_t bytes, void **out)
     return AMOF_OK;
 }
 
+hipError_t sync_stream(amof_ctx *ctx)
+{
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    ctx->pin_off = 0;      // every copy queued from the staging ring has run
+    return e;
+}
+
 int upload(amof_ctx *ctx, Slot s, const void *src, size_t bytes, void **out)
 {
     AMOF_TRY(ensure(ctx, s, bytes, out));
-    if (bytes) AMOF_HIP_TRY(ctx, hipMemcpyAsync(*out, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!bytes) return AMOF_OK;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (ctx->pin && need <= ctx->pin_cap - ctx->pin_off) {
+        // small table: through the pinned ring (the caller's buffer is free at once, the copy is truly asynchronous)
+        unsigned char *stage = ctx->pin + ctx->pin_off;
+        memcpy(stage, src, bytes);
+        ctx->pin_off += need;
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(*out, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return AMOF_OK;
+    }
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(*out, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     // pageable-host copies return once the source has been consumed
     return AMOF_OK;
 }
@@ -315,6 +332,13 @@ int amof_ctx_create(int device, amof_ctx **out)
         amof_ctx_destroy(ctx);
         return AMOF_EHIP;
     }
+    // (without the ring uploads fall back to pageable copies: slower, still correct)
+    ctx->pin_cap = (size_t)4 << 20;
+    if (hipHostMalloc((void **)&ctx->pin, ctx->pin_cap, hipHostMallocDefault) != hipSuccess) {
+        ctx->pin = nullptr;
+        ctx->pin_cap = 0;
+        (void)hipGetLastError();
+    }
     if (hipEventCreate(&ctx->ev_all0) != hipSuccess || hipEventCreate(&ctx->ev_all1) != hipSuccess ||
         hipEventCreate(&ctx->ev_dom0) != hipSuccess || hipEventCreate(&ctx->ev_dom1) != hipSuccess) {
         amof_ctx_destroy(ctx);
@@ -338,6 +362,7 @@ void amof_ctx_destroy(amof_ctx *ctx)
     if (ctx->ev_dom1) (void)hipEventDestroy(ctx->ev_dom1);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -366,7 +391,7 @@ int amof_ctx_synchronize(amof_ctx *ctx)
 {
     if (!ctx) return AMOF_EINVAL;
     AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
 

@@ -942,7 +942,7 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_end(ctx);
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(sumsq, d_out, (size_t)S * W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
 
@@ -984,6 +984,6 @@ extern "C" int amof_msd_direct(amof_ctx *ctx, const amof_traj *t, double *msd)
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_end(ctx);
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(msd, d_out, (size_t)F * (S + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }

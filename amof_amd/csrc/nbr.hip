@@ -366,8 +366,7 @@ __device__ __forceinline__ void nbr_ranges(const uint32_t *__restrict__ st /* [Q
 
 // Cell-list neighbour search of one centre atom (lane): the 27 cells around its own, as 9 rows (dz, dy) of the
 // x-run cx-1 .. cx+1 (two index ranges when the run wraps), inside partner species sb's segment of the sorted
-// frame.  All 18 range bounds are loaded before any partner is gathered (dependent L2 round trips otherwise); the
-// pair test is the fast path's: f32 distance of the wrapped fixed-point differences, pairs inside the guard band
+// frame.  The pair test is the fast path's: f32 distance of the wrapped fixed-point differences, pairs inside the guard band
 // re-decided by the canonical float64 arithmetic.  found(atom index) is called for every neighbour.
 template <bool ORTHO, typename F>
 __device__ __forceinline__ void cell_neighbours(const NbrFastArgs &fa, const QAtom *__restrict__ Qf,
@@ -386,33 +385,39 @@ __device__ __forceinline__ void cell_neighbours(const NbrFastArgs &fa, const QAt
     int xa0 = cx - 1, xb0 = cx + 1, xa1 = 0, xb1 = -1;
     if (xa0 < 0) { xa0 = nx - 1; xb0 = nx - 1; xa1 = 0; xb1 = cx + 1; }
     else if (xb0 >= nx) { xb0 = nx - 1; xa1 = 0; xb1 = 0; }
-    int lo[18], hi[18];
-#pragma unroll
-    for (int row = 0; row < 9; row++) {
-        int cz2 = cz + row / 3 - 1, cy2 = cy + row % 3 - 1;
+    // one plane of cells (dz) at a time: its six range bounds are loaded before any of its partners is gathered
+    // (dependent L2 round trips otherwise); all 18 at once cost 36 live registers and a third of the occupancy
+#pragma unroll 1
+    for (int dz = -1; dz <= 1; dz++) {
+        int cz2 = cz + dz;
         cz2 += cz2 < 0 ? nz : 0; cz2 -= cz2 >= nz ? nz : 0;
-        cy2 += cy2 < 0 ? ny : 0; cy2 -= cy2 >= ny ? ny : 0;
-        const int rowbase = (cz2 * ny + cy2) * nx;
-        lo[2 * row] = has ? (int)sts[rowbase + xa0] : 0;
-        hi[2 * row] = has ? (int)sts[rowbase + xb0 + 1] : 0;
-        lo[2 * row + 1] = has && xa1 <= xb1 ? (int)sts[rowbase + xa1] : 0;
-        hi[2 * row + 1] = has && xa1 <= xb1 ? (int)sts[rowbase + xb1 + 1] : 0;
-    }
+        int lo[6], hi[6];
 #pragma unroll
-    for (int r = 0; r < 18; r++) {
-        for (int j = lo[r]; j < hi[r]; j += 2) {
-            // two partners per trip, both gathered before either is tested
-            const uint4 q0 = *reinterpret_cast<const uint4 *>(Qf + j);
-            const uint4 q1 = *reinterpret_cast<const uint4 *>(Qf + min(j + 1, hi[r] - 1));
+        for (int k = 0; k < 3; k++) {
+            int cy2 = cy + k - 1;
+            cy2 += cy2 < 0 ? ny : 0; cy2 -= cy2 >= ny ? ny : 0;
+            const int rowbase = (cz2 * ny + cy2) * nx;
+            lo[2 * k] = has ? (int)sts[rowbase + xa0] : 0;
+            hi[2 * k] = has ? (int)sts[rowbase + xb0 + 1] : 0;
+            lo[2 * k + 1] = has && xa1 <= xb1 ? (int)sts[rowbase + xa1] : 0;
+            hi[2 * k + 1] = has && xa1 <= xb1 ? (int)sts[rowbase + xb1 + 1] : 0;
+        }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint4 qj = u == 0 ? q0 : q1;
-                const uint32_t idx_j = qj.w & NBR_IDX_MASK;
-                if (j + u >= hi[r] || idx_j == own_idx) continue;       // (no zero-shift self pair)
-                const float d = nbr_fast_dist<ORTHO>(sc, qc.ux, qc.uy, qc.uz, qj);
-                bool nbr = d < r_in;
-                if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, own_idx, idx_j, rc);
-                if (nbr) found(idx_j);
+        for (int r = 0; r < 6; r++) {
+            for (int j = lo[r]; j < hi[r]; j += 2) {
+                // two partners per trip, both gathered before either is tested
+                const uint4 q0 = *reinterpret_cast<const uint4 *>(Qf + j);
+                const uint4 q1 = *reinterpret_cast<const uint4 *>(Qf + min(j + 1, hi[r] - 1));
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint4 qj = u == 0 ? q0 : q1;
+                    const uint32_t idx_j = qj.w & NBR_IDX_MASK;
+                    if (j + u >= hi[r] || idx_j == own_idx) continue;       // (no zero-shift self pair)
+                    const float d = nbr_fast_dist<ORTHO>(sc, qc.ux, qc.uy, qc.uz, qj);
+                    bool nbr = d < r_in;
+                    if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, own_idx, idx_j, rc);
+                    if (nbr) found(idx_j);
+                }
             }
         }
     }
@@ -517,6 +522,7 @@ __device__ __forceinline__ bool unit_vec(double x, double y, double z, double &u
 //   2a  entries (centre c, neighbour slot u), all centres of the tile: gather the two positions once, canonical
 //       minimum-image vector, unit vector -> LDS;
 //   2b  every entry forms its angles with the later entries of the same centre from LDS -- no global loads.
+// Tiles whose centres hold more neighbours than the LDS table (NBRF_UVCAP entries) go through it in groups of centres.
 // Same arithmetic per angle as before (ase get_angles order), so the counts still equal the oracle's bit for bit.
 template <bool ORTHO, bool CELL = false>
 __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
@@ -620,15 +626,17 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
             }
         }
         n = has ? min(n, NBRF_NLIST) : 0;
-        // entries before each centre: exclusive scan over the workgroup of the neighbour counts of the centres that
-        // form angles at all (a centre with a single neighbour -- every N of ZIF-4 -- contributes nothing)
+        // a centre with a single neighbour -- every N of ZIF-4 -- forms no angle: only centres with >= 2 enter
         const int n_ent = n >= 2 ? n : 0;
+        // (barrier: the previous frame's angle phase has finished with pref / uv / ec)  no angle in this tile and
+        // frame -- e.g. a tile of N centres -- : next frame
+        if (!__syncthreads_or(n_ent > 0)) continue;
+        // entries before each centre: exclusive scan of n_ent over the workgroup
         int incl = n_ent;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off, 64);
             if (lane >= off) incl += t;
         }
-        __syncthreads();                       // the previous frame's angle phase has finished with pref / uv / ec
         if (lane == 63) s_wtot[wave] = incl;
         s_cidx[tid] = own_idx;
         __syncthreads();
@@ -637,17 +645,27 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
         pref[tid] = before + incl - n_ent;
         if (tid == NBRF_TILE - 1) pref[NBRF_TILE] = before + incl;
         __syncthreads();
-        const int total = pref[NBRF_TILE];
-        if (total <= NBRF_UVCAP) {
+        // centres in groups whose entries fit the LDS table (one group unless the tile holds > NBRF_UVCAP neighbours;
+        // a centre has at most NBRF_NLIST <= NBRF_UVCAP entries, so every group makes progress)
+        for (int c_begin = 0; c_begin < NBRF_TILE;) {
+            const int base = pref[c_begin];
+            int lo_c = c_begin, hi_c = NBRF_TILE + 1;     // largest c_end in (c_begin, TILE] with pref[c_end] - base <= UVCAP
+            while (hi_c - lo_c > 1) {
+                const int mid = (lo_c + hi_c) >> 1;
+                if (pref[mid] - base <= NBRF_UVCAP) lo_c = mid;
+                else hi_c = mid;
+            }
+            const int c_end = max(lo_c, c_begin + 1);
+            const int total = pref[c_end] - base;
             // 2a: one unit vector per (centre, neighbour slot)
             for (int e = tid; e < total; e += NBRF_TILE) {
-                int lo = 0, hi = NBRF_TILE;    // largest c with pref[c] <= e  (pref[NBRF_TILE] = total > e)
+                int lo = c_begin, hi = c_end;    // largest c in [c_begin, c_end) with pref[c] <= base + e
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if (pref[mid] <= e) lo = mid;
+                    if (pref[mid] <= base + e) lo = mid;
                     else hi = mid;
                 }
-                const int c = lo, u = e - pref[c];
+                const int c = lo, u = base + e - pref[c];
                 const double *pn = p + (size_t)nlist[u * NBRF_TILE + c] * 3, *pc = p + (size_t)s_cidx[c] * 3;
                 double vx, vy, vz, ax = 0.0, ay = 0.0, az = 0.0;
                 pair_base<ORTHO>(geo, pn[0] - pc[0], pn[1] - pc[1], pn[2] - pc[2], vx, vy, vz);
@@ -658,27 +676,12 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
             __syncthreads();
             // 2b: entry e = (c, u) with every later entry (c, v > u) of the same centre
             for (int e = tid; e < total; e += NBRF_TILE) {
-                const int c = ec[e], e_end = pref[c + 1], n_c = e_end - pref[c];
+                const int c = ec[e], e_end = pref[c + 1] - base, n_c = pref[c + 1] - pref[c];
                 const double ax = uvx[e], ay = uvy[e], az = uvz[e];
                 for (int ev = e + 1; ev < e_end; ev++) count_angle(ax, ay, az, uvx[ev], uvy[ev], uvz[ev], n_c);
             }
-        } else if (has && n >= 2) {
-            // more neighbours in this tile than the LDS table holds: per-centre loops straight from global memory
-            const double *pc = p + (size_t)own_idx * 3;
-            const double cx = pc[0], cy = pc[1], cz = pc[2];
-            for (int u = 0; u < n - 1; u++) {
-                const double *pu = p + (size_t)nlist[u * NBRF_TILE + tid] * 3;
-                double vx, vy, vz, ax, ay, az;
-                pair_base<ORTHO>(geo, pu[0] - cx, pu[1] - cy, pu[2] - cz, vx, vy, vz);
-                if (!unit_vec(vx, vy, vz, ax, ay, az)) { a.flags[0] = 1; continue; }
-                for (int v = u + 1; v < n; v++) {
-                    const double *pv = p + (size_t)nlist[v * NBRF_TILE + tid] * 3;
-                    double wx, wy, wz, bx, by, bz;
-                    pair_base<ORTHO>(geo, pv[0] - cx, pv[1] - cy, pv[2] - cz, wx, wy, wz);
-                    if (!unit_vec(wx, wy, wz, bx, by, bz)) { a.flags[0] = 1; continue; }
-                    count_angle(ax, ay, az, bx, by, bz, n);
-                }
-            }
+            c_begin = c_end;
+            if (c_begin < NBRF_TILE) __syncthreads();      // the next group overwrites the table
         }
     }
     __syncthreads();
@@ -790,7 +793,8 @@ static int nbr_fast_batch(amof_ctx *ctx, const amof_traj *t, NbrSetup &st, NbrFa
     if (nf.cell)
         AMOF_TRY(launch_quantize_cells(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst,
                                        t->n_species, t->n_atoms, (int)fb, (int)nfr, nf.nk[0], nf.nk[1], nf.nk[2],
-                                       (QAtom *)nf.d_Q, (uint32_t *)nf.d_start3, (int32_t *)nf.d_qflag));
+                                       (QAtom *)nf.d_Q, (uint32_t *)nf.d_start3, (int32_t *)nf.d_qflag,
+                                       *std::max_element(st.tiles.nsp.begin(), st.tiles.nsp.end())));
     else
         AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, t->n_species,
                                  t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
@@ -995,7 +999,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         timing_dom_end(ctx, launches);
         int32_t qflag = 0;
         AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nf.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
-        AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        AMOF_HIP_TRY(ctx, sync_stream(ctx));
         if (qflag) {   // atoms absurdly far from the cell: redo with the exact kernel
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_sums, 0, F * n_sets * sizeof(int64_t), ctx->stream));
         } else {
@@ -1020,7 +1024,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(sums, d_sums, F * n_sets * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     if (per_atom)
         AMOF_HIP_TRY(ctx, hipMemcpyAsync(per_atom, d_pa, F * n_sets * N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
 
@@ -1063,7 +1067,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
     a.n_angles = (unsigned long long *)d_ns;
     auto read_flags = [&](int32_t (&fl)[4]) -> int {
         AMOF_HIP_TRY(ctx, hipMemcpyAsync(fl, d_flags, sizeof fl, hipMemcpyDeviceToHost, ctx->stream));
-        AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        AMOF_HIP_TRY(ctx, sync_stream(ctx));
         return AMOF_OK;
     };
     auto clear_scratch = [&]() -> int {
@@ -1202,7 +1206,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         AMOF_HIP_TRY(ctx, hipGetLastError());
     }
     timing_end(ctx);
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
 
@@ -1247,7 +1251,7 @@ extern "C" int amof_bad_hist(amof_ctx *ctx, const amof_traj *t, const double *cu
     if (rc) return rc;
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, hb, hipMemcpyDeviceToHost, ctx->stream));
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(n_angles, d_nang, nbts, hipMemcpyDeviceToHost, ctx->stream));
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
 
@@ -1269,6 +1273,6 @@ extern "C" int amof_bad_hist_by_cn(amof_ctx *ctx, const amof_traj *t, const doub
     if (rc) return rc;
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, hb, hipMemcpyDeviceToHost, ctx->stream));
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(n_angles, d_nang, nbts, hipMemcpyDeviceToHost, ctx->stream));
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }

@@ -333,14 +333,16 @@ int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom,
 
 int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                           const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q,
-                          uint32_t *d_start3, int32_t *d_flag)
+                          uint32_t *d_start3, int32_t *d_flag, int64_t max_species_atoms)
 {
     if (nf <= 0 || S <= 0) return AMOF_OK;
     if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
     const int64_t ncell = (int64_t)nx * ny * nz;
     if (nx < 1 || ny < 1 || nz < 1 || ncell > CELL_LDS_MAX || N >= (1ll << CELL_SPECIES_SHIFT) || S > 64)
         return fail(ctx, AMOF_EINVAL, "bad cell grid");
-    const int cache_cap = (int)std::min<int64_t>(N, 4608);
+    // LDS record cache sized for the largest species segment (up to 4608 records = 72 KiB): with the cell counters
+    // beside it, a tight cache is what lets two workgroups share a CU
+    const int cache_cap = (int)std::min<int64_t>(std::max<int64_t>(max_species_atoms, 1), 4608);
     const size_t lds = (size_t)cache_cap * sizeof(QAtom) + (size_t)ncell * sizeof(unsigned);
     AMOF_HIP_TRY(ctx, allow_max_lds((const void *)quantize_cells_kernel));
     hipLaunchKernelGGL(quantize_cells_kernel, dim3((unsigned)S, (unsigned)nf), dim3(QUANT_THREADS), lds, ctx->stream, pos_dev,

@@ -1238,7 +1238,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     timing_dom_end(ctx, launches);
                     int32_t flag3 = 0;
                     AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag3, d_flag3, sizeof flag3, hipMemcpyDeviceToHost, ctx->stream));
-                    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    AMOF_HIP_TRY(ctx, sync_stream(ctx));
                     if (flag3) AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));   // far-away atoms: exact kernels
                     else done = true;
                     cell_taken = true;    // (either done, or the exact kernels take over)
@@ -1337,7 +1337,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 timing_dom_end(ctx, launches);
                 int32_t flag2 = 0;
                 AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag2, d_flag2, sizeof flag2, hipMemcpyDeviceToHost, ctx->stream));
-                AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                AMOF_HIP_TRY(ctx, sync_stream(ctx));
                 if (flag2) AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));
                 else done = true;
             }
@@ -1416,7 +1416,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             timing_dom_end(ctx, launches);
             int32_t flag = 0;
             AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
-            AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            AMOF_HIP_TRY(ctx, sync_stream(ctx));
             if (flag) {
                 // some atom lies > 1e4 cells away from the origin: redo with the exact kernel
                 AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));
@@ -1465,7 +1465,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
     }
     timing_end(ctx);
     // host metadata above lives on this stack frame: finish before returning
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     if (volume_sum) *volume_sum += geom.volume_sum;
     return AMOF_OK;
 }
@@ -1502,6 +1502,6 @@ extern "C" int amof_rdf_accumulate(amof_ctx *ctx, const amof_traj *traj, double 
     AMOF_TRY(upload(ctx, SLOT_OUT0, hist, bytes, &d_hist));
     AMOF_TRY(rdf_run(ctx, traj, rmax, nbins, (unsigned long long *)d_hist, volume_sum));
     AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
