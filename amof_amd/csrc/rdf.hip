@@ -1376,11 +1376,12 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                                          nullptr, (int32_t *)d_flag));
                 fa.f_base = (int32_t)fb;
                 fa.nf = (int32_t)nf;
-                // frames per workgroup chunk: ~150k workgroups per launch (1280 run at a time: > 100 rounds, so that
-                // ramp-up and drain stay around 1 %), between 2 and 16 frames -- fewer frames flush the LDS histogram
-                // too often, more do not fit the 4 MiB L2 of an XCD.  Measured on cfg3 (profiles/r02/rdf_fpc_sweep.txt):
-                // 5000 frames 87.28 (16) -> 86.84 ms (8); a 625-frame shard 11.33 (10) -> 11.08 ms (2).
-                int64_t fpc = (nf * (int64_t)fpairs.size() + 75000) / 150000;
+                // frames per workgroup chunk: ~80k workgroups per launch (1280 run at a time: > 60 rounds, so that
+                // ramp-up and drain stay around 1-2 %), between 2 and 16 frames -- fewer frames flush the LDS histogram
+                // more often (u64 global atomics: HBM-side write traffic), more do not fit the 4 MiB L2 of an XCD.
+                // Measured on cfg3 (profiles/r02/rdf_fpc_sweep.txt): a 625-frame shard 11.33 (10 frames) -> 11.08 ms (2);
+                // 5000 frames stay at 16 (8 would be 0.5 % faster for 38 % more traffic).
+                int64_t fpc = (nf * (int64_t)fpairs.size() + 40000) / 80000;
                 fpc = std::max<int64_t>(2, std::min<int64_t>(fpc, 16));
                 if (const char *fpc_env = getenv("AMOF_RDF_FPC")) fpc = std::max(1, atoi(fpc_env));     // experiments
                 fpc = std::min<int64_t>(fpc, std::max<int64_t>(1, nf));

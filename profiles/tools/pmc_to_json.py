@@ -34,7 +34,14 @@ def short(name):
 
 def load(workload):
     acc = defaultdict(lambda: defaultdict(list))
-    for path in glob.glob(os.path.join(src, workload + "_g*", "**", "*counter_collection.csv"), recursive=True):
+    for gdir in sorted(glob.glob(os.path.join(src, workload + "_g*"))):
+        if not os.path.isdir(gdir):
+            continue
+        # (a directory merged from several collections holds one CSV per run: the newest one counts)
+        csvs = glob.glob(os.path.join(gdir, "**", "*counter_collection.csv"), recursive=True)
+        if not csvs:
+            continue
+        path = max(csvs, key=os.path.getmtime)
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 name = row.get("Kernel_Name", "")

@@ -4,7 +4,7 @@ The bench's numbers come from 9792-atom frames in launches of hundreds to thousa
 mapping, heavy-first tile-pair order and equal XCD shares of ``rdf_tile_kernel_fast`` are only live there, and so is
 the ``msd_comb_kernel<28>`` bucket at F = 5000, W = 25.  These tests tie exactly those launches to the oracle:
 
-* RDF: a 544-frame device-resident launch (2 frames per chunk, 272 chunks, xcd_map on) against the C oracle on frames
+* RDF: a 544-frame device-resident launch (2 frames per chunk, 272 chunks, xcd_map on; the bench's 5000 frames run 16 per chunk) against the C oracle on frames
   sampled from different XCD shares -- by leave-one-out (H[0,F) - H[0,k) - H[k+1,F) is frame k's histogram as the
   BIG launches saw it) and as the sum of 16-frame blocks (which take the unmapped geometry);
 * MSD: F = 5000, delta_time = 100 on all 9792 atoms against the numpy restatement on a 272-atom slice;
