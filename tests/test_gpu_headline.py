@@ -74,6 +74,13 @@ def test_rdf_at_bench_geometry_vs_oracle(hip_ctx, traj544):
             rest += hip_ctx.rdf_accumulate(packed, rmax, nb, frame_range=(k + 1, F))[0]
         assert np.array_equal(full - rest, h_cpu), "leave-one-out differs from the oracle at frame %d" % k
 
+    # the bench's 5000-frame launches run 16 frames per chunk (34 -> 40 chunks here): same histogram
+    os.environ["AMOF_RDF_FPC"] = "16"
+    try:
+        full16, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+    finally:
+        del os.environ["AMOF_RDF_FPC"]
+    assert np.array_equal(full16, full)
     # checksum of checksums: blocks of 16 frames (34 launches without the XCD mapping) add up to the big launch
     acc = np.zeros_like(full)
     for f0 in range(0, F, 16):
