@@ -422,6 +422,132 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_db_kernel(const double *
     }
 }
 
+// Streaming form of the comb arithmetic for window spacings d of 64 .. 256 frames (WindowMsd's default is 100).
+// One thread owns one residue class r of the column and walks its comb x_e = u[r + d e], e = 0, 1, ...: the last L
+// entries live in a register ring, every new entry forms its L pairs (lags 1 .. L) against them -- one LDS read per
+// L terms, no lane masks in the steady state (the block form above spends 45 % of its vector instructions on masks,
+// addresses and scalar-register spills: PMC, profiles/r02/pmc_msd.json), every thread the same amount of work.
+// Workgroup = roundup64(d) threads and ONE column buffer (F doubles): four workgroups per CU overlap each other's
+// column load, scan and arithmetic.  The time origin k = 0 (r = 0, e = 0) is left out as in the reference
+// (amof/msd.py:200); lags beyond W - 1 are computed and dropped.
+template <int T>
+__device__ __forceinline__ void lds_scan_t(double *u, int F, double *wtot)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chunk = ((F + T - 1) / T) | 1;        // odd: strided LDS accesses of a wave spread over the banks
+    const int k0 = min(tid * chunk, F), k1 = min(k0 + chunk, F);
+    double s = 0.0;
+    for (int k = k0; k < k1; k++) s += u[k];
+    double v = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        double n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    __syncthreads();
+    if (lane == 63) wtot[wv] = v;
+    __syncthreads();
+    double run = v - s;
+    for (int q = 0; q < wv; q++) run += wtot[q];
+    for (int k = k0; k < k1; k++) {
+        run += u[k];
+        u[k] = run;
+    }
+    __syncthreads();
+}
+
+// one block of L comb entries (e = e0 .. e0 + L - 1; ring slot of entry e is e mod L, e0 a multiple of L).
+// BLK = 0: the block that starts the comb (e0 = 0): entry e only has e predecessors; BLK = 1: the second block
+// (e0 = L); BLK = 2: any later one.  A pair with entry 0 -- (0, s) in the first block, (0, L) at the start of the
+// second -- carries the factor m0 (0 for the residue class that holds the time origin).  GUARD: entries >= nq do not exist.
+template <int L, int BLK, bool GUARD>
+__device__ __forceinline__ void stream_block(const double *__restrict__ ub, int d, int e0, int nq, double m0,
+                                             double (&ring)[L], double (&acc)[L + 1])
+{
+#pragma unroll
+    for (int s = 0; s < L; s++) {
+        if (!GUARD || e0 + s < nq) {
+            const double x = ub[(size_t)d * (e0 + s)];
+#pragma unroll
+            for (int w = 1; w <= L; w++) {
+                if (!(BLK == 0 && w > s)) {                     // (compile time)
+                    const double dd = x - ring[(s - w + 4 * L) % L];
+                    const bool with_origin = (BLK == 0 && w == s) || (BLK == 1 && s == 0 && w == L);
+                    acc[w] = fma(with_origin ? dd * m0 : dd, dd, acc[w]);
+                }
+            }
+            ring[s] = x;
+        }
+    }
+}
+
+template <int L, int T>
+__global__ __launch_bounds__(T) void msd_stream_kernel(const double *__restrict__ DT, int64_t Fp, int F,
+                                                       const int32_t *__restrict__ perm,
+                                                       const MsdGroup *__restrict__ groups, int d, int W, int Wstride,
+                                                       double *__restrict__ partial)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *u = reinterpret_cast<double *>(lds_raw);  // [Fp]
+    __shared__ double red[T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const MsdGroup gr = groups[blockIdx.x];
+    const int ncol = 3 * gr.count;
+    const int ngran = (int)(Fp / 2);                   // 16-byte granules per column
+    const bool active = tid < d;                       // thread = residue class
+    const int r = active ? tid : 0;
+    const int nq = active ? (F - r + d - 1) / d : 0;   // entries of this thread's comb
+    const int nq_min = F / d;                          // every comb has at least this many
+    const double m0 = r == 0 ? 0.0 : 1.0;
+    double acc[L + 1], ring[L];
+#pragma unroll
+    for (int w = 0; w <= L; w++) acc[w] = 0.0;
+    // (measured and rejected: the next column prefetched through 40 registers per thread while this one is combed --
+    //  253 VGPRs, one wave per SIMD, 0.63 instead of 0.55 ms)
+    for (int c = 0; c < ncol; c++) {
+        const int64_t atom = perm[gr.start + c / 3];
+        const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
+        __syncthreads();                               // the previous column is fully consumed
+        for (int blk = wave; blk * 64 < ngran; blk += T / 64) {
+            const int gran = blk * 64 + lane;
+            if (gran < ngran) dma16(col + 2 * gran, reinterpret_cast<unsigned char *>(u) + (size_t)blk * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        lds_scan_t<T>(u, F, red);
+        if (active) {
+            const double *__restrict__ ub = u + r;
+#pragma unroll
+            for (int k = 0; k < L; k++) ring[k] = 0.0;
+            int e0 = 0;
+            if (nq_min >= 2 * L) {
+                stream_block<L, 0, false>(ub, d, 0, nq, m0, ring, acc);
+                stream_block<L, 1, false>(ub, d, L, nq, m0, ring, acc);
+                for (e0 = 2 * L; e0 + L <= nq_min; e0 += L) stream_block<L, 2, false>(ub, d, e0, nq, m0, ring, acc);
+                for (; e0 < nq; e0 += L) stream_block<L, 2, true>(ub, d, e0, nq, m0, ring, acc);
+            } else {
+                stream_block<L, 0, true>(ub, d, 0, nq, m0, ring, acc);
+                if (L < nq) stream_block<L, 1, true>(ub, d, L, nq, m0, ring, acc);
+                for (e0 = 2 * L; e0 < nq; e0 += L) stream_block<L, 2, true>(ub, d, e0, nq, m0, ring, acc);
+            }
+        }
+    }
+    // fixed order: lanes by shuffles, waves in sequence (deterministic)
+#pragma unroll
+    for (int w = 1; w <= L; w++) {
+        double v = acc[w];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (tid == 0 && w < W) {
+            double tot = 0.0;
+            for (int q = 0; q < T / 64; q++) tot += red[q];
+            partial[(size_t)blockIdx.x * Wstride + w] = tot;
+        }
+    }
+    if (tid == 0) partial[(size_t)blockIdx.x * Wstride] = 0.0;      // lag 0
+}
+
 // Further passes for W > 32: windows w0 .. w0 + Wn - 1 (Wn <= WT).  A task holds its COMB_B base
 // entries and the COMB_B + WT - 1 partner entries that start w0 comb steps later.
 template <int WT>
@@ -889,7 +1015,27 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         };
         ctx->last_path = comb_d > 0 ? "msd_comb" : "msd_group";
         hipError_t e;
-        if (comb_d > 0 && W <= 4) e = launch_comb(msd_comb_kernel<4>, msd_comb_db_kernel<4>);
+        // streaming comb kernel: one thread per residue class (window spacing 64 .. 256 frames, <= 32 windows)
+        const bool stream = comb_d >= 64 && comb_d <= 256 && W <= 32 && (size_t)Fp * sizeof(double) <= 150 * 1024 &&
+                            !getenv("AMOF_MSD_NOSTREAM");
+        const int streamT = comb_d <= 128 ? 128 : 256;
+        auto launch_stream = [&](auto kern) -> hipError_t {
+            hipError_t e2 = allow_max_lds((const void *)kern);
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(streamT), (size_t)Fp * sizeof(double), ctx->stream,
+                               (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
+                               comb_d, (int)W, (int)W, (double *)d_part);
+            ctx->last_path = "msd_stream";
+            return hipGetLastError();
+        };
+#define AMOF_STREAM(L) (streamT == 128 ? launch_stream(msd_stream_kernel<L, 128>) : launch_stream(msd_stream_kernel<L, 256>))
+        if (stream && W <= 8) e = AMOF_STREAM(7);
+        else if (stream && W <= 16) e = AMOF_STREAM(15);
+        else if (stream && W <= 24) e = AMOF_STREAM(23);
+        else if (stream && W <= 25) e = AMOF_STREAM(24);
+        else if (stream) e = AMOF_STREAM(31);
+#undef AMOF_STREAM
+        else if (comb_d > 0 && W <= 4) e = launch_comb(msd_comb_kernel<4>, msd_comb_db_kernel<4>);
         else if (comb_d > 0 && W <= 8) e = launch_comb(msd_comb_kernel<8>, msd_comb_db_kernel<8>);
         else if (comb_d > 0 && W <= 12) e = launch_comb(msd_comb_kernel<12>, msd_comb_db_kernel<12>);
         else if (comb_d > 0 && W <= 16) e = launch_comb(msd_comb_kernel<16>, msd_comb_db_kernel<16>);

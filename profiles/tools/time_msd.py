@@ -19,6 +19,7 @@ torch.cuda.synchronize()
 ctx = _hip.get_context(0)
 window = np.arange(0, F // 2, 100).astype(np.int32)
 os.environ["AMOF_MSD_NODB"] = "1"
+os.environ["AMOF_MSD_NOSTREAM"] = "1"
 ref, _ = ctx.msd_window(packed, window)
 print("variant                     pipeline   comb    rest (ms)   max rel dev vs single buffer")
 for nodb in ("1", ""):
@@ -34,6 +35,14 @@ for nodb in ("1", ""):
         dev = float(np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-300)))
         print("%-25s %8.3f %8.3f %8.3f   %.2e  %s" % ("single" if nodb else "double-buffered", 1e3 * best[0],
                                                             1e3 * best[1], 1e3 * (best[0] - best[1]), dev, ctx.last_path()))
+os.environ.pop("AMOF_MSD_NOSTREAM", None)
+best = (1e9, 0)
+for _ in range(4):
+    out, _ = ctx.msd_window(packed, window)
+    best = min(best, (ctx.last_kernel_seconds(False), ctx.last_kernel_seconds(True)))
+dev = float(np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-300)))
+print("%-25s %8.3f %8.3f %8.3f   %.2e  %s" % ("streaming", 1e3 * best[0], 1e3 * best[1], 1e3 * (best[0] - best[1]), dev,
+                                            ctx.last_path()))
 # atom-sharded: one eighth of the atoms
 for n in (1, 2, 4, 8):
     best = 1e9

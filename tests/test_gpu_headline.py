@@ -151,7 +151,7 @@ def test_msd_headline_shape_vs_numpy_on_atom_slice(hip_ctx):
     # one contiguous atom range holding every species (the first replica of the 272-atom cell)
     a0, a1 = 0, 272
     sumsq, k2 = hip_ctx.msd_window(packed, window, atom_range=(a0, a1))
-    assert hip_ctx.last_path() == "msd_comb"
+    assert hip_ctx.last_path() == "msd_stream"      # window spacing 100: one thread per residue class
     pos_h = packed.pos.cpu().numpy()
     mask = np.zeros(N, dtype=bool)
     mask[a0:a1] = True

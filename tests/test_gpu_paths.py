@@ -296,7 +296,11 @@ def test_rdf_pipelined_host_staging(hip_ctx):
 
 @pytest.mark.parametrize("F,d,W", [(7, 1, 3), (50, 3, 16), (333, 7, 24), (333, 11, 25), (1000, 100, 5), (1000, 31, 32),
                                    (257, 13, 12), (90, 100, 1), (64, 2, 29), (1201, 50, 21),
-                                   (333, 3, 40), (1000, 7, 64), (2000, 9, 100), (700, 5, 33), (900, 11, 70)])
+                                   (333, 3, 40), (1000, 7, 64), (2000, 9, 100), (700, 5, 33), (900, 11, 70),
+                                   # window spacings of 64 .. 256 frames: the streaming kernel (one thread per residue
+                                   # class; whole blocks, ragged comb ends, combs shorter than one block, 128 / 256 threads)
+                                   (5000, 100, 25), (3000, 64, 20), (2000, 128, 12), (2600, 129, 9), (4100, 256, 8),
+                                   (999, 77, 13), (1530, 100, 15), (4999, 100, 32), (650, 65, 10), (3333, 90, 24)])
 def test_msd_comb_kernel_equals_generic_and_oracle(hip_ctx, F, d, W):
     # windows w*d: the comb kernel (every template bucket, ragged comb ends, F < d, the skipped origin)
     # against the generic LDS kernel and the numpy restatement
@@ -309,7 +313,13 @@ def test_msd_comb_kernel_equals_generic_and_oracle(hip_ctx, F, d, W):
     packed = PackedTrajectory((s - np.floor(s)) @ cell, cell, [1, 1, 1, 1, 8, 8, 30, 30, 30])
     window = np.array([w * d for w in range(W) if w * d < F], dtype=np.int32)
     comb, kinds = hip_ctx.msd_window(packed, window)
-    assert hip_ctx.last_path() == ("msd_comb" if len(window) >= 2 else "msd_group")
+    streams = 64 <= d <= 256 and 2 <= len(window) <= 32
+    assert hip_ctx.last_path() == ("msd_stream" if streams else ("msd_comb" if len(window) >= 2 else "msd_group"))
+    if streams:
+        with _env(AMOF_MSD_NOSTREAM="1"):
+            blockform, _ = hip_ctx.msd_window(packed, window)
+            assert hip_ctx.last_path() == "msd_comb"
+        np.testing.assert_allclose(comb, blockform, rtol=1e-12, atol=1e-12)
     with _env(AMOF_MSD_NOCOMB="1"):
         generic, _ = hip_ctx.msd_window(packed, window)
         assert hip_ctx.last_path() == "msd_group"
