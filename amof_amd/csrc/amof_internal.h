@@ -158,6 +158,22 @@ inline double fast_guard_rel(const HostGeom &g, int64_t n_cells, bool sq_scaled 
     return 1.1 * (5.0 * kappa + 3.06) * u;
 }
 
+// ZF form of the diagonal-cell tile kernel (rdf.hip fast_q_zf): the slab-axis difference is the difference of two f32
+// coordinates in bins, Z_j' = fl(c (z_j - z0)), Z_i' = fl(c (z_i - z0)), one rounding each (f64 product -> f32):
+//   |dz - Z| <= A + u |Z|,  A = u (|Z_j'| + |Z_i'|) <= u Hb (G / 2^32 + 1/16 + 1/256)
+// (Hb = slab-axis height in bins, G the culling reach, sub-tile span < 2^28, slab widening 2^24; 1/128 taken).
+// With zeta = Z^2 / T:  |t - T| <= u T (7 - 4 zeta) + 2 |Z| A (x, y terms as in the sq_scaled chain: 7u; the z term:
+// subtraction, product, final fma: 3u), so  |q~ - q| <= u q (3.5 - 2 zeta + 1.56) + A sqrt(zeta); over zeta in [0, 1] and
+// q <= qmax = nbins + 1, with a = A / (u qmax):  <= u qmax (5.06 + a^2 / 8)  (a <= 4; else 3.06 + a).  10 % margin on both.
+// Returns the bound in bins (without the fixed-point grid term g_m).
+inline double fast_guard_zf(int nbins, double hb, double gfrac)
+{
+    const double u = 1.0 / 16777216.0, qmax = (double)nbins + 1.0;
+    const double a = hb * (gfrac + 1.0 / 16 + 1.0 / 128) / qmax;
+    const double extra = a <= 4.0 ? a * a / 8.0 : a - 2.0;
+    return 1.1 * u * qmax * (3.5 + extra + 1.56);
+}
+
 // species-sorted tiling of the atoms
 struct Tile {
     int32_t start;    // offset into perm

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "amof_internal.h"
@@ -219,6 +220,8 @@ struct RdfFastArgs {
     float half_m_guard;      // 1/2 - g_f rounded DOWN (g_f in bins: the f32 candidate's error bound)
     float nb_hi;             // nbins + g_f rounded UP
     double guard64;          // g_m (bins): f64-from-fixed-point candidate
+    double guard64_2;        // 2 g_m (1 + 1e-9), g_m^2 (1 + 1e-9): level 2 decides on T - e^2 against +-(2 e g_m + g_m^2)
+    double guard64_sq;
     int32_t xcd_map;         // 1: chunk -> XCD affinity mapping of the grid
     int32_t n_chunks;        // tile kernel: frames [c nf / n_chunks, (c+1) nf / n_chunks) belong to chunk c
     int32_t img_queue;       // IMG variant: capacity of one parking buffer
@@ -229,6 +232,12 @@ struct RdfFastArgs {
 constexpr int FAST_THREADS = 256;
 constexpr int IMG_QUEUE_MAX = 1024; // IMG variant: parked near-face pairs per step and buffer (capacity chosen by the host)
 constexpr int FAST_TILE = 512;      // two centre atoms per thread
+
+// a wave-uniform double, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // candidate bin coordinate q~ = |r_j - r_i| / dr from the fixed-point fractional coordinates
 template <bool ORTHO>
@@ -247,6 +256,17 @@ __device__ __forceinline__ float fast_q(const float *sc, int ix, int iy, int iz)
         t = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     }
     return __builtin_amdgcn_sqrtf(t);
+}
+
+// ZF form (diagonal cell, slab-culled tile pairs): the slab-axis difference needs no per-pair wrap -- the partners a
+// step visits lie within reach of the centre sub-tile's slab range -- so it arrives as the difference dz of two f32
+// values already in units of bins (partner and centre relative to the sub-tile's slab midpoint, one rounding each):
+// v_sub_f32 + v_fmac_f32 instead of v_sub_u32 + v_cvt_f32_i32 + v_mul_f32 + v_fmac_f32.  Error bound: fast_guard_zf.
+__device__ __forceinline__ float fast_q_zf(const float *sc, int ix, int iy, float dz)
+{
+    const float fx = (float)ix, fy = (float)iy;
+    const float x2 = fx * fx, y2 = fy * fy;
+    return __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(y2, sc[4], x2 * sc[3])));
 }
 
 // squared candidate coordinate (bins^2) in f64 from the fixed-point differences
@@ -271,26 +291,37 @@ __device__ __forceinline__ double medium_t(const double *sc, int ix, int iy, int
 // only): T >= (e+g_m)^2 -> bin e, T < (e-g_m)^2 -> bin e-1 (bin nbins = out of
 // range).  Level 3 (|q - e| <= g_m, or coincident atoms): canonical arithmetic
 // on the original float64 positions with exact sqrt and divide.
-template <bool ORTHO>
+// (ZF kernels keep the partner's f32 slab coordinate in qj.w: the atom index then comes from the quantised frame, qseg[j])
+// PROV: the fast path has already counted the pair in its candidate bin (int)q (always-add scheme): take that back.
+template <bool ORTHO, bool ZF = false, bool PROV = false>
 __device__ __forceinline__ void rdf_pair_refine(unsigned *hist, const RdfFastArgs &fa,
-                                                const FrameScale *__restrict__ fs, const double *__restrict__ g,
+                                                const double *sc64, const double *__restrict__ g,
                                                 float q, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj,
-                                                const double *__restrict__ p, uint32_t idx_i)
+                                                const double *__restrict__ p, uint32_t idx_i,
+                                                const QAtom *__restrict__ qseg = nullptr, int j = 0)
 {
     const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
-    const double T = medium_t<ORTHO>(fs->sc64, ix, iy, iz);
+    const double T = medium_t<ORTHO>(sc64, ix, iy, iz);
     const float ef = rintf(q);
-    const double e = (double)ef, gm = fa.guard64;
-    const double hi = (e + gm) * (e + gm), lo = (e - gm) * (e - gm);
+    const double e = (double)ef;
+    // T >= (e + g_m)^2  <=>  D = T - e^2 >= 2 e g_m + g_m^2 =: band (D is exact: e^2 is an integer below 2^24 and T
+    // - e^2 fits the significand); T < (e - g_m)^2 is implied by D < -band (stricter by 2 g_m^2: a few more level-3 pairs)
+    const double D = fma(-e, e, T), band = fma(e, fa.guard64_2, fa.guard64_sq);
     const int ei = (int)ef;
     int b = -1;
-    if (T >= hi) b = ei;
-    else if (T < lo && ei > 0) b = ei - 1;
+    if (D >= band) b = ei;
+    else if (D < -band && ei > 0) b = ei - 1;
+    if (PROV) {
+        const int cand = (int)q;                       // (q < nbins + 1/2 here: never clamped)
+        if (b == cand) return;                         // the provisional count was right
+        atomicAdd(&hist[cand], 0xffffffffu);           // (u32 counters wrap; the sum is what is flushed)
+    }
     if (b >= 0) {
         if (b < fa.a.nbins) atomicAdd(&hist[b], 1u);
         return;
     }
-    const double *pi = p + (size_t)idx_i * 3, *pj = p + (size_t)qj.w * 3;
+    const uint32_t idx_j = ZF ? qseg[j].idx : qj.w;
+    const double *pi = p + (size_t)idx_i * 3, *pj = p + (size_t)idx_j * 3;
     double dx, dy, dz;
     pair_base<ORTHO>(g, pj[0] - pi[0], pj[1] - pi[1], pj[2] - pi[2], dx, dy, dz);
     rdf_count(hist, norm2(dx, dy, dz), fa.a.rmax2, fa.a.dr, fa.a.nbins);
@@ -320,12 +351,28 @@ __device__ __forceinline__ void rdf_pair_images(unsigned *hist, const RdfFastArg
 // within reach of a cell face (|i_k| > near_t[k]) can have a second image in range or an ambiguous base image --
 // they are not touched here (near = true) and are evaluated canonically, images included; for every other pair the
 // base image is unambiguous and the only one that can be in range.
-template <bool ORTHO, bool IMG = false>
+template <bool ORTHO, bool IMG = false, bool ZF = false>
 __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool live, float half_m_guard,
                                          float nb_hi, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj,
-                                         float &q, const uint32_t *near_t = nullptr, bool *near = nullptr)
+                                         float &q, const uint32_t *near_t = nullptr, bool *near = nullptr,
+                                         float zif = 0.0f, float clampv = 0.0f, bool live_all = false)
 {
     const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
+    if (ZF) {
+        // Always add, fix up later: one LDS atomic costs the CU's LDS pipe the same whatever the number of active
+        // lanes (profiles/r02/ubench_lds_atomic.txt), so nothing is gained by masking -- and the masks (two compares,
+        // five scalar instructions and a skip branch per pair) were what the loop waited for.  Every lane adds to the
+        // candidate bin of min(q, clampv): clampv = nbins + 1/2 + (lane mod 32) sends out-of-range (and dead) pairs to
+        // 32 trash words behind the histogram with a "safe" fractional part, so that `unsafe` is exactly "in range
+        // and within the guard of a bin edge"; such a pair has been counted provisionally and rdf_pair_refine<PROV>
+        // takes that count back before it adds the exact one.
+        q = fast_q_zf(sc, ix, iy, __uint_as_float(qj.w) - zif);
+        if (!live_all) q = live ? q : __builtin_inff();
+        q = __builtin_fminf(q, clampv);
+        const bool unsafe = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
+        atomicAdd(&hist[(int)q], 1u);
+        return unsafe;
+    }
     if (IMG) {
         // (axes that are clear of their half height carry the sentinel and are skipped: wave-uniform branches)
         bool nr = false;
@@ -342,16 +389,20 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
     return in && !safe;
 }
 
-template <bool ORTHO, bool DIAG, bool TAIL, bool IMG = false>
-__device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const FrameScale *__restrict__ fs,
+template <bool ORTHO, bool DIAG, bool TAIL, bool IMG = false, bool ZF = false, bool ZFK = false>
+__device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const double *sc64,
                                           const double *__restrict__ g, const float *sc, const uint4 *tq,
                                           int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
                                           float half_m_guard, float nb_hi, uint32_t uax, uint32_t uay,
                                           uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
                                           uint32_t idb, const double *__restrict__ p,
                                           const uint32_t *near_t = nullptr, int gi = 0, uint2 *nq = nullptr,
-                                          unsigned *nq_count = nullptr, unsigned nq_cap = 0)
+                                          unsigned *nq_count = nullptr, unsigned nq_cap = 0,
+                                          float zaf = 0.0f, float zbf = 0.0f, const QAtom *__restrict__ qseg = nullptr,
+                                          float clampv = 0.0f)
 {
+    // ZF: this step uses the f32 slab coordinates; ZFK: the kernel is a ZF kernel (the .w of the LDS copies may have
+    // been overwritten by an earlier step of the frame: atom indices always come from the quantised frame)
     // four partner atoms per trip, read by broadcast before any LDS atomic
     uint4 qj[4];
 #pragma unroll
@@ -365,15 +416,18 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
         const bool la = has_a && (!TAIL || j < cntj) && (!DIAG || j > ia);
         const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
         bool ma = false, mb = false;
-        na[u] = fast_bin<ORTHO, IMG>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u], near_t, &ma);
-        nb[u] = fast_bin<ORTHO, IMG>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u], near_t, &mb);
+        // (ZF: centres that do not exist carry an infinite slab coordinate, so only DIAG / TAIL need a live mask)
+        na[u] = fast_bin<ORTHO, IMG, ZF>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u], near_t, &ma, zaf,
+                                         clampv, !DIAG && !TAIL);
+        nb[u] = fast_bin<ORTHO, IMG, ZF>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u], near_t, &mb, zbf,
+                                         clampv, !DIAG && !TAIL);
         anynear |= ma | mb;
     }
     if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {   // a few % of the pairs
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (na[u]) rdf_pair_refine<ORTHO>(hist, fa, fs, g, qa[u], uax, uay, uaz, qj[u], p, ida);
-            if (nb[u]) rdf_pair_refine<ORTHO>(hist, fa, fs, g, qb[u], ubx, uby, ubz, qj[u], p, idb);
+            if (na[u]) rdf_pair_refine<ORTHO, ZFK, ZF>(hist, fa, sc64, g, qa[u], uax, uay, uaz, qj[u], p, ida, qseg, j0 + u);
+            if (nb[u]) rdf_pair_refine<ORTHO, ZFK, ZF>(hist, fa, sc64, g, qb[u], ubx, uby, ubz, qj[u], p, idb, qseg, j0 + u);
         }
     }
     if (IMG) {
@@ -415,9 +469,10 @@ __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
     dma16(src_lane, dst_wave);
 }
 
-template <bool ORTHO, bool CULL, bool IMG = false>
+template <bool ORTHO, bool CULL, bool IMG = false, bool ZFK = false>
 __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
+    static_assert(!ZFK || (ORTHO && CULL && !IMG), "f32 slab coordinates: diagonal cells, slab culling, no image queue");
     const RdfArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // double-buffered tiles: J (512 entries) and the centre sub-tile (128 entries)
@@ -431,7 +486,8 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const unsigned nq_cap = (unsigned)fa.img_queue;
     __shared__ unsigned nq_count[3];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: the quad loops below count in SGPRs)
     // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8), each
     // with its own 4 MiB L2.  All work items of one frame chunk go to the same XCD so that the
     // chunk's quantised frames (16 frames x 16 B x N) are re-read from that L2, not from the
@@ -464,6 +520,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const int la = 2 * lane, lb = la + 1;                          // local indices in the sub-tile
     const float half_m_guard = fa.half_m_guard;
     const float nb_hi = fa.nb_hi;
+    const float clampv = (float)nbins + 0.5f + (float)(lane & 31);   // ZF kernels: see fast_bin (32 trash words behind hist)
     const int cntj = tj.count;
     const int cntj4 = (cntj + 3) & ~3;
     const int full = cntj & ~3;
@@ -507,6 +564,14 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
 #pragma unroll
         for (int k = 0; k < 9; k++)
             sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
+        // the f64 scales of the level-2 refinement: diagonal cells keep their three in scalar registers (a vector load
+        // at the head of every refinement visit costs a memory latency each time)
+        double sc64r[3] = {0.0, 0.0, 0.0};
+        if (ORTHO) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) sc64r[k] = uniform_f64(fs->sc64[k]);
+        }
+        const double *sc64 = ORTHO ? sc64r : fs->sc64;
         uint32_t near_t[3] = {0x7fffffffu, 0x7fffffffu, 0x7fffffffu};
         if (IMG) {
 #pragma unroll
@@ -543,6 +608,8 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         // the partners within reach of the centre atoms (slab distance <= cull_gap, circular)
         // form at most two contiguous index ranges, found once per frame.
         int rb0 = diag ? (sub * FAST_SUB) : 0, re0 = cntj, rb1 = 0, re1 = 0;
+        bool zf = false;          // this step runs on f32 slab coordinates (ZF kernels)
+        uint32_t z0 = 0u;         // their origin: the middle of the centre sub-tile's slab range
         if (CULL) {
             // the sub-tile is slab-sorted: its first / last atoms give its slab range
             const uint32_t s_first = tc[0].z >> 24, s_last = tc[cnti - 1].z >> 24;
@@ -572,34 +639,74 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                     re0 = b_;
                     rb1 = max(rb0, a_); re1 = cntj;
                 }                          // else the two pieces touch: whole tile
+                if (ZFK) {
+                    // f32 slab coordinates are valid when no slab difference of a partner inside the reach window and a
+                    // centre can wrap: |z_j - z0| <= G + W/2 + 2^24 + 1, |z_i - z0| <= W/2 + 1, their difference below
+                    // 2^31 in magnitude -- then it IS the minimum image.  A partner outside the window (quads are
+                    // visited whole) comes out beyond G either way round, i.e. out of range.  W < 2^28 is the span
+                    // the host's error bound (fast_guard_zf) assumes.
+                    const uint32_t W = whi - wlo;
+                    zf = W < (1u << 28) && (unsigned long long)G + W + (2ull << 24) < (1ull << 31);
+                    z0 = wlo + (W >> 1);
+                }
             }
         }
-#pragma unroll 1
+        // quad ranges of the two pieces: [qb_r, qe_r), quads dealt round-robin to the four waves
+        int qbr[2], qer[2];
+#pragma unroll
         for (int r = 0; r < 2; r++) {
             const int rb = r == 0 ? rb0 : rb1, re = r == 0 ? re0 : re1;
-            if (re <= rb) continue;
-            int qb = rb & ~3;
-            const int qe = (re + 3) & ~3;
-            if (r == 1) qb = max(qb, (max(re0, rb0) + 3) & ~3);   // never visit a quad twice
-            const int qe_full = min(qe, full);
-            // quads are dealt round-robin to the four waves
-            if (diag) {
-                for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
-                    fast_quad<ORTHO, true, true, IMG>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
-                                                      nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p, near_t, gi, nq,
-                                                      &nq_count[step % 3], nq_cap);
-            } else {
-                int j0 = qb + 4 * wave;
-                for (; j0 < qe_full; j0 += 16)
-                    fast_quad<ORTHO, false, false, IMG>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
-                                                        half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p,
-                                                        near_t, gi, nq, &nq_count[step % 3], nq_cap);
-                if (j0 == full && j0 < qe && full < cntj)
-                    fast_quad<ORTHO, false, true, IMG>(hist, fa, fs, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
-                                                       half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz, idb, p,
-                                                       near_t, gi, nq, &nq_count[step % 3], nq_cap);
-            }
+            qbr[r] = rb & ~3;
+            qer[r] = re <= rb ? 0 : (re + 3) & ~3;
+            if (r == 1) qbr[r] = max(qbr[r], (max(re0, rb0) + 3) & ~3);   // never visit a quad twice
         }
+        float zaf = 0.0f, zbf = 0.0f;
+        if (ZFK && zf) {
+            // each wave converts the slab coordinate of the partners it is about to meet (its own quads of both
+            // pieces) into bins relative to z0, one rounding (f64 product -> f32), and parks it in the LDS copy's
+            // .w; centre atoms likewise, in registers.  Wave-local: LDS operations of a wave execute in order.
+            const double cz = sc64[2];
+            uint4 *tqw = tqb + jb * FAST_TILE;
+#pragma unroll 1
+            for (int r = 0; r < 2; r++) {
+                for (int j = qbr[r] + 4 * wave + 16 * (lane >> 2) + (lane & 3); j < qer[r]; j += 256)
+                    tqw[j].w = __float_as_uint((float)((double)(int)(tqw[j].z - z0) * cz));
+            }
+            zaf = has_a ? (float)((double)(int)(uaz - z0) * cz) : __builtin_inff();
+            zbf = has_b ? (float)((double)(int)(ubz - z0) * cz) : __builtin_inff();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const QAtom *__restrict__ qseg = fa.Q + (size_t)fl * (size_t)a.N + tj.start;
+        auto run = [&](auto zf_tag) {
+            constexpr bool ZF = decltype(zf_tag)::value;
+#pragma unroll 1
+            for (int r = 0; r < 2; r++) {
+                const int qb = qbr[r], qe = qer[r];
+                if (qe <= qb) continue;
+                const int qe_full = min(qe, full);
+                if (diag) {
+                    for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
+                        fast_quad<ORTHO, true, true, IMG, ZF, ZFK>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
+                                                                   half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
+                                                                   idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap, zaf,
+                                                                   zbf, qseg, clampv);
+                } else {
+                    int j0 = qb + 4 * wave;
+                    for (; j0 < qe_full; j0 += 16)
+                        fast_quad<ORTHO, false, false, IMG, ZF, ZFK>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
+                                                                     half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
+                                                                     idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap,
+                                                                     zaf, zbf, qseg, clampv);
+                    if (j0 == full && j0 < qe && full < cntj)
+                        fast_quad<ORTHO, false, true, IMG, ZF, ZFK>(hist, fa, sc64, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
+                                                                    half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
+                                                                    idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap, zaf,
+                                                                    zbf, qseg, clampv);
+                }
+            }
+        };
+        if (ZFK && zf) run(std::true_type{});
+        else run(std::false_type{});
         if (IMG && !fa.img_defer) {
             // large shares: dense canonical pass over this step's parked pairs right away (one more barrier per step)
             __syncthreads();
@@ -735,7 +842,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_range_kernel_fast(RdfRang
                     const int ia = tha == -1 ? -1 : (tha == 0x7fffffff ? 0x7fffffff : tha - base);
                     const int ib = thb == -1 ? -1 : (thb == 0x7fffffff ? 0x7fffffff : thb - base);
                     for (int j0 = 4 * wave; j0 < cntj4; j0 += 16)
-                        fast_quad<ORTHO, true, true>(hist, fa, fs, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                        fast_quad<ORTHO, true, true>(hist, fa, fs->sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
                                                      nb_hi, ca.ux, ca.uy, ca.uz, ca.idx, cb.ux, cb.uy, cb.uz, cb.idx, p);
                 }
             }
@@ -870,7 +977,7 @@ __global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs c
                                 if (fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard) {
                                     atomicAdd(&h[(int)q], 1u);
                                 } else {
-                                    rdf_pair_refine<ORTHO>(h, fa, fs, g, q, own.ux, own.uy, own.uz,
+                                    rdf_pair_refine<ORTHO>(h, fa, fs->sc64, g, q, own.ux, own.uy, own.uz,
                                                            make_uint4(qj.x, qj.y, qj.z, qj.w & CELL_IDX_MASK), p, ida);
                                 }
                             }
@@ -1131,6 +1238,28 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.half_m_guard = fhalf;
             }
             fa.guard64 = guard_m;
+            fa.guard64_2 = 2.0 * guard_m * (1.0 + 1e-9);
+            fa.guard64_sq = guard_m * guard_m * (1.0 + 1e-9);
+            // Diagonal cells with slab culling: the tile kernel takes the slab-axis difference from f32 coordinates
+            // (ZF, see fast_q_zf); its candidate carries one more absolute term, hence its own (slightly wider) guard.
+            const char *nozf = getenv("AMOF_RDF_NOZF");
+            bool use_zf = fast && !fast_img && ortho && cull && !(nozf && nozf[0] == '1');
+            float zf_nb_hi = fa.nb_hi, zf_half_m_guard = fa.half_m_guard;
+            if (use_zf) {
+                double hb = 0.0, gfrac = 0.0;
+                for (int64_t k = 0; k < nc; k++) {
+                    hb = std::max(hb, geom.rec[(size_t)k * GEOM_STRIDE + 18 + axis] / dr);
+                    gfrac = std::max(gfrac, (double)fsv[(size_t)k].cull_gap / 4294967296.0);
+                }
+                const double guard_zf = fast_guard_zf(nbins, hb, gfrac) + guard_m;
+                if (!(guard_zf < 0.25)) use_zf = false;
+                const double hi = (double)nbins + guard_zf, half = 0.5 - guard_zf;
+                float fhi = (float)hi, fhalf = (float)half;
+                if ((double)fhi < hi) fhi = nextafterf(fhi, INFINITY);
+                if ((double)fhalf > half) fhalf = nextafterf(fhalf, -INFINITY);
+                zf_nb_hi = fhi;
+                zf_half_m_guard = fhalf;
+            }
             // ---- 3-D cell list for cutoffs far below the cell size (cell kernel) ----
             bool cell_taken = false;
             {
@@ -1405,6 +1534,16 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     else if (ortho) e = launch(rdf_tile_kernel_fast<true, false, true>);
                     else if (cull) e = launch(rdf_tile_kernel_fast<false, true, true>);
                     else e = launch(rdf_tile_kernel_fast<false, false, true>);
+                }
+                else if (use_zf) {
+                    RdfFastArgs fz = fa;
+                    fz.nb_hi = zf_nb_hi;
+                    fz.half_m_guard = zf_half_m_guard;
+                    hipError_t e2 = allow_max_lds((const void *)rdf_tile_kernel_fast<true, true, false, true>);
+                    if (e2 == hipSuccess)     // (+ 32 trash words behind the histogram: always-add scheme)
+                        hipLaunchKernelGGL((rdf_tile_kernel_fast<true, true, false, true>), grid, dim3(FAST_THREADS),
+                                           lds + 32 * sizeof(unsigned), ctx->stream, fz);
+                    e = e2;
                 }
                 else if (ortho && cull) e = launch(rdf_tile_kernel_fast<true, true>);
                 else if (ortho) e = launch(rdf_tile_kernel_fast<true, false>);
