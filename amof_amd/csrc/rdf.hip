@@ -1521,7 +1521,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.a.frames_per_chunk = (int32_t)fpc;
                 fa.n_chunks = (int32_t)chunks;
                 dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
-                if (launches == 0) timing_dom_begin(ctx, fast_img ? "rdf_tile_img" : "rdf_tile");
+                if (launches == 0) timing_dom_begin(ctx, fast_img ? "rdf_tile_img" : use_zf ? "rdf_tile_zf" : "rdf_tile");
                 auto launch = [&](auto kern) -> hipError_t {
                     hipError_t e2 = allow_max_lds((const void *)kern);
                     if (e2 != hipSuccess) return e2;

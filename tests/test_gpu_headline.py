@@ -51,7 +51,7 @@ def test_rdf_at_bench_geometry_vs_oracle(hip_ctx, traj544):
     assert nb == 2310
     kinds, sp = H.species_of(packed.numbers)
     full, vol, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-    assert hip_ctx.last_path() == "rdf_tile"
+    assert hip_ctx.last_path() == "rdf_tile_zf"     # diagonal cell, slab culling: f32 slab coordinates, always-add histogram
     assert hip_ctx.last_kernel_launches() == 1
     # ordered-pair histograms are symmetric; every frame contributes the same number of pairs only statistically,
     # but the volume sum is exact

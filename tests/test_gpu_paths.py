@@ -46,7 +46,13 @@ def test_rdf_fast_equals_exact_equals_oracle(hip_ctx, kind):
     packed, rmax, nb = _traj(kind)
     with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
         fast, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-        assert hip_ctx.last_path() == "rdf_tile"
+        # diagonal cell + slab culling: the variant with f32 slab coordinates and the always-add histogram
+        assert hip_ctx.last_path() == ("rdf_tile_zf" if kind == "elongated" else "rdf_tile")
+        if kind == "elongated":
+            with _env(AMOF_RDF_NOZF="1"):
+                nozf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+                assert hip_ctx.last_path() == "rdf_tile"
+            assert np.array_equal(fast, nozf)
         with _env(AMOF_RDF_NOCULL="1"):
             nocull, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
             assert hip_ctx.last_path() == "rdf_tile"
@@ -255,7 +261,7 @@ def test_rdf_range_kernel_two_level_cell_list(hip_ctx, tri):
             assert hip_ctx.last_path() == "rdf_range"
         with _env(AMOF_RDF_NORANGE="1", AMOF_RDF_NOCELL="1"):
             slab, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() == "rdf_tile"
+            assert hip_ctx.last_path() in ("rdf_tile", "rdf_tile_zf")
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
         assert np.array_equal(got, ref) and np.array_equal(slab, ref)
     # exactly three slabs (nz = 3): the forward-slab rule must not double count across the wrap
@@ -381,7 +387,7 @@ def test_rdf_cell_kernel_three_level_cell_list(hip_ctx, kind):
             assert hip_ctx.last_path() == "rdf_cell"
         with _env(AMOF_RDF_NOCELL="1"):
             other, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() in ("rdf_tile", "rdf_range")
+            assert hip_ctx.last_path() in ("rdf_tile", "rdf_tile_zf", "rdf_range")
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
         assert np.array_equal(got, ref), (kind, rmax, nb, int(got.sum()), int(ref.sum()))
         assert np.array_equal(other, ref)
@@ -432,8 +438,60 @@ def test_rdf_image_aware_variant_on_a_plain_case(hip_ctx):
     packed = H.random_walk(H.replicate(H.zif4_frame(), (2, 1, 2)), 3, 0.05, 98, ortho=True)
     with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
         plain, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, 700)
-        assert hip_ctx.last_path() == "rdf_tile"
+        assert hip_ctx.last_path() in ("rdf_tile", "rdf_tile_zf")
         with _env(AMOF_RDF_FORCE_IMG="1"):
             img, _, _ = hip_ctx.rdf_accumulate(packed, 7.0, 700)
             assert hip_ctx.last_path() == "rdf_tile_img"
     assert np.array_equal(plain, img)
+
+
+def _zf_vs_oracle(hip_ctx, packed, rmax, nb):
+    kinds, sp = H.species_of(packed.numbers)
+    with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
+        zf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        assert hip_ctx.last_path() == "rdf_tile_zf"
+        with _env(AMOF_RDF_NOZF="1"):
+            plain, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_tile"
+    ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
+    assert np.array_equal(plain, ref)
+    assert np.array_equal(zf, ref), (rmax, nb, int(zf.sum()), int(ref.sum()), int(np.abs(zf.astype(np.int64) - ref).sum()))
+
+
+def test_rdf_zf_lattice_pairs_on_bin_edges(hip_ctx):
+    # the variant with f32 slab coordinates (diagonal cell, slab culling live): a perfect lattice in a long box puts
+    # every distance on a bin edge, i.e. every in-range pair takes the provisional count + fix-up route
+    a, n = 2.0, (6, 6, 18)
+    pos = np.array([[x, y, z] for x in range(n[0]) for y in range(n[1]) for z in range(n[2])], dtype=float) * a
+    numbers = np.where(np.arange(len(pos)) % 5 == 0, 30, np.where(np.arange(len(pos)) % 2 == 0, 7, 6))
+    cell = np.diag([n[0] * a, n[1] * a, n[2] * a])
+    packed = PackedTrajectory(np.stack([pos, pos + 0.25, pos - 31.0]), cell, numbers)
+    for rmax, nb in [(5.9, 59), (6.0, 600), (6.0, 6), (5.999, 2310)]:
+        _zf_vs_oracle(hip_ctx, packed, rmax, nb)
+
+
+def test_rdf_zf_uneven_slabs_and_rare_species(hip_ctx):
+    # atoms bunched into a few thin layers along the long axis plus a rare species spread over all of it: centre
+    # sub-tiles of the rare species span more than 1/16 of the axis (those steps fall back to the integer slab
+    # differences inside the same launch), bunched ones sit in a single slab; coincident atoms included
+    rng = np.random.default_rng(77)
+    L = np.array([14.0, 15.0, 48.0])
+    N = 2600
+    z = np.concatenate([rng.normal(c, 0.4, 600) for c in (3.0, 11.0, 30.0, 41.0)])
+    z = np.concatenate([z, rng.uniform(0, L[2], N - len(z))])
+    xy = rng.uniform(0, 1, (N, 2)) * L[:2]
+    pos = np.column_stack([xy, z])
+    pos[7] = pos[3]                                   # two atoms on top of each other
+    numbers = np.where(np.arange(N) >= 2400, 30, np.where(np.arange(N) % 2 == 0, 6, 1))
+    frames = np.stack([pos, pos + rng.normal(0, 0.05, pos.shape), pos + np.array([0.0, 0.0, 24.0])])
+    packed = PackedTrajectory(frames, np.diag(L), numbers)
+    for rmax, nb in [(7.0, 700), (6.5, 2310), (3.0, 50)]:
+        _zf_vs_oracle(hip_ctx, packed, rmax, nb)
+
+
+def test_rdf_zf_changing_diagonal_cells(hip_ctx):
+    # NPT-like: a different diagonal cell per frame (per-frame scales, reach and guards)
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (1, 2, 4)), 5, 0.06, 91, cell_jitter=0.02, ortho=True)
+    assert packed.cell.shape[0] == 5
+    rmax = float(np.min(packed.cell_lengths()) / 2)
+    _zf_vs_oracle(hip_ctx, packed, rmax, int(rmax // 0.01))
