@@ -232,6 +232,7 @@ struct RdfFastArgs {
 constexpr int FAST_THREADS = 256;
 constexpr int IMG_QUEUE_MAX = 1024; // IMG variant: parked near-face pairs per step and buffer (capacity chosen by the host)
 constexpr int FAST_TILE = 512;      // two centre atoms per thread
+constexpr int FAST_TRASH = 32;      // tile kernel: words behind the LDS histogram that take the out-of-range pairs (fast_bin<AA>)
 
 // a wave-uniform double, moved to scalar registers
 __device__ __forceinline__ double uniform_f64(double v)
@@ -351,28 +352,13 @@ __device__ __forceinline__ void rdf_pair_images(unsigned *hist, const RdfFastArg
 // within reach of a cell face (|i_k| > near_t[k]) can have a second image in range or an ambiguous base image --
 // they are not touched here (near = true) and are evaluated canonically, images included; for every other pair the
 // base image is unambiguous and the only one that can be in range.
-template <bool ORTHO, bool IMG = false, bool ZF = false>
+template <bool ORTHO, bool IMG = false, bool ZF = false, bool AA = false>
 __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool live, float half_m_guard,
                                          float nb_hi, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj,
                                          float &q, const uint32_t *near_t = nullptr, bool *near = nullptr,
                                          float zif = 0.0f, float clampv = 0.0f, bool live_all = false)
 {
     const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
-    if (ZF) {
-        // Always add, fix up later: one LDS atomic costs the CU's LDS pipe the same whatever the number of active
-        // lanes (profiles/r02/ubench_lds_atomic.txt), so nothing is gained by masking -- and the masks (two compares,
-        // five scalar instructions and a skip branch per pair) were what the loop waited for.  Every lane adds to the
-        // candidate bin of min(q, clampv): clampv = nbins + 1/2 + (lane mod 32) sends out-of-range (and dead) pairs to
-        // 32 trash words behind the histogram with a "safe" fractional part, so that `unsafe` is exactly "in range
-        // and within the guard of a bin edge"; such a pair has been counted provisionally and rdf_pair_refine<PROV>
-        // takes that count back before it adds the exact one.
-        q = fast_q_zf(sc, ix, iy, __uint_as_float(qj.w) - zif);
-        if (!live_all) q = live ? q : __builtin_inff();
-        q = __builtin_fminf(q, clampv);
-        const bool unsafe = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
-        atomicAdd(&hist[(int)q], 1u);
-        return unsafe;
-    }
     if (IMG) {
         // (axes that are clear of their half height carry the sentinel and are skipped: wave-uniform branches)
         bool nr = false;
@@ -382,14 +368,28 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
         *near = live && nr;
         live = live && !nr;
     }
-    q = fast_q<ORTHO>(sc, ix, iy, iz);
+    q = ZF ? fast_q_zf(sc, ix, iy, __uint_as_float(qj.w) - zif) : fast_q<ORTHO>(sc, ix, iy, iz);
+    if (AA) {
+        // Always add, fix up later (tile kernel): one LDS atomic costs the CU's LDS pipe the same whatever the number
+        // of active lanes (profiles/r02/ubench_lds_atomic.txt), so nothing is gained by masking -- and the masks (two
+        // compares, five scalar instructions and a skip branch per pair) were what the loop waited for.  Every lane
+        // adds to the candidate bin of min(q, clampv): clampv = nbins + 1/2 + (lane mod 32) sends out-of-range (and
+        // dead: q = inf) pairs to 32 trash words behind the histogram with a "safe" fractional part, so that `unsafe`
+        // is exactly "in range and within the guard of a bin edge"; such a pair has been counted provisionally and
+        // rdf_pair_refine<PROV> takes that count back before it adds the exact one.
+        if (!live_all) q = live ? q : __builtin_inff();
+        q = __builtin_fminf(q, clampv);
+        const bool unsafe = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
+        atomicAdd(&hist[(int)q], 1u);
+        return unsafe;
+    }
     const bool in = live && (q < nb_hi);
     const bool safe = fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard;
     if (in && safe) atomicAdd(&hist[(int)q], 1u);
     return in && !safe;
 }
 
-template <bool ORTHO, bool DIAG, bool TAIL, bool IMG = false, bool ZF = false, bool ZFK = false>
+template <bool ORTHO, bool DIAG, bool TAIL, bool IMG = false, bool ZF = false, bool ZFK = false, bool AA = false>
 __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const double *sc64,
                                           const double *__restrict__ g, const float *sc, const uint4 *tq,
                                           int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
@@ -417,17 +417,17 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
         const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
         bool ma = false, mb = false;
         // (ZF: centres that do not exist carry an infinite slab coordinate, so only DIAG / TAIL need a live mask)
-        na[u] = fast_bin<ORTHO, IMG, ZF>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u], near_t, &ma, zaf,
-                                         clampv, !DIAG && !TAIL);
-        nb[u] = fast_bin<ORTHO, IMG, ZF>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u], near_t, &mb, zbf,
-                                         clampv, !DIAG && !TAIL);
+        na[u] = fast_bin<ORTHO, IMG, ZF, AA>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u], near_t, &ma, zaf,
+                                             clampv, ZF && !DIAG && !TAIL);
+        nb[u] = fast_bin<ORTHO, IMG, ZF, AA>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u], near_t, &mb, zbf,
+                                             clampv, ZF && !DIAG && !TAIL);
         anynear |= ma | mb;
     }
     if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {   // a few % of the pairs
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (na[u]) rdf_pair_refine<ORTHO, ZFK, ZF>(hist, fa, sc64, g, qa[u], uax, uay, uaz, qj[u], p, ida, qseg, j0 + u);
-            if (nb[u]) rdf_pair_refine<ORTHO, ZFK, ZF>(hist, fa, sc64, g, qb[u], ubx, uby, ubz, qj[u], p, idb, qseg, j0 + u);
+            if (na[u]) rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qa[u], uax, uay, uaz, qj[u], p, ida, qseg, j0 + u);
+            if (nb[u]) rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qb[u], ubx, uby, ubz, qj[u], p, idb, qseg, j0 + u);
         }
     }
     if (IMG) {
@@ -473,6 +473,9 @@ template <bool ORTHO, bool CULL, bool IMG = false, bool ZFK = false>
 __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
     static_assert(!ZFK || (ORTHO && CULL && !IMG), "f32 slab coordinates: diagonal cells, slab culling, no image queue");
+    // always-add histogram scheme (fast_bin<AA>): measured per variant (profiles/r02/tile_variants.txt) -- the plain
+    // general-cell variant spills under it (nine scales, 96 VGPRs) and keeps the masked form
+    constexpr bool AA = ORTHO || IMG;
     const RdfArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // double-buffered tiles: J (512 entries) and the centre sub-tile (128 entries)
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     // IMG: queue of the pairs that need the canonical evaluation (drained densely once per step), two counters
     // (two buffers: a step parks into one while the previous step's is drained; three counters so that one can be
     // reset a whole step away from its last reader and its next writer)
-    uint2 *nq_base = reinterpret_cast<uint2 *>(hist + ((fa.a.nbins + 1) & ~1));   // [2][img_queue]
+    uint2 *nq_base = reinterpret_cast<uint2 *>(hist + ((fa.a.nbins + FAST_TRASH + 1) & ~1));   // [2][img_queue]
     const unsigned nq_cap = (unsigned)fa.img_queue;
     __shared__ unsigned nq_count[3];
 
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const int la = 2 * lane, lb = la + 1;                          // local indices in the sub-tile
     const float half_m_guard = fa.half_m_guard;
     const float nb_hi = fa.nb_hi;
-    const float clampv = (float)nbins + 0.5f + (float)(lane & 31);   // ZF kernels: see fast_bin (32 trash words behind hist)
+    const float clampv = (float)nbins + 0.5f + (float)(lane & (FAST_TRASH - 1));   // see fast_bin<AA>
     const int cntj = tj.count;
     const int cntj4 = (cntj + 3) & ~3;
     const int full = cntj & ~3;
@@ -686,19 +689,19 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                 const int qe_full = min(qe, full);
                 if (diag) {
                     for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
-                        fast_quad<ORTHO, true, true, IMG, ZF, ZFK>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
+                        fast_quad<ORTHO, true, true, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
                                                                    half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
                                                                    idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap, zaf,
                                                                    zbf, qseg, clampv);
                 } else {
                     int j0 = qb + 4 * wave;
                     for (; j0 < qe_full; j0 += 16)
-                        fast_quad<ORTHO, false, false, IMG, ZF, ZFK>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
+                        fast_quad<ORTHO, false, false, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
                                                                      half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
                                                                      idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap,
                                                                      zaf, zbf, qseg, clampv);
                     if (j0 == full && j0 < qe && full < cntj)
-                        fast_quad<ORTHO, false, true, IMG, ZF, ZFK>(hist, fa, sc64, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
+                        fast_quad<ORTHO, false, true, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
                                                                     half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
                                                                     idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap, zaf,
                                                                     zbf, qseg, clampv);
@@ -1482,7 +1485,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag));
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int32_t), ctx->stream));
             fa.Q = (const QAtom *)d_Q;
-            size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)nbins * sizeof(unsigned);
+            size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)(nbins + FAST_TRASH) * sizeof(unsigned);
             fa.img_queue = 0;
             fa.img_defer = 0;
             if (fast_img) {
@@ -1493,7 +1496,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 const double want = std::max(96.0, ceil(4.0 * expect / 32.0) * 32.0);
                 fa.img_defer = want <= 256.0 ? 1 : 0;
                 fa.img_queue = fa.img_defer ? (int32_t)want : IMG_QUEUE_MAX;
-                lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + 1) & ~1) * sizeof(unsigned) +
+                lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 1) & ~1) * sizeof(unsigned) +
                       (fa.img_defer ? 2 : 1) * (size_t)fa.img_queue * sizeof(uint2);
             }
             int64_t launches = 0;
@@ -1540,9 +1543,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     fz.nb_hi = zf_nb_hi;
                     fz.half_m_guard = zf_half_m_guard;
                     hipError_t e2 = allow_max_lds((const void *)rdf_tile_kernel_fast<true, true, false, true>);
-                    if (e2 == hipSuccess)     // (+ 32 trash words behind the histogram: always-add scheme)
-                        hipLaunchKernelGGL((rdf_tile_kernel_fast<true, true, false, true>), grid, dim3(FAST_THREADS),
-                                           lds + 32 * sizeof(unsigned), ctx->stream, fz);
+                    if (e2 == hipSuccess)
+                        hipLaunchKernelGGL((rdf_tile_kernel_fast<true, true, false, true>), grid, dim3(FAST_THREADS), lds,
+                                           ctx->stream, fz);
                     e = e2;
                 }
                 else if (ortho && cull) e = launch(rdf_tile_kernel_fast<true, true>);
