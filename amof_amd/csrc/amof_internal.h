@@ -236,7 +236,7 @@ int launch_cell_sort(amof_ctx *ctx, const double *pos_dev, const double *d_geom,
 constexpr int CELL_LDS_MAX = 16384;
 int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                           const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q,
-                          uint32_t *d_start3, int32_t *d_flag, int64_t max_species_atoms);
+                          uint32_t *d_start3, int32_t *d_flag, int64_t max_species_atoms, unsigned long long used_mask);
 
 void timing_begin(amof_ctx *ctx);
 void timing_end(amof_ctx *ctx);

@@ -784,6 +784,8 @@ struct NbrFast {
     bool cell = false;
     int nk[3] = {0, 0, 0};
     void *d_start3 = nullptr;
+    unsigned long long used_mask = ~0ull;   // species with a cutoff to any species: the only ones the cell sort handles
+    int64_t max_used_atoms = 0;             // (its LDS record cache is sized for the largest of them)
 };
 
 // quantise + sort one frame batch for the neighbour kernels (slab list or cell list) and point fa at it
@@ -793,8 +795,8 @@ static int nbr_fast_batch(amof_ctx *ctx, const amof_traj *t, NbrSetup &st, NbrFa
     if (nf.cell)
         AMOF_TRY(launch_quantize_cells(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst,
                                        t->n_species, t->n_atoms, (int)fb, (int)nfr, nf.nk[0], nf.nk[1], nf.nk[2],
-                                       (QAtom *)nf.d_Q, (uint32_t *)nf.d_start3, (int32_t *)nf.d_qflag,
-                                       *std::max_element(st.tiles.nsp.begin(), st.tiles.nsp.end())));
+                                       (QAtom *)nf.d_Q, (uint32_t *)nf.d_start3, (int32_t *)nf.d_qflag, nf.max_used_atoms,
+                                       nf.used_mask));
     else
         AMOF_TRY(launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, (const int64_t *)nf.d_spfirst, t->n_species,
                                  t->n_atoms, (int)fb, (int)nfr, nf.axis, (QAtom *)nf.d_Q, (uint32_t *)nf.d_slab,
@@ -844,6 +846,18 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     }
     nf.sp_first.assign(S + 1, 0);
     for (int x = 0; x < S; x++) nf.sp_first[x + 1] = nf.sp_first[x] + st.tiles.nsp[x];
+    // species without a cutoff to any species are neither centres nor partners: the cell sort skips them
+    nf.used_mask = 0ull;
+    nf.max_used_atoms = 1;
+    for (int x = 0; x < S && x < 64; x++) {
+        bool used = false;
+        for (int y = 0; y < S; y++) used |= cutoff[x * S + y] > 0.0 || cutoff[y * S + x] > 0.0;
+        if (used) {
+            nf.used_mask |= 1ull << x;
+            nf.max_used_atoms = std::max<int64_t>(nf.max_used_atoms, st.tiles.nsp[x]);
+        }
+    }
+    if (S > 64) { nf.used_mask = ~0ull; nf.max_used_atoms = *std::max_element(st.tiles.nsp.begin(), st.tiles.nsp.end()); }
     // 3-D cell list instead of the slab list when the cutoffs are far below the cell size: cells at least R thick
     // (R = the largest cutoff), >= 3 per axis, reach 1 -- a centre meets the partners of 27 cells instead of a slab
     // range (ZIF-4 3x3x4, Zn-N at 2.5 A: ~7 candidates per Zn instead of ~930)

@@ -104,13 +104,22 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_cells_kernel(const dou
                                                                        const int64_t *__restrict__ sp_first, int S,
                                                                        int64_t N, int f0, int nx, int ny, int nz,
                                                                        QAtom *__restrict__ Q, uint32_t *__restrict__ start3,
-                                                                       int32_t *flag, int cache_cap)
+                                                                       int32_t *flag, int cache_cap,
+                                                                       unsigned long long used_mask)
 {
     extern __shared__ __align__(16) unsigned char qcache_raw[];
     QAtom *cache = reinterpret_cast<QAtom *>(qcache_raw);                   // [cache_cap]
     unsigned *cnt = reinterpret_cast<unsigned *>(cache + cache_cap);        // [ncell]
     __shared__ unsigned wsum[QUANT_THREADS / 64];
-    const int sp = blockIdx.x, fl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // blockIdx.x counts the species that take part in the search (used_mask: those with a cutoff to any species);
+    // the others are neither sorted nor read by the neighbour kernels
+    int sp = 0;
+    {
+        unsigned long long m = used_mask;
+        for (unsigned k = 0; k < blockIdx.x; k++) m &= m - 1ull;
+        sp = __ffsll((long long)m) - 1;
+    }
+    const int fl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int f = f0 + fl;
     const int ncell = nx * ny * nz;
     const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_cells_kernel(const dou
         st[c] = (uint32_t)k0 + run;
         run += v;
     }
-    if (sp == S - 1 && tid == 0) start3[(size_t)fl * ((size_t)S * ncell + 1) + (size_t)S * ncell] = (uint32_t)N;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) start3[(size_t)fl * ((size_t)S * ncell + 1) + (size_t)S * ncell] = (uint32_t)N;
     __syncthreads();
     QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
     for (int64_t k = k0 + tid; k < k1; k += QUANT_THREADS) {
@@ -333,9 +342,12 @@ int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom,
 
 int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                           const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q,
-                          uint32_t *d_start3, int32_t *d_flag, int64_t max_species_atoms)
+                          uint32_t *d_start3, int32_t *d_flag, int64_t max_species_atoms, unsigned long long used_mask)
 {
     if (nf <= 0 || S <= 0) return AMOF_OK;
+    if (S < 64) used_mask &= (1ull << S) - 1ull;
+    const int n_used = __builtin_popcountll(used_mask);
+    if (n_used == 0) return AMOF_OK;
     if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
     const int64_t ncell = (int64_t)nx * ny * nz;
     if (nx < 1 || ny < 1 || nz < 1 || ncell > CELL_LDS_MAX || N >= (1ll << CELL_SPECIES_SHIFT) || S > 64)
@@ -345,8 +357,8 @@ int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_
     const int cache_cap = (int)std::min<int64_t>(std::max<int64_t>(max_species_atoms, 1), 4608);
     const size_t lds = (size_t)cache_cap * sizeof(QAtom) + (size_t)ncell * sizeof(unsigned);
     AMOF_HIP_TRY(ctx, allow_max_lds((const void *)quantize_cells_kernel));
-    hipLaunchKernelGGL(quantize_cells_kernel, dim3((unsigned)S, (unsigned)nf), dim3(QUANT_THREADS), lds, ctx->stream, pos_dev,
-                       d_geom, n_cells, d_perm, d_spfirst, S, N, f0, nx, ny, nz, d_Q, d_start3, d_flag, cache_cap);
+    hipLaunchKernelGGL(quantize_cells_kernel, dim3((unsigned)n_used, (unsigned)nf), dim3(QUANT_THREADS), lds, ctx->stream, pos_dev,
+                       d_geom, n_cells, d_perm, d_spfirst, S, N, f0, nx, ny, nz, d_Q, d_start3, d_flag, cache_cap, used_mask);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     return AMOF_OK;
 }
