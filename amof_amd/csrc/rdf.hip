@@ -472,7 +472,7 @@ __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
 template <bool ORTHO, bool CULL, bool IMG = false, bool ZFK = false>
 __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
-    static_assert(!ZFK || (ORTHO && CULL && !IMG), "f32 slab coordinates: diagonal cells, slab culling, no image queue");
+    static_assert(!ZFK || (ORTHO && !IMG), "f32 slab coordinates: diagonal cells, no image queue");
     // always-add histogram scheme (fast_bin<AA>): measured per variant (profiles/r02/tile_variants.txt) -- the plain
     // general-cell variant spills under it (nine scales, 96 VGPRs) and keeps the masked form
     constexpr bool AA = ORTHO || IMG;
@@ -611,68 +611,106 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         // the partners within reach of the centre atoms (slab distance <= cull_gap, circular)
         // form at most two contiguous index ranges, found once per frame.
         int rb0 = diag ? (sub * FAST_SUB) : 0, re0 = cntj, rb1 = 0, re1 = 0;
-        bool zf = false;          // this step runs on f32 slab coordinates (ZF kernels)
+        bool zf = false;          // this step has quads that run on f32 slab coordinates (ZF kernels)
         uint32_t z0 = 0u;         // their origin: the middle of the centre sub-tile's slab range
-        if (CULL) {
+        // quad ranges [b, e) of this step, quads dealt round-robin to the four waves: zq on f32 slab coordinates,
+        // iq on the integer slab differences
+        int zqb[2] = {0, 0}, zqe[2] = {0, 0}, iqb[2] = {0, 0}, iqe[2] = {0, 0};
+        if (CULL || ZFK) {
             // the sub-tile is slab-sorted: its first / last atoms give its slab range
             const uint32_t s_first = tc[0].z >> 24, s_last = tc[cnti - 1].z >> 24;
             const uint32_t wlo = s_first << 24, whi = (s_last << 24) | 0xffffffu;
-            const uint32_t G = __builtin_amdgcn_readfirstlane(fs->cull_gap);
-            // reachable keys: [wlo - G, whi + G] (mod 2^32), widened to whole slabs (2^24 each)
-            const unsigned long long span = (unsigned long long)(whi - wlo) + 2ull * G + (2ull << 24);
-            if (G != 0u && span < (1ull << 32)) {
-                const uint32_t klo = wlo - G, khi = whi + G;
-                const uint32_t slo = klo >> 24, shi = khi >> 24;
-                // every lane samples two quads of tile J; ballots give the boundary quads
-                const int q0 = lane, q1 = lane + 64;     // FAST_TILE / 4 = 128 quads
-                const uint32_t l0 = tq[min(4 * q0 + 3, cntj - 1)].z >> 24, l1 = tq[min(4 * q1 + 3, cntj - 1)].z >> 24;
-                const uint32_t h0 = tq[min(4 * q0, cntj - 1)].z >> 24, h1 = tq[min(4 * q1, cntj - 1)].z >> 24;
-                auto first_set = [&](bool g0, bool g1) {
-                    const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
-                    const int fq = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
-                    return min(4 * fq, cntj);
-                };
-                // a_: start of the first quad whose LAST partner has slab >= slo
-                // b_: start of the first quad whose FIRST partner has slab > shi
-                const int a_ = first_set(4 * q0 >= cntj || l0 >= slo, 4 * q1 >= cntj || l1 >= slo);
-                const int b_ = first_set(4 * q0 >= cntj || h0 > shi, 4 * q1 >= cntj || h1 > shi);
-                if (klo <= khi) {
-                    rb0 = max(rb0, a_); re0 = b_;
-                } else if (b_ < a_) {      // wrapped reach: keys <= khi or >= klo
-                    re0 = b_;
-                    rb1 = max(rb0, a_); re1 = cntj;
-                }                          // else the two pieces touch: whole tile
-                if (ZFK) {
-                    // f32 slab coordinates are valid when no slab difference of a partner inside the reach window and a
-                    // centre can wrap: |z_j - z0| <= G + W/2 + 2^24 + 1, |z_i - z0| <= W/2 + 1, their difference below
-                    // 2^31 in magnitude -- then it IS the minimum image.  A partner outside the window (quads are
-                    // visited whole) comes out beyond G either way round, i.e. out of range.  W < 2^28 is the span
-                    // the host's error bound (fast_guard_zf) assumes.
-                    const uint32_t W = whi - wlo;
-                    zf = W < (1u << 28) && (unsigned long long)G + W + (2ull << 24) < (1ull << 31);
+            const uint32_t W = whi - wlo;
+            // every lane samples two quads of tile J; ballots give the boundary quads
+            const int q0 = lane, q1 = lane + 64;     // FAST_TILE / 4 = 128 quads
+            const uint32_t l0 = tq[min(4 * q0 + 3, cntj - 1)].z >> 24, l1 = tq[min(4 * q1 + 3, cntj - 1)].z >> 24;
+            const uint32_t h0 = tq[min(4 * q0, cntj - 1)].z >> 24, h1 = tq[min(4 * q1, cntj - 1)].z >> 24;
+            auto first_set = [&](bool g0, bool g1) {
+                const unsigned long long m0 = __ballot(g0), m1 = __ballot(g1);
+                const int fq = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : 128);
+                return min(4 * fq, cntj);
+            };
+            if (CULL) {
+                const uint32_t G = __builtin_amdgcn_readfirstlane(fs->cull_gap);
+                // reachable keys: [wlo - G, whi + G] (mod 2^32), widened to whole slabs (2^24 each)
+                const unsigned long long span = (unsigned long long)W + 2ull * G + (2ull << 24);
+                if (G != 0u && span < (1ull << 32)) {
+                    const uint32_t klo = wlo - G, khi = whi + G;
+                    const uint32_t slo = klo >> 24, shi = khi >> 24;
+                    // a_: start of the first quad whose LAST partner has slab >= slo
+                    // b_: start of the first quad whose FIRST partner has slab > shi
+                    const int a_ = first_set(4 * q0 >= cntj || l0 >= slo, 4 * q1 >= cntj || l1 >= slo);
+                    const int b_ = first_set(4 * q0 >= cntj || h0 > shi, 4 * q1 >= cntj || h1 > shi);
+                    if (klo <= khi) {
+                        rb0 = max(rb0, a_); re0 = b_;
+                    } else if (b_ < a_) {      // wrapped reach: keys <= khi or >= klo
+                        re0 = b_;
+                        rb1 = max(rb0, a_); re1 = cntj;
+                    }                          // else the two pieces touch: whole tile
+                    if (ZFK) {
+                        // f32 slab coordinates are valid when no slab difference of a partner inside the reach window and
+                        // a centre can wrap: |z_j - z0| <= G + W/2 + 2^24 + 1, |z_i - z0| <= W/2 + 1, their difference
+                        // below 2^31 in magnitude -- then it IS the minimum image.  A partner outside the window (quads are
+                        // visited whole) comes out beyond G either way round, i.e. out of range.  W < 2^28 is the span
+                        // the host's error bound (fast_guard_zf) assumes.
+                        zf = W < (1u << 28) && (unsigned long long)G + W + (2ull << 24) < (1ull << 31);
+                        z0 = wlo + (W >> 1);
+                    }
+                }
+                int qbr[2], qer[2];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int rb = r == 0 ? rb0 : rb1, re = r == 0 ? re0 : re1;
+                    qbr[r] = rb & ~3;
+                    qer[r] = re <= rb ? 0 : (re + 3) & ~3;
+                    if (r == 1) qbr[r] = max(qbr[r], (max(re0, rb0) + 3) & ~3);   // never visit a quad twice
+                    (zf ? zqb : iqb)[r] = qbr[r];
+                    (zf ? zqe : iqe)[r] = qer[r];
+                }
+            } else {
+                // No culling (the cutoff reaches across the slab axis: cubic cells at the default cutoff): every quad is
+                // visited, and the f32 slab coordinates still hold for all partners but a band around the antipode of
+                // the sub-tile, where the wrap depends on the centre.  G2 = the largest reach they allow; a ZF quad may
+                // only hold partners inside the window (here a partner outside is NOT out of range), so the window is
+                // cut at whole quads from the inside: a2 = first quad whose FIRST partner has slab >= slo, b2 = first
+                // quad whose LAST partner has slab > shi.  The band (>= 4 slabs wide) and the straddling quads take the
+                // integer path.
+                const int start = rb0, endq = (cntj + 3) & ~3;          // (start is a multiple of 4)
+                iqb[0] = start; iqe[0] = endq;
+                if (W < (1u << 28)) {
+                    const uint32_t G2 = 0x7fffffffu - W - (2u << 24) - 2u;
+                    const uint32_t klo = wlo - G2, khi = whi + G2;
+                    const uint32_t slo = klo >> 24, shi = khi >> 24;
+                    const int a2 = first_set(4 * q0 >= cntj || h0 >= slo, 4 * q1 >= cntj || h1 >= slo);
+                    const int b2 = first_set(4 * q0 >= cntj || l0 > shi, 4 * q1 >= cntj || l1 > shi);
+                    auto up4 = [](int x) { return (x + 3) & ~3; };
+                    zf = true;
                     z0 = wlo + (W >> 1);
+                    if (klo <= khi) {              // window = slabs [slo, shi]: ZF quads [a2, b2)
+                        zqb[0] = max(start, a2); zqe[0] = up4(b2);
+                        iqb[0] = start; iqe[0] = min(max(start, a2), endq);
+                        iqb[1] = max(start, up4(b2)); iqe[1] = endq;
+                    } else {                       // window = slabs [0, shi] and [slo, 255]: ZF quads [0, b2) and [a2, end)
+                        zqb[0] = start; zqe[0] = up4(b2);
+                        zqb[1] = max(start, a2); zqe[1] = endq;
+                        iqb[0] = max(start, up4(b2)); iqe[0] = min(max(start, a2), endq);
+                    }
                 }
             }
-        }
-        // quad ranges of the two pieces: [qb_r, qe_r), quads dealt round-robin to the four waves
-        int qbr[2], qer[2];
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int rb = r == 0 ? rb0 : rb1, re = r == 0 ? re0 : re1;
-            qbr[r] = rb & ~3;
-            qer[r] = re <= rb ? 0 : (re + 3) & ~3;
-            if (r == 1) qbr[r] = max(qbr[r], (max(re0, rb0) + 3) & ~3);   // never visit a quad twice
+        } else {
+            iqb[0] = rb0 & ~3;
+            iqe[0] = (re0 + 3) & ~3;
         }
         float zaf = 0.0f, zbf = 0.0f;
         if (ZFK && zf) {
-            // each wave converts the slab coordinate of the partners it is about to meet (its own quads of both
-            // pieces) into bins relative to z0, one rounding (f64 product -> f32), and parks it in the LDS copy's
-            // .w; centre atoms likewise, in registers.  Wave-local: LDS operations of a wave execute in order.
+            // each wave converts the slab coordinate of the partners it is about to meet on the ZF path (its own quads
+            // of both pieces) into bins relative to z0, one rounding (f64 product -> f32), and parks it in the LDS
+            // copy's .w; centre atoms likewise, in registers.  Wave-local: LDS operations of a wave execute in order.
             const double cz = sc64[2];
             uint4 *tqw = tqb + jb * FAST_TILE;
 #pragma unroll 1
             for (int r = 0; r < 2; r++) {
-                for (int j = qbr[r] + 4 * wave + 16 * (lane >> 2) + (lane & 3); j < qer[r]; j += 256)
+                for (int j = zqb[r] + 4 * wave + 16 * (lane >> 2) + (lane & 3); j < zqe[r]; j += 256)
                     tqw[j].w = __float_as_uint((float)((double)(int)(tqw[j].z - z0) * cz));
             }
             zaf = has_a ? (float)((double)(int)(uaz - z0) * cz) : __builtin_inff();
@@ -680,7 +718,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         const QAtom *__restrict__ qseg = fa.Q + (size_t)fl * (size_t)a.N + tj.start;
-        auto run = [&](auto zf_tag) {
+        auto run = [&](auto zf_tag, const int *qbr, const int *qer) {
             constexpr bool ZF = decltype(zf_tag)::value;
 #pragma unroll 1
             for (int r = 0; r < 2; r++) {
@@ -708,8 +746,8 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                 }
             }
         };
-        if (ZFK && zf) run(std::true_type{});
-        else run(std::false_type{});
+        if (ZFK && zf) run(std::true_type{}, zqb, zqe);
+        run(std::false_type{}, iqb, iqe);
         if (IMG && !fa.img_defer) {
             // large shares: dense canonical pass over this step's parked pairs right away (one more barrier per step)
             __syncthreads();
@@ -1243,16 +1281,17 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             fa.guard64 = guard_m;
             fa.guard64_2 = 2.0 * guard_m * (1.0 + 1e-9);
             fa.guard64_sq = guard_m * guard_m * (1.0 + 1e-9);
-            // Diagonal cells with slab culling: the tile kernel takes the slab-axis difference from f32 coordinates
-            // (ZF, see fast_q_zf); its candidate carries one more absolute term, hence its own (slightly wider) guard.
+            // Diagonal cells: the tile kernel takes the slab-axis difference from f32 coordinates (ZF, see fast_q_zf) --
+            // with slab culling for every visited partner, without it for all but a band around the sub-tile's antipode;
+            // its candidate carries one more absolute term, hence its own (slightly wider) guard.
             const char *nozf = getenv("AMOF_RDF_NOZF");
-            bool use_zf = fast && !fast_img && ortho && cull && !(nozf && nozf[0] == '1');
+            bool use_zf = fast && !fast_img && ortho && !(nozf && nozf[0] == '1');
             float zf_nb_hi = fa.nb_hi, zf_half_m_guard = fa.half_m_guard;
             if (use_zf) {
                 double hb = 0.0, gfrac = 0.0;
                 for (int64_t k = 0; k < nc; k++) {
                     hb = std::max(hb, geom.rec[(size_t)k * GEOM_STRIDE + 18 + axis] / dr);
-                    gfrac = std::max(gfrac, (double)fsv[(size_t)k].cull_gap / 4294967296.0);
+                    gfrac = std::max(gfrac, cull ? (double)fsv[(size_t)k].cull_gap / 4294967296.0 : 0.5);   // (no culling: reach 2^31)
                 }
                 const double guard_zf = fast_guard_zf(nbins, hb, gfrac) + guard_m;
                 if (!(guard_zf < 0.25)) use_zf = false;
@@ -1542,9 +1581,13 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     RdfFastArgs fz = fa;
                     fz.nb_hi = zf_nb_hi;
                     fz.half_m_guard = zf_half_m_guard;
-                    hipError_t e2 = allow_max_lds((const void *)rdf_tile_kernel_fast<true, true, false, true>);
-                    if (e2 == hipSuccess)
+                    hipError_t e2 = cull ? allow_max_lds((const void *)rdf_tile_kernel_fast<true, true, false, true>)
+                                         : allow_max_lds((const void *)rdf_tile_kernel_fast<true, false, false, true>);
+                    if (e2 == hipSuccess && cull)
                         hipLaunchKernelGGL((rdf_tile_kernel_fast<true, true, false, true>), grid, dim3(FAST_THREADS), lds,
+                                           ctx->stream, fz);
+                    else if (e2 == hipSuccess)
+                        hipLaunchKernelGGL((rdf_tile_kernel_fast<true, false, false, true>), grid, dim3(FAST_THREADS), lds,
                                            ctx->stream, fz);
                     e = e2;
                 }

@@ -46,16 +46,21 @@ def test_rdf_fast_equals_exact_equals_oracle(hip_ctx, kind):
     packed, rmax, nb = _traj(kind)
     with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
         fast, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-        # diagonal cell + slab culling: the variant with f32 slab coordinates and the always-add histogram
-        assert hip_ctx.last_path() == ("rdf_tile_zf" if kind == "elongated" else "rdf_tile")
-        if kind == "elongated":
+        # diagonal cells: the variant with f32 slab coordinates and the always-add histogram
+        diagonal = bool(np.all(packed.cell == packed.cell * np.eye(3)))
+        assert hip_ctx.last_path() == ("rdf_tile_zf" if diagonal else "rdf_tile")
+        if diagonal:
             with _env(AMOF_RDF_NOZF="1"):
                 nozf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
                 assert hip_ctx.last_path() == "rdf_tile"
             assert np.array_equal(fast, nozf)
         with _env(AMOF_RDF_NOCULL="1"):
             nocull, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() == "rdf_tile"
+            assert hip_ctx.last_path() == ("rdf_tile_zf" if diagonal else "rdf_tile")
+            with _env(AMOF_RDF_NOZF="1"):
+                nocull_nozf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+                assert hip_ctx.last_path() == "rdf_tile"
+            assert np.array_equal(nocull, nocull_nozf)
     with _env(AMOF_RDF_KERNEL="v1"):
         exact, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
         assert hip_ctx.last_path() == "rdf_exact"
@@ -445,17 +450,18 @@ def test_rdf_image_aware_variant_on_a_plain_case(hip_ctx):
     assert np.array_equal(plain, img)
 
 
-def _zf_vs_oracle(hip_ctx, packed, rmax, nb):
+def _zf_vs_oracle(hip_ctx, packed, rmax, nb, nocull_too=True):
     kinds, sp = H.species_of(packed.numbers)
-    with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
-        zf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-        assert hip_ctx.last_path() == "rdf_tile_zf"
-        with _env(AMOF_RDF_NOZF="1"):
-            plain, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() == "rdf_tile"
     ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
-    assert np.array_equal(plain, ref)
-    assert np.array_equal(zf, ref), (rmax, nb, int(zf.sum()), int(ref.sum()), int(np.abs(zf.astype(np.int64) - ref).sum()))
+    for env in ([{}, {"AMOF_RDF_NOCULL": "1"}] if nocull_too else [{}]):     # (culling forced off: the antipodal-band split)
+        with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1", **env):
+            zf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_tile_zf"
+            with _env(AMOF_RDF_NOZF="1"):
+                plain, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+                assert hip_ctx.last_path() == "rdf_tile"
+        assert np.array_equal(plain, ref)
+        assert np.array_equal(zf, ref), (env, rmax, nb, int(zf.sum()), int(ref.sum()), int(np.abs(zf.astype(np.int64) - ref).sum()))
 
 
 def test_rdf_zf_lattice_pairs_on_bin_edges(hip_ctx):
@@ -495,3 +501,26 @@ def test_rdf_zf_changing_diagonal_cells(hip_ctx):
     assert packed.cell.shape[0] == 5
     rmax = float(np.min(packed.cell_lengths()) / 2)
     _zf_vs_oracle(hip_ctx, packed, rmax, int(rmax // 0.01))
+
+
+def test_rdf_zf_cubic_cells_without_culling(hip_ctx):
+    # cubic cells at the default cutoff (half the cell): no slab culling is possible, every partner is visited, and the
+    # f32 slab coordinates cover all of them but the band around the sub-tile's antipode -- a perfect lattice (every
+    # distance on a bin edge, pairs at exactly half the cell), layered atoms with a rare species, and a random gas
+    a, n = 2.0, 10
+    g = np.arange(n) * a
+    pos = np.array([[x, y, z] for x in g for y in g for z in g], dtype=float)
+    numbers = np.where(np.arange(len(pos)) % 7 == 0, 30, np.where(np.arange(len(pos)) % 2 == 0, 7, 6))
+    packed = PackedTrajectory(np.stack([pos, pos + 0.5, pos - 27.0]), np.diag([n * a] * 3), numbers)
+    for rmax, nb in [(10.0, 1000), (10.0, 10), (9.99, 2310), (7.0, 70)]:
+        _zf_vs_oracle(hip_ctx, packed, rmax, nb, nocull_too=False)
+        assert hip_ctx.last_path() == "rdf_tile"      # (the last call of the helper ran with AMOF_RDF_NOZF)
+    rng = np.random.default_rng(5)
+    L, N = 24.0, 3000
+    z = np.concatenate([rng.normal(c, 0.3, 700) for c in (2.0, 9.0, 14.0, 21.5)])
+    z = np.concatenate([z, rng.uniform(0, L, N - len(z))])
+    p = np.column_stack([rng.uniform(0, L, (N, 2)), z])
+    numbers = np.where(np.arange(N) >= 2850, 30, np.where(np.arange(N) % 3 == 0, 6, 1))
+    packed = PackedTrajectory(np.stack([p, p[:, [2, 0, 1]], p + 100.0]), np.diag([L] * 3), numbers)
+    for rmax, nb in [(12.0, 1200), (11.5, 2310), (12.0, 37)]:
+        _zf_vs_oracle(hip_ctx, packed, rmax, nb, nocull_too=False)

@@ -1,5 +1,5 @@
 """Randomized parity soak for the tile kernel's variant with f32 slab coordinates and the always-add histogram
-("rdf_tile_zf": diagonal cells with slab culling): long diagonal boxes, uniform / layered / lattice atom
+("rdf_tile_zf": diagonal cells, with slab culling or -- near-cubic boxes -- without): long and near-cubic diagonal boxes, uniform / layered / lattice atom
 distributions, one to four species (rare ones included: their centre sub-tiles span wide slab ranges and fall back to
 the integer differences step by step), constant or per-frame cells -- against the C oracle and against the plain tile
 kernel (AMOF_RDF_NOZF=1).  Run by hand on a GPU box: `python tests/tools/soak_gpu_zf.py SECONDS` (not collected by pytest)."""
@@ -28,14 +28,14 @@ while time.time() < t_end:
     if kind == "lattice":
         a = float(rng.choice([1.0, 1.5, 2.0]))
         nx, ny = int(rng.integers(4, 8)), int(rng.integers(4, 8))
-        nz = max(int(rng.integers(2, 4) * max(nx, ny) + 1), N // (nx * ny))
+        nz = max(int(rng.integers(2, 4) * max(nx, ny) + 1), N // (nx * ny)) if seed % 2 else int(rng.integers(4, 9))
         g = np.array([[x, y, z] for x in range(nx) for y in range(ny) for z in range(nz)], dtype=float) * a
         N = len(g)
         L = np.array([nx, ny, nz]) * a
         pos = np.stack([g + rng.choice([0.0, 0.25, -3.0 * L[2]]) for _ in range(F)])
     else:
         rho = rng.uniform(0.03, 0.08)
-        stretch = rng.uniform(2.2, 4.5)
+        stretch = rng.uniform(2.2, 4.5) if seed % 2 else rng.uniform(0.9, 1.3)     # long boxes (culling) / near-cubic (none)
         Lx = (N / rho / stretch) ** (1 / 3) * rng.uniform(0.8, 1.25)
         Ly = (N / rho / stretch) ** (1 / 3) * rng.uniform(0.8, 1.25)
         L = np.array([Lx, Ly, N / rho / (Lx * Ly)])
