@@ -187,7 +187,7 @@ struct HostTiles {
     std::vector<int64_t> nsp;      // atoms per species
     std::vector<int32_t> sp_first_tile, sp_ntiles;
 };
-void build_tiles(const amof_traj *t, int tile, HostTiles &out);
+void build_tiles(const amof_traj *t, int tile, HostTiles &out, int granule = 0);
 
 // staging of the position array (host -> device) or pass-through
 int stage_positions(amof_ctx *ctx, const amof_traj *t, const double **pos_dev);

@@ -262,7 +262,10 @@ int build_images(amof_ctx *ctx, const amof_traj *t, const HostGeom &g, double R,
     return AMOF_OK;
 }
 
-void build_tiles(const amof_traj *t, int tile, HostTiles &out)
+// granule > 0 (the fast RDF tile kernel: its 128-atom centre sub-tiles): tile sizes are multiples of the granule except
+// the last tile of a species, so that only one sub-tile per species is ragged (ZIF-4 3x3x4: Zn 576 = 384 + 192 instead
+// of 288 + 288, i.e. sub-tiles 128 128 128 | 128 64 instead of 128 128 32 | 128 128 32)
+void build_tiles(const amof_traj *t, int tile, HostTiles &out, int granule)
 {
     int S = t->n_species;
     int64_t N = t->n_atoms;
@@ -282,8 +285,11 @@ void build_tiles(const amof_traj *t, int tile, HostTiles &out)
         out.sp_first_tile[s] = (int32_t)out.tiles.size();
         out.sp_ntiles[s] = (int32_t)nt;
         int64_t base = nt ? n / nt : 0, rem = nt ? n % nt : 0, off = first[s];
+        const int64_t ng = granule > 0 ? (n + granule - 1) / granule : 0;      // granules of this species
+        const int64_t gbase = nt ? ng / nt : 0, grem = nt ? ng % nt : 0;
         for (int64_t k = 0; k < nt; k++) {
             int64_t cnt = base + (k < rem ? 1 : 0);
+            if (granule > 0) cnt = std::min<int64_t>((gbase + (k < grem ? 1 : 0)) * granule, first[s] + n - off);
             Tile tl;
             tl.start = (int32_t)off;
             tl.count = (int32_t)cnt;

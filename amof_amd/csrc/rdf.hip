@@ -1210,7 +1210,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         bool done = false;
         if (fast || fast_img) {
             HostTiles ftiles;
-            build_tiles(t, FAST_TILE, ftiles);
+            build_tiles(t, FAST_TILE, ftiles, FAST_SUB);
             std::vector<int2> fpairs;
             for (int i = 0; i < (int)ftiles.tiles.size(); i++)
                 for (int j = i; j < (int)ftiles.tiles.size(); j++) fpairs.push_back(make_int2(i, j));
