@@ -204,7 +204,8 @@ __global__ __launch_bounds__(RDF_TILE) void rdf_tile_kernel_global(RdfArgs a)
 // height, so both images are out of range there.
 // per-cell record of the fast path (one per frame when the cell changes)
 struct FrameScale {
-    float sc[9];        // ORTHO: sc[0..2] = L_k * 2^-32 / dr, sc[3..5] their squares ; else cell[k][c] * 2^-32 / dr (rows in stored order)
+    float sc[9];        // ORTHO: sc[0..2] = L_k * 2^-32 / dr, sc[3..5] their squares ; else the lower-triangular factor of the
+                        // metric of cell * 2^-32 / dr (rows in stored order): sc[0], sc[3], sc[4], sc[6..8]; the others 0
     uint32_t cull_gap;  // slab-gap threshold of this cell (0 = culling off)
     uint32_t near_t[3]; // IMG variant: a pair with |i_k| > near_t[k] (stored axis order) is evaluated canonically
     uint32_t _pad;
@@ -251,9 +252,10 @@ __device__ __forceinline__ float fast_q(const float *sc, int ix, int iy, int iz)
         const float x2 = fx * fx, y2 = fy * fy, z2 = fz * fz;
         t = fmaf(z2, sc[5], fmaf(y2, sc[4], x2 * sc[3]));
     } else {
+        // general cell: the scales are the lower-triangular factor of the cell's metric (lower_factor, amof_internal.h)
         const float dx = fmaf(fz, sc[6], fmaf(fy, sc[3], fx * sc[0]));
-        const float dy = fmaf(fz, sc[7], fmaf(fy, sc[4], fx * sc[1]));
-        const float dz = fmaf(fz, sc[8], fmaf(fy, sc[5], fx * sc[2]));
+        const float dy = fmaf(fz, sc[7], fy * sc[4]);
+        const float dz = fz * sc[8];
         t = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     }
     return __builtin_amdgcn_sqrtf(t);
@@ -280,8 +282,8 @@ __device__ __forceinline__ double medium_t(const double *sc, int ix, int iy, int
         dx = fx * sc[0]; dy = fy * sc[1]; dz = fz * sc[2];
     } else {
         dx = fma(fz, sc[6], fma(fy, sc[3], fx * sc[0]));
-        dy = fma(fz, sc[7], fma(fy, sc[4], fx * sc[1]));
-        dz = fma(fz, sc[8], fma(fy, sc[5], fx * sc[2]));
+        dy = fma(fz, sc[7], fy * sc[4]);
+        dz = fz * sc[8];
     }
     return fma(dz, dz, fma(dy, dy, dx * dx));
 }
@@ -1152,7 +1154,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         const double quant = csum * (1.0 / 2147483648.0);
         const double guard_m = quant / dr + (double)nbins * 1e-12;
         // f32 candidate: relative error bound of the chain, see fast_guard_rel (amof_internal.h)
-        const double guard_f = (double)nbins * fast_guard_rel(geom, nc, true) + guard_m;
+        const double guard_f = (double)nbins * fast_guard_rel_rdf(geom, t->cell, nc) + guard_m;
         const char *force = getenv("AMOF_RDF_KERNEL");
         bool fast = !extra && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS - 5120 &&
                     guard_f < 0.25 && !(force && strcmp(force, "v1") == 0);
@@ -1250,8 +1252,10 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 if (ortho) {
                     for (int q = 0; q < 3; q++) r.sc64[q] = c[4 * ord[q]] * two32 / dr;
                 } else {
+                    double rows[9];
                     for (int q = 0; q < 3; q++)
-                        for (int x = 0; x < 3; x++) r.sc64[3 * q + x] = c[3 * ord[q] + x] * two32 / dr;
+                        for (int x = 0; x < 3; x++) rows[3 * q + x] = c[3 * ord[q] + x] * two32 / dr;
+                    lower_factor(rows, r.sc64);
                 }
                 for (int q = 0; q < 9; q++) r.sc[q] = (float)r.sc64[q];
                 if (ortho)
@@ -1342,7 +1346,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                         if (ortho) {
                             for (int q = 0; q < 3; q++) r.sc64[q] = c[4 * q] * two32 / dr;
                         } else {
-                            for (int q = 0; q < 9; q++) r.sc64[q] = c[q] * two32 / dr;
+                            double rows[9];
+                            for (int q = 0; q < 9; q++) rows[q] = c[q] * two32 / dr;
+                            lower_factor(rows, r.sc64);
                         }
                         for (int q = 0; q < 9; q++) r.sc[q] = (float)r.sc64[q];
                         if (ortho)
@@ -1442,8 +1448,10 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     if (ortho) {
                         for (int q = 0; q < 3; q++) r.sc64[q] = c[4 * ord2[q]] * two32 / dr;
                     } else {
+                        double rows[9];
                         for (int q = 0; q < 3; q++)
-                            for (int x = 0; x < 3; x++) r.sc64[3 * q + x] = c[3 * ord2[q] + x] * two32 / dr;
+                            for (int x = 0; x < 3; x++) rows[3 * q + x] = c[3 * ord2[q] + x] * two32 / dr;
+                        lower_factor(rows, r.sc64);
                     }
                     for (int q = 0; q < 9; q++) r.sc[q] = (float)r.sc64[q];
                     if (ortho)
