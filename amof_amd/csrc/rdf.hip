@@ -354,19 +354,25 @@ __device__ __forceinline__ void rdf_pair_images(unsigned *hist, const RdfFastArg
 // within reach of a cell face (|i_k| > near_t[k]) can have a second image in range or an ambiguous base image --
 // they are not touched here (near = true) and are evaluated canonically, images included; for every other pair the
 // base image is unambiguous and the only one that can be in range.
+// IMG variant: does the pair lie within reach of a cell face, |i_k| > near_t[k] on some axis?  Decided on the f32
+// conversions with thresholds near_f[k] just below float(near_t[k]) (rounded down, then one ulp less): a pair beyond the
+// integer threshold is always flagged, a few just below it may be too -- they take the canonical route, which is exact.
+__device__ __forceinline__ bool near_pair(const float *near_f, int ix, int iy, int iz)
+{
+    return (fabsf((float)ix) > near_f[0]) | (fabsf((float)iy) > near_f[1]) | (fabsf((float)iz) > near_f[2]);
+}
+
 template <bool ORTHO, bool IMG = false, bool ZF = false, bool AA = false>
 __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool live, float half_m_guard,
                                          float nb_hi, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj,
-                                         float &q, const uint32_t *near_t = nullptr, bool *near = nullptr,
+                                         float &q, const float *near_f = nullptr, bool *near = nullptr,
                                          float zif = 0.0f, float clampv = 0.0f, bool live_all = false)
 {
     const int ix = (int)(qj.x - uix), iy = (int)(qj.y - uiy), iz = (int)(qj.z - uiz);
     if (IMG) {
-        // (axes that are clear of their half height carry the sentinel and are skipped: wave-uniform branches)
-        bool nr = false;
-        if (near_t[0] != 0x7fffffffu) nr |= (uint32_t)ix + near_t[0] > 2u * near_t[0];
-        if (near_t[1] != 0x7fffffffu) nr |= (uint32_t)iy + near_t[1] > 2u * near_t[1];
-        if (near_t[2] != 0x7fffffffu) nr |= (uint32_t)iz + near_t[2] > 2u * near_t[2];
+        // on the converted differences the candidate needs anyway: one compare per axis (thresholds rounded down, see
+        // the kernel; axes that are clear of their half height carry +inf)
+        const bool nr = near_pair(near_f, ix, iy, iz);
         *near = live && nr;
         live = live && !nr;
     }
@@ -398,7 +404,7 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
                                           float half_m_guard, float nb_hi, uint32_t uax, uint32_t uay,
                                           uint32_t uaz, uint32_t ida, uint32_t ubx, uint32_t uby, uint32_t ubz,
                                           uint32_t idb, const double *__restrict__ p,
-                                          const uint32_t *near_t = nullptr, int gi = 0, uint2 *nq = nullptr,
+                                          const float *near_f = nullptr, int gi = 0, uint2 *nq = nullptr,
                                           unsigned *nq_count = nullptr, unsigned nq_cap = 0,
                                           float zaf = 0.0f, float zbf = 0.0f, const QAtom *__restrict__ qseg = nullptr,
                                           float clampv = 0.0f)
@@ -419,9 +425,9 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
         const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
         bool ma = false, mb = false;
         // (ZF: centres that do not exist carry an infinite slab coordinate, so only DIAG / TAIL need a live mask)
-        na[u] = fast_bin<ORTHO, IMG, ZF, AA>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u], near_t, &ma, zaf,
+        na[u] = fast_bin<ORTHO, IMG, ZF, AA>(hist, sc, la, half_m_guard, nb_hi, uax, uay, uaz, qj[u], qa[u], near_f, &ma, zaf,
                                              clampv, ZF && !DIAG && !TAIL);
-        nb[u] = fast_bin<ORTHO, IMG, ZF, AA>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u], near_t, &mb, zbf,
+        nb[u] = fast_bin<ORTHO, IMG, ZF, AA>(hist, sc, lb, half_m_guard, nb_hi, ubx, uby, ubz, qj[u], qb[u], near_f, &mb, zbf,
                                              clampv, ZF && !DIAG && !TAIL);
         anynear |= ma | mb;
     }
@@ -441,10 +447,7 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
                 const bool la = has_a && (!TAIL || j < cntj) && (!DIAG || j > ia);
                 const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
                 auto is_near = [&](uint32_t ux, uint32_t uy, uint32_t uz) {
-                    const uint32_t ix = q.x - ux, iy = q.y - uy, iz = q.z - uz;
-                    return (near_t[0] != 0x7fffffffu && ix + near_t[0] > 2u * near_t[0]) |
-                           (near_t[1] != 0x7fffffffu && iy + near_t[1] > 2u * near_t[1]) |
-                           (near_t[2] != 0x7fffffffu && iz + near_t[2] > 2u * near_t[2]);
+                    return near_pair(near_f, (int)(q.x - ux), (int)(q.y - uy), (int)(q.z - uz));
                 };
                 auto park = [&](uint32_t idc) {
                     const unsigned slot = atomicAdd(nq_count, 1u);
@@ -577,10 +580,13 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
             for (int k = 0; k < 3; k++) sc64r[k] = uniform_f64(fs->sc64[k]);
         }
         const double *sc64 = ORTHO ? sc64r : fs->sc64;
-        uint32_t near_t[3] = {0x7fffffffu, 0x7fffffffu, 0x7fffffffu};
+        float near_f[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
         if (IMG) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) near_t[k] = __builtin_amdgcn_readfirstlane(fs->near_t[k]);
+            for (int k = 0; k < 3; k++) {
+                const uint32_t tk = __builtin_amdgcn_readfirstlane(fs->near_t[k]);
+                if (tk != 0x7fffffffu) near_f[k] = __uint_as_float(__float_as_uint(__uint2float_rd(tk)) - 1u);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for this step has landed
         __syncthreads();                                    // everyone's has; the previous step is fully consumed
@@ -731,19 +737,19 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                     for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
                         fast_quad<ORTHO, true, true, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
                                                                    half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
-                                                                   idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap, zaf,
+                                                                   idb, p, near_f, gi, nq, &nq_count[step % 3], nq_cap, zaf,
                                                                    zbf, qseg, clampv);
                 } else {
                     int j0 = qb + 4 * wave;
                     for (; j0 < qe_full; j0 += 16)
                         fast_quad<ORTHO, false, false, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
                                                                      half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
-                                                                     idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap,
+                                                                     idb, p, near_f, gi, nq, &nq_count[step % 3], nq_cap,
                                                                      zaf, zbf, qseg, clampv);
                     if (j0 == full && j0 < qe && full < cntj)
                         fast_quad<ORTHO, false, true, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
                                                                     half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
-                                                                    idb, p, near_t, gi, nq, &nq_count[step % 3], nq_cap, zaf,
+                                                                    idb, p, near_f, gi, nq, &nq_count[step % 3], nq_cap, zaf,
                                                                     zbf, qseg, clampv);
                 }
             }
