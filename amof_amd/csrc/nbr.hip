@@ -134,11 +134,11 @@ __global__ __launch_bounds__(CN_TILE) void cn_kernel(NbrArgs a)
 // ------------------------------------------------------------------ BAD ----
 // numpy.histogram with explicit edges: bin k holds edges[k] <= x < edges[k+1],
 // the last bin is right-closed; outside -> -1.
-__device__ __forceinline__ int hist_bin(const double *__restrict__ edges, int nb, double x)
+// (e0, en = first / last edge, inv_w = nb / (en - e0): the first guess only -- the comparisons with the edges decide)
+__device__ __forceinline__ int hist_bin(const double *__restrict__ edges, int nb, double x, double e0, double en, double inv_w)
 {
-    if (!(x >= edges[0]) || !(x <= edges[nb])) return -1;
-    double w = (edges[nb] - edges[0]) / nb;
-    int k = (int)((x - edges[0]) / w);
+    if (!(x >= e0) || !(x <= en)) return -1;
+    int k = (int)((x - e0) * inv_w);
     k = max(0, min(k, nb - 1));
     while (k > 0 && x < edges[k]) k--;
     while (k < nb - 1 && x >= edges[k + 1]) k++;
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
     const int f0 = blockIdx.y * a.frames_per_chunk;
     const int f1 = min(f0 + a.frames_per_chunk, a.F);
     const int nb = a.nb;
+    const double hb_e0 = a.edges[0], hb_en = a.edges[nb], hb_inv_w = (double)nb / (hb_en - hb_e0);   // hist_bin's first guess
     const bool direct = a.cn_max > 0 || a.global_hist;     // straight into global memory (no LDS histogram)
     for (int k = tid; k < nb && !a.global_hist; k += BAD_TILE) hist[k] = 0u;
     unsigned long long nang = 0;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
                 if (dot > 1.0) dot = 1.0;
                 if (dot < -1.0) dot = -1.0;
                 double ang = (180.0 / M_PI) * acos(dot);
-                int k = hist_bin(a.edges, nb, ang);
+                int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w);
                 if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
                     const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
                     atomicAdd(&a.n_angles[slot], 1ull);
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
     const int cnt_c = min(NBRF_TILE, nA - c0);
     const bool has = tid < cnt_c;
     const int nb = a.nb;
+    const double hb_e0 = a.edges[0], hb_en = a.edges[nb], hb_inv_w = (double)nb / (hb_en - hb_e0);   // hist_bin's first guess
     const bool direct = a.cn_max > 0 || a.global_hist;     // straight into global memory (no LDS histogram)
     for (int k = tid; k < nb && !a.global_hist; k += NBRF_TILE) hist[k] = 0u;
     unsigned long long nang = 0;
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
         if (dot > 1.0) dot = 1.0;
         if (dot < -1.0) dot = -1.0;
         const double ang = (180.0 / M_PI) * acos(dot);
-        const int k = hist_bin(a.edges, nb, ang);
+        const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w);
         if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
             const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n_centre, a.cn_max) : (size_t)trip;
             atomicAdd(&a.n_angles[slot], 1ull);
