@@ -5,7 +5,12 @@
 //   rdf_exact      rdf_tile_kernel<ORTHO,EXTRA> / rdf_tile_kernel_global: canonical float64 arithmetic per pair and
 //                  per periodic image; partially periodic cells, large image shares, nbins beyond the LDS histogram
 //   rdf_tile       rdf_tile_kernel_fast<ORTHO,CULL>: 32-bit fixed-point minimum image, f32 candidate bins with an
-//                  exact re-decision near every edge, slab-sorted tiles by LDS-DMA (the headline, half-cell cutoffs)
+//                  exact re-decision near every edge, slab-sorted tiles by LDS-DMA (half-cell cutoffs); general cells
+//                  on the lower-triangular factor of their metric (guard_math.h)
+//   rdf_tile_zf    the same for diagonal cells (the headline): ZF = f32 slab-axis coordinates per step -- the slab-sorted
+//                  axis needs no per-pair wrap (with culling: every visited partner; without: all but the band around
+//                  the sub-tile's antipode) -- and the always-add LDS histogram (every lane adds to its candidate bin,
+//                  out-of-range pairs to trash words, flagged pairs are fixed up by the refinement: no lane masks)
 //   rdf_tile_img   the same with IMG = true: cutoffs beyond half a cell height (sheared cells at the default
 //                  cutoff); pairs within reach of a cell face are parked and evaluated canonically, images included
 //   rdf_range      rdf_range_kernel_fast: 2-level (slab x y-bin) cell list for small cutoffs
