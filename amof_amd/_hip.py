@@ -28,7 +28,7 @@ ABI_VERSION = 2
 
 EXPORTS = [
     "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_destroy", "amof_last_error",
-    "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_ctx_wait_stream", "amof_last_kernel_seconds", "amof_last_kernel_launches",
+    "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_ctx_wait_stream", "amof_ctx_debug_poison", "amof_last_kernel_seconds", "amof_last_kernel_launches",
     "amof_last_path",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_bad_hist_by_cn",
@@ -93,6 +93,7 @@ def load_library():
         lib.amof_ctx_set_stream.argtypes = [P, P]
         lib.amof_ctx_synchronize.argtypes = [P]
         lib.amof_ctx_wait_stream.argtypes = [P, P]
+        lib.amof_ctx_debug_poison.argtypes = [P, ctypes.c_int]
         lib.amof_last_kernel_seconds.argtypes = [P, ctypes.c_int]
         lib.amof_last_kernel_seconds.restype = ctypes.c_double
         lib.amof_last_kernel_launches.argtypes = [P]
@@ -250,6 +251,11 @@ class Context(object):
     @_locked
     def synchronize(self):
         self._check(self._lib.amof_ctx_synchronize(self._h))
+
+    @_locked
+    def debug_poison(self, byte=0xA5):
+        """Test hook: overwrite every scratch buffer the context owns (no call may rely on a previous call's scratch)."""
+        self._check(self._lib.amof_ctx_debug_poison(self._h, int(byte)))
 
     @_locked
     def wait_stream(self, stream_ptr):

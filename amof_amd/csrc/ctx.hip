@@ -379,7 +379,14 @@ const char *amof_last_error(const amof_ctx *ctx) { return ctx ? ctx->err.c_str()
 int amof_ctx_set_stream(amof_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return AMOF_EINVAL;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next != ctx->stream) {
+        // copies out of the pinned staging ring may still be queued on the old stream (an entry point that failed
+        // before its final synchronisation): drain it before the ring is reused from the new one
+        AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        AMOF_HIP_TRY(ctx, sync_stream(ctx));
+        ctx->stream = next;
+    }
     return AMOF_OK;
 }
 
@@ -390,6 +397,18 @@ int amof_ctx_wait_stream(amof_ctx *ctx, void *hip_stream)
     AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     AMOF_HIP_TRY(ctx, hipEventRecord(ctx->ev_order, (hipStream_t)hip_stream));
     AMOF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
+    return AMOF_OK;
+}
+
+int amof_ctx_debug_poison(amof_ctx *ctx, int byte)
+{
+    if (!ctx) return AMOF_EINVAL;
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    for (int s = 0; s < SLOT_COUNT; s++)
+        if (ctx->buf[s].p && ctx->buf[s].cap) AMOF_HIP_TRY(ctx, hipMemsetAsync(ctx->buf[s].p, byte, ctx->buf[s].cap, ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
 

@@ -808,7 +808,8 @@ static int nbr_fast_batch(amof_ctx *ctx, const amof_traj *t, NbrSetup &st, NbrFa
     return AMOF_OK;
 }
 
-static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cutoff, NbrSetup &st, NbrFast &nf)
+static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cutoff, NbrSetup &st, NbrFast &nf,
+                            unsigned long long centre_mask = 0ull)
 {
     const int S = t->n_species;
     const int64_t nc = t->n_cells;
@@ -854,7 +855,9 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     for (int x = 0; x < S && x < 64; x++) {
         bool used = false;
         for (int y = 0; y < S; y++) used |= cutoff[x * S + y] > 0.0 || cutoff[y * S + x] > 0.0;
-        if (used) {
+        // (centre_mask: species the caller queues as centres whatever their cutoffs -- per-atom counts of a
+        //  zero-cutoff set still read the centre's record, which must therefore be sorted)
+        if (used || (centre_mask >> x & 1ull)) {
             nf.used_mask |= 1ull << x;
             nf.max_used_atoms = std::max<int64_t>(nf.max_used_atoms, st.tiles.nsp[x]);
         }
@@ -864,7 +867,7 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     // (R = the largest cutoff), >= 3 per axis, reach 1 -- a centre meets the partners of 27 cells instead of a slab
     // range (ZIF-4 3x3x4, Zn-N at 2.5 A: ~7 candidates per Zn instead of ~930)
     {
-        bool cell_ok = t->n_atoms >= 256 && t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && !getenv("AMOF_NBR_NOCELL");
+        bool cell_ok = t->n_atoms >= 256 && t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && S <= 64 && !getenv("AMOF_NBR_NOCELL");
         for (int x = 0; x < 3; x++) {
             nf.nk[x] = (int)std::min(1024.0, floor(hmin[x] / (R * (1.0 + 1e-5))));
             if (nf.nk[x] < 3) cell_ok = false;
@@ -983,7 +986,11 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
     a.sums = (unsigned long long *)d_sums;
     a.per_atom = (int32_t *)d_pa;
     NbrFast nf;
-    AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf));
+    unsigned long long centre_mask = 0ull;
+    if (per_atom)
+        for (int s2 = 0; s2 < n_sets; s2++)
+            if (sets[2 * s2] < 64) centre_mask |= 1ull << sets[2 * s2];
+    AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf, centre_mask));
     bool done = false;
     if (nf.ok) {
         std::vector<int4> fwork;
@@ -1147,8 +1154,9 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
         if (qflag) {           // atoms absurdly far from the cell: redo with the exact kernel
             AMOF_TRY(clear_scratch());
-        } else if (flags[1]) { // a centre has more than AMOF_MAX_NEIGHBOURS neighbours: big-list pass below
-            overflow = true;
+        } else if (flags[1]) {
+            // a centre has more than NBRF_NLIST neighbours: the exact kernel with its AMOF_MAX_NEIGHBOURS-deep LDS lists
+            // comes next (dense systems with 17..32 neighbours stay in LDS); only if that overflows too, the big-list pass
             AMOF_TRY(clear_scratch());
         } else {
             done = true;

@@ -159,6 +159,11 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_cells_kernel(const dou
         st[c] = (uint32_t)k0 + run;
         run += v;
     }
+    // The neighbour kernels take the upper bound of a species' LAST cell from the entry behind its table, i.e. cell 0 of
+    // the next species (or the closing entry): write it here, because the next species may not be sorted at all (it has
+    // no block when it carries no cutoff) and the table is scratch that nobody clears.  When the next species IS
+    // sorted its block stores the same value (k0' + 0 = k1): a benign same-value race.
+    if (tid == 0) st[ncell] = (uint32_t)k1;
     if (blockIdx.x == gridDim.x - 1 && tid == 0) start3[(size_t)fl * ((size_t)S * ncell + 1) + (size_t)S * ncell] = (uint32_t)N;
     __syncthreads();
     QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;

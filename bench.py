@@ -265,7 +265,20 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--all-on-device", type=int, default=None, help="rehearsal: put every rank on this GPU")
     ap.add_argument("--dump-hist", type=str, default=None, help="rank 0 saves the merged RDF histogram (npy) here")
+    ap.add_argument("--rank-probe", type=int, default=None, metavar="CODE",
+                    help="launcher check (no GPU needed): every rank prints its RANK / WORLD_SIZE and exits with CODE")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): this process becomes the launcher.  It has not touched the
+        # GPU (no torch import yet) and starts the ranks as a CHILD process -- never exec -- relaying their output
+        # (rank 0's JSON line) and the exit code.
+        raise SystemExit(self_launch(args.gpus))
+    if args.rank_probe is not None:
+        print(json.dumps({"probe": True, "rank": int(os.environ.get("RANK", "0")),
+                          "world": int(os.environ.get("WORLD_SIZE", "1")), "gpus": args.gpus,
+                          "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+        raise SystemExit(args.rank_probe)
 
     import torch
     import torch.distributed as dist
@@ -278,8 +291,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it plainly, or with --nproc-per-node %d)"
+                         % (args.gpus, world, args.gpus))
     if args.all_on_device is not None:
         local_rank = args.all_on_device
     torch.cuda.set_device(local_rank)
@@ -524,6 +537,22 @@ def main():
     if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a child process on 127.0.0.1 and a free port; returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def _rdf_range(F, rank, world, strong):

@@ -44,8 +44,9 @@ extern "C" {
 
 /* capacities */
 #define AMOF_MAX_LDS_BINS 36864     /* histogram bins held in LDS per workgroup (u32); more bins: global-memory kernels */
-#define AMOF_MAX_NEIGHBOURS 32      /* neighbours per centre atom the BAD kernels keep in LDS; a centre with more sends
-                                       the call through a second pass with lists in global memory (no error) */
+#define AMOF_MAX_NEIGHBOURS 32      /* neighbours per centre atom the exact BAD kernel keeps in LDS (the fast kernels keep
+                                       16 and hand a call with a fuller centre to the exact kernel); a centre with more
+                                       sends the call through a further pass with lists in global memory (no error) */
 #define AMOF_MAX_IMAGES 4096        /* extra periodic images per frame (AMOF_ECAPACITY when exceeded) */
 
 typedef struct amof_ctx amof_ctx;
@@ -87,6 +88,10 @@ int amof_ctx_synchronize(amof_ctx *ctx);
  * calls this first: the library's kernels otherwise run on the context's non-blocking stream with
  * no ordering against the producer. */
 int amof_ctx_wait_stream(amof_ctx *ctx, void *hip_stream);
+/* Diagnostics for the test-suite: fill every scratch buffer the context currently owns with `byte`
+ * (after a synchronisation).  No call may depend on what a previous call left in scratch; a test
+ * that poisons between calls turns such a dependence into a wrong answer instead of a lucky one. */
+int amof_ctx_debug_poison(amof_ctx *ctx, int byte);
 
 /* Seconds spent inside kernels of the last call, measured with HIP events on
  * the context's stream around the dominant kernel's launches:
@@ -94,9 +99,15 @@ int amof_ctx_wait_stream(amof_ctx *ctx, void *hip_stream);
 double amof_last_kernel_seconds(const amof_ctx *ctx, int which);
 /* number of launches of the dominant kernel in the last call */
 int64_t amof_last_kernel_launches(const amof_ctx *ctx);
-/* kernel family that produced the result of the last call, e.g. "rdf_tile", "rdf_tile_img", "rdf_cell", "rdf_range",
- * "rdf_exact", "cn_fast", "cn_exact", "bad_fast", "bad_exact", "bad_exact_biglist", "msd_comb", "msd_group", "msd_comb_global", "msd_global",
- * "msd_direct" (diagnostics and tests; "" before the first call) */
+/* kernel family that produced the result of the last call (diagnostics and tests; "" before the first call):
+ *   RDF  "rdf_tile_zf" (diagonal cells, f32 slab coordinates), "rdf_tile" (general fast tile kernel),
+ *        "rdf_tile_img" (cutoffs beyond half a cell height), "rdf_cell" (3-D cell list), "rdf_range" (2-level list),
+ *        "rdf_exact" (canonical float64 arithmetic per pair)
+ *   CN   "cn_cell", "cn_fast", "cn_exact"
+ *   BAD  "bad_cell", "bad_fast", "bad_exact", "bad_exact_biglist"
+ *   MSD  "msd_stream" (register-ring comb, window spacing 64..256), "msd_comb" (block comb kernels incl. the
+ *        double-buffered and > 32-window passes), "msd_group" (arbitrary window lists), "msd_comb_global" /
+ *        "msd_global" (series too long for LDS), "msd_direct" */
 const char *amof_last_path(const amof_ctx *ctx);
 
 /*

@@ -55,3 +55,27 @@ def test_two_rank_rehearsal_line():
     # the two ranks' frame shards tile the trajectory
     assert ranks[0]["rdf_frames"][0] == 0 and ranks[0]["rdf_frames"][1] == ranks[1]["rdf_frames"][0]
     assert ranks[1]["rdf_frames"][1] == d["config"]["frames_total"]
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` from a plain shell (the shape of the driver's command): the parent starts the ranks
+    as a child process through torch.distributed.run on 127.0.0.1, relays their output and their exit code.  Checked
+    here without a GPU through --rank-probe (every rank reports RANK / WORLD_SIZE and exits before touching torch)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    ok = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--rank-probe", "0"], env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    probes = [json.loads(l) for l in ok.stdout.splitlines() if l.startswith("{")]
+    assert sorted(p["rank"] for p in probes) == [0, 1]
+    assert all(p["world"] == 2 and p["gpus"] == 2 and p["master_addr"] == "127.0.0.1" for p in probes)
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--rank-probe", "3"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert bad.returncode != 0                      # a failing rank is not swallowed by the launcher
+    # under a launcher with a different world size the mismatch is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    one = subprocess.run([sys.executable, bench, "--gpus", "1", "--rank-probe", "0"], env=env2, capture_output=True,
+                         text=True, timeout=300)
+    assert one.returncode == 0 and json.loads(one.stdout.strip())["world"] == 1

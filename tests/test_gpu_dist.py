@@ -92,3 +92,22 @@ def test_rccl_backend_single_rank(tmp_path):
             got = pd.read_pickle(os.path.join(str(tmp_path), "%s_%s.pkl" % (k, mode)))
             assert list(got.columns) == list(df.columns), k
             np.testing.assert_allclose(got.values, df.values, rtol=1e-12, atol=1e-15)
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's multi-GPU command): the parent
+    must start the two ranks itself (child process, 127.0.0.1), relay rank 0's JSON line and exit 0.  Both ranks share
+    cuda:0 here (gloo rendezvous -- RCCL refuses two ranks per device); the merged result is verified against the
+    oracle by the bench itself."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--all-on-device", "0", "--backend", "gloo",
+           "--frames", "96", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-bad"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    rows = [json.loads(l) for l in run.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(rows) == 1
+    d = rows[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["verified"] is True
+    assert [r["rdf_frames"] for r in d["per_rank"]] == [[0, 48], [48, 96]]

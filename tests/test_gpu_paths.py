@@ -142,6 +142,64 @@ def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
     assert a_ref.sum() > 0
 
 
+@pytest.mark.parametrize("poison", [0x00, 0xA5, 0xFF])
+def test_cell_list_sparse_cutoff_matrix_on_poisoned_scratch(hip_ctx, poison):
+    """a species WITH a cutoff followed, in sorted species order, by one WITHOUT (kinds H, C, N, Zn: 'C-N' alone
+    leaves Zn unsorted behind N; 'C-H' alone leaves N and Zn): the cell kernels take the upper bound of a species'
+    last cell row from the table entry behind it, which the skipped species never writes.  Scratch is poisoned
+    before every call, so a stale or unwritten entry shows (zero: neighbours dropped; large: garbage ranges).
+    Also per-atom counts of a set whose centre species carries no cutoff at all (its records must still be sorted)."""
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (2, 2, 1)), 3, 0.05, 77, ortho=True)
+    kinds, sp = H.species_of(packed.numbers)
+    S = len(kinds)
+    h, c, n, zn = kinds.index(1), kinds.index(6), kinds.index(7), kinds.index(30)
+    assert (h, c, n, zn) == (0, 1, 2, 3)
+    edges = np.arange(int(180 // 0.5) + 2) * 0.5
+    cases = [({(c, n): 1.6}, [(c, n), (n, c), (zn, n), (h, h)], [(c, n), (n, c), (n, -1)]),
+             ({(h, c): 1.3}, [(h, c), (c, h), (zn, zn)], [(c, h), (c, -1)]),
+             ({(n, n): 2.6}, [(n, n), (h, n)], [(n, n)]),
+             ({(h, h): 2.0, (c, c): 1.7}, [(h, h), (c, c), (n, zn)], [(h, h), (c, c), (-1, -1)])]
+    for cut, sets, triples in cases:
+        rcm = np.zeros((S, S))
+        for (x, y), rc in cut.items():
+            rcm[x, y] = rcm[y, x] = rc
+        s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
+        h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
+        with _env(AMOF_NBR_FORCE_CELL="1"):
+            hip_ctx.debug_poison(poison)
+            s_cell, pa_cell = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+            assert hip_ctx.last_path() == "cn_cell"
+            hip_ctx.debug_poison(poison)
+            s_only = hip_ctx.cn_count(packed, rcm, sets)
+            hip_ctx.debug_poison(poison)
+            h_cell, a_cell = hip_ctx.bad_hist(packed, rcm, triples, edges)
+            assert hip_ctx.last_path() == "bad_cell"
+        assert np.array_equal(s_cell, s_ref) and np.array_equal(pa_cell, pa_ref), cut
+        assert np.array_equal(s_only, s_ref), cut
+        assert np.array_equal(a_cell, a_ref) and np.array_equal(h_cell, h_ref), cut
+        assert s_ref.sum() > 0
+
+
+def test_bad_fast_list_overflow_takes_the_lds_exact_kernel_first(hip_ctx):
+    """a centre with 17 .. 32 neighbours overflows the fast kernels' 16-entry lists: the call is redone by the exact
+    kernel with its 32-deep LDS lists ("bad_exact"), not by the count + global big-list passes; beyond 32: big list"""
+    packed = H.random_walk(H.zif4_frame(), 2, 0.05, 78)
+    kinds, sp = H.species_of(packed.numbers)
+    S = len(kinds)
+    edges = np.arange(int(180 // 1.0) + 2) * 1.0
+    sets = [(a, b) for a in range(S) for b in range(S)]
+    for rc, want in ((3.4, "bad_exact"), (5.0, "bad_exact_biglist")):
+        rcm = np.full((S, S), rc)
+        triples = [(-1, -1)]
+        pa = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)[1]
+        most = np.where(pa < 0, 0, pa).sum(axis=1).max()          # fullest centre, all partner species together
+        assert (16 < most <= 32) if want == "bad_exact" else most > 32
+        hb, ab = hip_ctx.bad_hist(packed, rcm, triples, edges)
+        assert hip_ctx.last_path() == want, (rc, hip_ctx.last_path())
+        hr, ar = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
+        assert np.array_equal(ab, ar) and np.array_equal(hb, hr)
+
+
 def test_cell_list_neighbours_on_lattices_and_sheared_cells(hip_ctx):
     """the 3-D cell-list CN / BAD kernels where the cell grid is tight: atoms exactly on cell faces (integer
     lattice, cells a whole number of lattice constants thick), pairs exactly at the cutoff, a strongly sheared
@@ -169,7 +227,8 @@ def test_cell_list_neighbours_on_lattices_and_sheared_cells(hip_ctx):
             assert np.array_equal(s_cell, s_ref) and np.array_equal(pa_cell, pa_ref), (rc, path_cn)
             assert np.array_equal(a_cell, a_ref) and np.array_equal(h_cell, h_ref), (rc, path_bad)
             if np.array_equal(cell, np.diag(np.diag(cell))):
-                assert path_cn == "cn_cell" and path_bad in ("bad_cell", "bad_exact_biglist")
+                # (a centre with 17 .. 32 neighbours sends the call to the exact kernel's LDS lists, beyond that to the big list)
+                assert path_cn == "cn_cell" and path_bad in ("bad_cell", "bad_exact", "bad_exact_biglist")
 
 
 def test_pairs_exactly_at_the_cutoff(hip_ctx):
