@@ -24,7 +24,7 @@ AMOF_ENOMEM = -4
 AMOF_EHIP = -5
 AMOF_ECAPACITY = -6
 AMOF_ENODEVICE = -7
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = [
     "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_destroy", "amof_last_error",
@@ -32,7 +32,7 @@ EXPORTS = [
     "amof_last_path",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_bad_hist_by_cn",
-    "amof_msd_window", "amof_msd_direct",
+    "amof_msd_window", "amof_msd_window_dev", "amof_msd_com_dev", "amof_msd_direct",
     "amof_xyz_scan", "amof_xyz_read", "amof_cp2k_cell_read", "amof_ingest_last_error",
 ]
 
@@ -109,6 +109,9 @@ def load_library():
         lib.amof_bad_hist_by_cn.argtypes = [P, TP, P, P, ctypes.c_int32, P, ctypes.c_int32, ctypes.c_int32, P, P]
         lib.amof_msd_window.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int64, ctypes.c_int64, P]
+        lib.amof_msd_window_dev.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_int64, ctypes.c_int64, P, P]
+        lib.amof_msd_com_dev.argtypes = [P, TP, ctypes.c_int64, ctypes.c_int64, P]
         lib.amof_msd_direct.argtypes = [P, TP, P]
         lib.amof_xyz_scan.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         lib.amof_xyz_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -377,11 +380,42 @@ class Context(object):
         return hist, nang
 
     @_locked
-    def msd_window(self, packed, windows, unwrap=False, remove_com=True, atom_range=None):
-        """``(sumsq [S][W] f64, kinds)``: raw sums of squared displacements."""
+    def msd_com(self, packed, frame_range, out):
+        """centre of mass of frames ``[f0, f1)`` into rows ``f0 .. f1`` of ``out`` (torch CUDA f64 ``[F][3]``); the other
+        rows are left alone (an atom-sharded run: every rank its frame share, then one sum of the zero-filled tables)."""
+        th = self._traj(packed)
+        assert out.is_cuda and out.is_contiguous() and out.numel() == 3 * th.n_frames and out.element_size() == 8
+        assert out.device.index == self.device
+        self._order_after_torch()
+        self._check(self._lib.amof_msd_com_dev(self._h, ctypes.byref(th.c), int(frame_range[0]), int(frame_range[1]),
+                                               ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    @_locked
+    def msd_window(self, packed, windows, unwrap=False, remove_com=True, atom_range=None, com=None, out=None):
+        """``(sumsq [S][W] f64, kinds)``: raw sums of squared displacements.
+
+        ``out``: optional torch CUDA f64 tensor ``[S][W]`` the sums are ADDED into on the device (stays resident for
+        the ranks' all-reduce); ``com``: optional torch CUDA f64 ``[F][3]`` precomputed centre of mass (``msd_com``)."""
         th = self._traj(packed)
         windows = np.ascontiguousarray(windows, dtype=np.int32)
         a0, a1 = (0, th.n_atoms) if atom_range is None else atom_range
+        if out is not None or com is not None:
+            import torch
+            if out is None:
+                out = torch.zeros((th.S, len(windows)), dtype=torch.float64, device=torch.device("cuda", self.device))
+            assert out.is_cuda and out.is_contiguous() and out.numel() == th.S * len(windows) and out.element_size() == 8
+            assert out.device.index == self.device
+            if com is not None:
+                assert com.is_cuda and com.is_contiguous() and com.numel() == 3 * th.n_frames and com.element_size() == 8
+                assert com.device.index == self.device
+            self._order_after_torch()
+            rc = self._lib.amof_msd_window_dev(self._h, ctypes.byref(th.c), ctypes.c_void_p(windows.ctypes.data),
+                                               len(windows), 1 if unwrap else 0, 1 if remove_com else 0, int(a0), int(a1),
+                                               ctypes.c_void_p(com.data_ptr()) if com is not None else None,
+                                               ctypes.c_void_p(out.data_ptr()))
+            self._check(rc)
+            return out, th.kinds
         out = np.zeros((th.S, len(windows)), dtype=np.float64)
         rc = self._lib.amof_msd_window(self._h, ctypes.byref(th.c), ctypes.c_void_p(windows.ctypes.data),
                                        len(windows), 1 if unwrap else 0, 1 if remove_com else 0,

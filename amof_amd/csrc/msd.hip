@@ -854,19 +854,29 @@ __global__ __launch_bounds__(MSD_THREADS) void direct_reduce_kernel(const double
 
 using namespace amof;
 
-extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W,
-                               int32_t unwrap, int32_t remove_com, int64_t atom_begin, int64_t atom_end,
-                               double *sumsq)
+__global__ void add_f64_kernel(double *dst, const double *src, int n)
 {
-    if (!ctx) return AMOF_EINVAL;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// sumsq (host, overwritten) or sumsq_dev (device, accumulated into) receives the [S][W] sums; com_ext: optional
+// precomputed centre of mass of every frame (device [F][3]; frame-sharded ranks compute their rows with
+// amof_msd_com_dev and all-reduce them), not with unwrap (the unwrapped centre of mass is a different quantity)
+static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W, int32_t unwrap,
+                          int32_t remove_com, int64_t atom_begin, int64_t atom_end, const double *com_ext, double *sumsq,
+                          double *sumsq_dev)
+{
     AMOF_TRY(validate_traj(ctx, t, remove_com != 0));
     const int S = t->n_species;
     const int64_t N = t->n_atoms, F = t->n_frames;
-    if (W < 0 || (W > 0 && !windows) || !sumsq) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    if (W < 0 || (W > 0 && !windows) || (!sumsq && !sumsq_dev)) return fail(ctx, AMOF_EINVAL, "NULL argument");
     if (atom_begin < 0 || atom_end > N || atom_begin > atom_end) return fail(ctx, AMOF_EINVAL, "bad atom range");
+    if (com_ext && unwrap) return fail(ctx, AMOF_EINVAL, "a precomputed centre of mass cannot be combined with unwrap");
     for (int w = 0; w < W; w++)
         if (windows[w] < 0 || (F > 0 && windows[w] >= F)) return fail(ctx, AMOF_EINVAL, "window %d out of range", windows[w]);
-    for (int k = 0; k < S * W; k++) sumsq[k] = 0.0;
+    if (sumsq)
+        for (int k = 0; k < S * W; k++) sumsq[k] = 0.0;
     if (F == 0 || N == 0 || W == 0 || atom_begin == atom_end) return AMOF_OK;
     if (F > 0x7fffffffLL) return fail(ctx, AMOF_EINVAL, "too many frames");
     const size_t lds_need = ((size_t)F + (size_t)W) * sizeof(double);
@@ -942,12 +952,12 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
         return hg.all_ortho ? go(delta_transpose_kernel<TF, TA, TH, true>) : go(delta_transpose_kernel<TF, TA, TH, false>);
     };
     if (!unwrap) {
-        if (remove_com) {
+        if (remove_com && !com_ext) {
             hipLaunchKernelGGL(com_kernel, dim3((unsigned)F), dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
                                (const double *)d_mass, N, total_mass, (double *)d_com);
         }
         // only the atoms of this call's range are transposed (atom-sharded ranks each do their share)
-        AMOF_HIP_TRY(ctx, transpose((const double *)d_com, atom_begin, atom_end));
+        AMOF_HIP_TRY(ctx, transpose(remove_com && com_ext ? com_ext : (const double *)d_com, atom_begin, atom_end));
     } else {
         // the unwrapped centre of mass needs every atom: all columns are transposed and scanned
         AMOF_TRY(ensure(ctx, SLOT_AUX4, dt_bytes, &d_UT));
@@ -1086,8 +1096,67 @@ extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t 
     hipLaunchKernelGGL(msd_reduce_kernel, dim3((unsigned)(S * W)), dim3(MSD_THREADS), 0, ctx->stream,
                        (const double *)d_part, (const int32_t *)d_sgf, (int)W, (double *)d_out);
     AMOF_HIP_TRY(ctx, hipGetLastError());
+    if (sumsq_dev) {
+        hipLaunchKernelGGL(add_f64_kernel, dim3((unsigned)((S * W + 255) / 256)), dim3(256), 0, ctx->stream, sumsq_dev,
+                           (const double *)d_out, S * (int)W);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
+    }
     timing_end(ctx);
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(sumsq, d_out, (size_t)S * W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (sumsq)
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(sumsq, d_out, (size_t)S * W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
+    return AMOF_OK;
+}
+
+extern "C" int amof_msd_window(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W,
+                               int32_t unwrap, int32_t remove_com, int64_t atom_begin, int64_t atom_end,
+                               double *sumsq)
+{
+    if (!ctx) return AMOF_EINVAL;
+    if (!sumsq) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    return msd_window_run(ctx, t, windows, W, unwrap, remove_com, atom_begin, atom_end, nullptr, sumsq, nullptr);
+}
+
+extern "C" int amof_msd_window_dev(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W,
+                                   int32_t unwrap, int32_t remove_com, int64_t atom_begin, int64_t atom_end,
+                                   const double *com_dev, double *sumsq_dev)
+{
+    if (!ctx) return AMOF_EINVAL;
+    if (!sumsq_dev) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    return msd_window_run(ctx, t, windows, W, unwrap, remove_com, atom_begin, atom_end, com_dev, nullptr, sumsq_dev);
+}
+
+extern "C" int amof_msd_com_dev(amof_ctx *ctx, const amof_traj *t, int64_t frame_begin, int64_t frame_end, double *com_dev)
+{
+    if (!ctx) return AMOF_EINVAL;
+    AMOF_TRY(validate_traj(ctx, t, true));
+    const int64_t N = t->n_atoms, F = t->n_frames;
+    if (!com_dev) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    if (frame_begin < 0 || frame_end > F || frame_begin > frame_end) return fail(ctx, AMOF_EINVAL, "bad frame range");
+    if (frame_begin == frame_end || N == 0) return AMOF_OK;
+    double total_mass = 0.0;
+    for (int64_t i = 0; i < N; i++) total_mass += t->masses[i];
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    timing_begin(ctx);
+    const double *pos_dev = nullptr;
+    if (t->pos_on_device) {
+        pos_dev = t->pos;
+    } else {        // host input: only the frames of the range travel
+        amof_traj sub = *t;
+        sub.pos = t->pos + (size_t)frame_begin * (size_t)N * 3;
+        sub.n_frames = frame_end - frame_begin;
+        AMOF_TRY(stage_positions(ctx, &sub, &pos_dev));
+        pos_dev -= (size_t)frame_begin * (size_t)N * 3;
+    }
+    void *d_mass;
+    AMOF_TRY(upload(ctx, SLOT_AUX1, t->masses, (size_t)N * sizeof(double), &d_mass));
+    timing_dom_begin(ctx, "msd_com");
+    hipLaunchKernelGGL(com_kernel, dim3((unsigned)(frame_end - frame_begin)), dim3(MSD_THREADS), 0, ctx->stream,
+                       pos_dev + (size_t)frame_begin * (size_t)N * 3, (const double *)d_mass, N, total_mass,
+                       com_dev + 3 * frame_begin);
+    timing_dom_end(ctx, 1);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    timing_end(ctx);
     AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }

@@ -208,6 +208,26 @@ class PackedTrajectory(object):
     def volumes(self):
         return np.abs(np.linalg.det(self.cell))
 
+    def volume_sum(self, frame_range=None):
+        """Sum of the cell volumes over the frames, in the library's own operation order (``csrc/ctx.hip geom_one`` /
+        ``build_geometry``: cofactor expansion along the first row, ``|det|``, added frame by frame -- a constant cell
+        is ADDED once per frame, not multiplied), so that the value equals the ``volume_sum`` of an
+        ``amof_rdf_accumulate`` call over the same frames bit for bit.  A rank of a frame-sharded run computes the
+        whole trajectory's sum here instead of all-reducing partial sums (one collective less, and the mean volume no
+        longer depends on the sharding)."""
+        f0, f1 = (0, self.n_frames) if frame_range is None else frame_range
+        c = self.cell.reshape(self.cell.shape[0], 9)
+        if c.shape[0] > 1:
+            c = c[f0:f1]
+        m00 = c[:, 4] * c[:, 8] - c[:, 5] * c[:, 7]
+        m01 = c[:, 3] * c[:, 8] - c[:, 5] * c[:, 6]
+        m02 = c[:, 3] * c[:, 7] - c[:, 4] * c[:, 6]
+        vol = np.abs(c[:, 0] * m00 - c[:, 1] * m01 + c[:, 2] * m02)
+        if vol.shape[0] == 1:
+            vol = np.full(f1 - f0, vol[0])
+        # np.cumsum adds strictly left to right (np.sum does not: pairwise blocks)
+        return float(np.cumsum(vol)[-1]) if vol.size else 0.0
+
     def pos_host(self):
         if _is_torch_tensor(self.pos):
             return self.pos.detach().cpu().numpy()

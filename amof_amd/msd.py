@@ -145,10 +145,29 @@ class WindowMsd(Msd):
         atom_range = _dist.shard_range(N, rank, world) if merge and distributed != 'local' else (0, N)
         dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
         ctx = _hip.get_context(dev)
-        sumsq, kinds = ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
-                                      atom_range=atom_range)
-        if merge and distributed != 'local':
-            sumsq = _dist.all_reduce_sum(sumsq, device=ctx.device)
+        sharded = merge and distributed != 'local'
+        if sharded and _dist.device_collectives():
+            # atoms are sharded (reference: one joblib worker per element, amof/msd.py:252-256); what every rank would
+            # otherwise repeat -- the centre of mass of EVERY frame from all atoms -- is frame-sharded: each rank fills
+            # its rows of a zeroed [F][3] table, one all-reduce (120 kB at 5000 frames; x + 0 = x, exact) completes it.
+            # The S x W sums stay in HBM from the kernels through their all-reduce.
+            import torch
+            dev = torch.device("cuda", ctx.device)
+            com = None
+            if unwrap != True and packed.on_device:  # noqa: E712  (the unwrapped centre of mass is another quantity)
+                com = torch.zeros((F, 3), dtype=torch.float64, device=dev)
+                ctx.msd_com(packed, _dist.shard_range(F, rank, world), com)
+                _dist.all_reduce_sum(com)
+            out = torch.zeros((len(_hip.packed_species(packed)[0]), len(window)), dtype=torch.float64, device=dev)
+            _, kinds = ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
+                                      atom_range=atom_range, com=com, out=out)
+            _dist.all_reduce_sum(out)
+            sumsq = out.cpu().numpy()
+        else:
+            sumsq, kinds = ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
+                                          atom_range=atom_range)
+            if sharded:
+                sumsq = _dist.all_reduce_sum(sumsq, device=ctx.device)
         self.sumsq = sumsq
         idx = {z: k for k, z in enumerate(kinds)}
 

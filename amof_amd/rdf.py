@@ -112,21 +112,35 @@ class Rdf(object):
         else:
             frame_range = (0, F_local)
         n_frames = frame_range[1] - frame_range[0]
+        sharded = merge and distributed != 'local'
         if merge and _dist.device_collectives():
-            # the histogram stays in HBM from the kernels through the RCCL all-reduce (amof_rdf_accumulate_dev)
+            # the histogram stays in HBM from the kernels through the RCCL all-reduce (amof_rdf_accumulate_dev).  A
+            # frame-sharded run needs ONE collective: every rank holds every cell, so the volume sum of the whole
+            # trajectory is computed locally (PackedTrajectory.volume_sum, the library's own operation order) and the
+            # frame count is known.  Own-block ranks ('local') carry their frame count in a spare word of the same
+            # tensor and all-reduce the float volume sums separately.
             import torch
             S = len(_hip.packed_species(packed)[0])
-            out = torch.zeros((S, S, bins), dtype=torch.int64, device=torch.device("cuda", ctx.device))
+            buf = torch.zeros(S * S * bins + 1, dtype=torch.int64, device=torch.device("cuda", ctx.device))
+            out = buf[:S * S * bins].view(S, S, bins)
             _, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range, out=out)
-            tot = torch.tensor([vol_sum, float(n_frames)], dtype=torch.float64).to(out.device)
-            _dist.all_reduce_sum(out)
-            _dist.all_reduce_sum(tot)
-            hist = out.cpu().numpy().view(np.uint64)
-            tot = tot.cpu().numpy()
-            vol_sum, n_frames = float(tot[0]), int(round(tot[1]))
+            if sharded:
+                _dist.all_reduce_sum(out)
+                vol_sum, n_frames = packed.volume_sum(), F_local
+            else:
+                buf[-1] = n_frames
+                _dist.all_reduce_sum(buf)
+                vol_sum = float(_dist.all_reduce_sum(np.array([vol_sum]), device=ctx.device)[0])
+            host = buf.cpu().numpy()
+            hist = host[:S * S * bins].reshape(S, S, bins).view(np.uint64)
+            if not sharded:
+                n_frames = int(host[-1])
         else:
             hist, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range)
-            if merge:
+            if sharded:
+                hist = _dist.all_reduce_sum(hist, device=ctx.device)
+                vol_sum, n_frames = packed.volume_sum(), F_local
+            elif merge:
                 hist = _dist.all_reduce_sum(hist, device=ctx.device)
                 tot = _dist.all_reduce_sum(np.array([vol_sum, float(n_frames)]), device=ctx.device)
                 vol_sum, n_frames = float(tot[0]), int(round(tot[1]))

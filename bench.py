@@ -409,37 +409,50 @@ def main():
         pairs = f_loc * N * (N - 1) / 2.0                  # unordered pair evaluations per launch
         in_range = float(np.asarray(rdf.hist).sum()) / 2.0 * (f_loc / float(frames_per_step))
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by
-        # profiles/tools/pmc_traffic.py), recorded under profiles/ for this exact workload; null for any other size
+        # profiles/tools/pmc_to_json.py), recorded under profiles/ for this exact workload; null for any other size
         traffic = {}
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and (N, F, world) == (9792, 5000, 1):
             with open(tfile) as fh:
                 traffic = json.load(fh).get("cfg3", {})
-        # the bound that applies to the all-pairs kernel is VALU issue: cycles a SIMD spends per
-        # wave-level pair (64 pairs), measured live; beside it the same quantity predicted from the kernel's own
-        # executed instruction counts (SQ counters) weighted with the per-instruction issue costs measured on the box,
-        # and the share of the pairs the slab culling leaves (geometry, computed here)
+        # The bound that applies to the all-pairs kernel is VALU issue.  roofline_valu prices the kernel's
+        # EXECUTED vector instructions (SQ counters of this very launch shape, profiles/tools/collect_pmc.sh ->
+        # pmc_to_json.py -> profiles/valu_model.json) with the issue cost of each class measured on the box in-kernel
+        # (profiles/tools/ubench2.hip -> profiles/r03/ubench2_valu_issue.txt: 2.19 cycles per wave-instruction and SIMD
+        # for add/mul/fma/int, 4.1 for conversions / fract / compares / min / shift-add, 8.1 for sqrt), against the SIMD
+        # cycles of the LIVE launch (live kernel seconds x the effective clock of the counter run).  Instructions the
+        # counters do not classify are priced all-full-rate (frac) and all-half-rate (frac_high).
         lz = float(np.max(packed.cell_lengths()))
         visited = min(1.0, (2.0 * rmax) / lz + 3.0 / 256.0) if 2.0 * rmax * 1.05 < lz else 1.0
         valu = {"simd_cycles_per_wave_pair_all_pairs": t_rdf * N_SIMD * CLOCK_HZ / (pairs / 64.0),
                 "visited_fraction_geometric": visited,
                 "simd_cycles_per_visited_wave_pair": t_rdf * N_SIMD * CLOCK_HZ / (pairs / 64.0) / visited}
+        roofline_valu = None
         mfile = os.path.join(ROOT, "profiles", "valu_model.json")
         if os.path.exists(mfile) and (N, F, world) == (9792, 5000, 1):
-            # instruction counts of this very launch shape from the SQ counters (profiles/tools/collect_pmc.sh ->
-            # pmc_to_json.py), priced with the issue costs measured on the box, against the LIVE kernel time
             with open(mfile) as fh:
                 model = json.load(fh).get("rdf_tile_kernel_fast")
-            if model:
+            if model and model.get("effective_clock_ghz"):
                 lo, hi = model["valu_issue_cycles_per_simd"]
-                live_cycles = t_rdf * CLOCK_HZ
+                clock = model["effective_clock_ghz"] * 1e9
+                live_cycles = t_rdf * clock
+                valu["simd_cycles_per_visited_wave_pair"] = live_cycles * N_SIMD / (pairs / 64.0) / visited
+                valu["simd_cycles_per_wave_pair_all_pairs"] = live_cycles * N_SIMD / (pairs / 64.0)
                 valu["pmc"] = {"valu_instructions_per_launch": model["valu_instructions_per_launch"],
                                "valu_instructions_per_visited_wave_pair":
                                    model["valu_instructions_per_launch"] / (pairs / 64.0 * visited),
                                "by_class": model["by_class"], "other_valu": model["other_valu"],
                                "lane_utilisation": model["lane_utilisation"],
-                               "issue_slot_utilisation_in_pmc_run": model["issue_slot_utilisation"]}
-                valu["issue_slot_utilisation"] = [lo / live_cycles, hi / live_cycles]
+                               "cycles_per_instruction_used": model["cycles_per_instruction_used"],
+                               "issue_slot_utilisation_in_counter_run": model["issue_slot_utilisation"]}
+                roofline_valu = {
+                    "kernel": model["kernel"], "bound": "valu_issue",
+                    "achieved": lo / t_rdf / 1e9, "peak": clock / 1e9, "unit": "G issue-cycles/s per SIMD",
+                    "frac": lo / live_cycles, "frac_high": min(1.0, hi / live_cycles),
+                    "peak_fp32_vector_tflops": 157.3, "fp32_equivalent_tflops": 157.3 * lo / live_cycles,
+                    "effective_clock_ghz": clock / 1e9, "cost_table": model.get("cost_table"),
+                    "note": "share of the SIMDs' issue cycles the kernel's executed VALU instructions need at their "
+                            "measured per-class issue costs; the rest is LDS / scalar / wait time"}
         msd_bytes = alg_bytes if world == 1 else F * (24 * N + 72)      # every rank reads all frames for the COM
         out = {
             "metric": "frames/s (RDF+MSD, 10k-atom ZIF-4)",
@@ -455,7 +468,10 @@ def main():
                        "parallelism": ("RDF frames sharded x%d + RCCL all-reduce of the u64 histograms in HBM; MSD atoms "
                                        "sharded x%d + all-reduce of the f64 sums" % (world, world)) if strong else
                                       ("own %d-frame block per rank x%d, RCCL all-reduce of the u64 histograms" % (F, world))},
-            "roofline": {"kernel": "rdf_tile_kernel_fast", "bound": "hbm", "achieved": alg_bytes / t_rdf / 1e9,
+            # ("bound" names the roof this block prices against -- the contract's "hbm" | "mfma"; the resource that
+            #  actually limits this kernel is VALU issue: "limited_by", priced in roofline_valu)
+            "roofline": {"kernel": "rdf_tile_kernel_fast", "bound": "hbm", "limited_by": "valu_issue (roofline_valu)",
+                         "achieved": alg_bytes / t_rdf / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / t_rdf / 1e9 / HBM_PEAK_GBPS,
                          "traffic": traffic.get("rdf_tile_kernel_fast"), "launch_seconds": t_rdf,
                          "algorithmic_bytes": alg_bytes, "frames_in_launch": f_loc,
@@ -464,7 +480,7 @@ def main():
                                  "fraction is tiny by construction and north_star's >= 50 % HBM target does not apply "
                                  "to this kernel -- see valu_issue and pair_evals_per_s"},
             "pair_evals_per_s": pairs / t_rdf, "pairs_in_range_per_s": in_range / t_rdf,
-            "valu_issue": valu,
+            "roofline_valu": roofline_valu, "valu_issue": valu,
             "roofline_msd": {"kernel": "msd pipeline (com + delta_transpose + msd_comb + reduce)", "bound": "hbm",
                              "achieved": msd_bytes / mean["msd_all"] / 1e9, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": msd_bytes / mean["msd_all"] / 1e9 / HBM_PEAK_GBPS,

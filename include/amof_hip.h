@@ -40,7 +40,7 @@ extern "C" {
 #define AMOF_ECAPACITY (-6)  /* a documented kernel capacity was exceeded */
 #define AMOF_ENODEVICE (-7)  /* no usable GPU */
 
-#define AMOF_ABI_VERSION 2
+#define AMOF_ABI_VERSION 3
 
 /* capacities */
 #define AMOF_MAX_LDS_BINS 36864     /* histogram bins held in LDS per workgroup (u32); more bins: global-memory kernels */
@@ -193,6 +193,19 @@ int amof_bad_hist_by_cn(amof_ctx *ctx, const amof_traj *traj, const double *cuto
 int amof_msd_window(amof_ctx *ctx, const amof_traj *traj, const int32_t *windows, int32_t n_windows,
                     int32_t unwrap, int32_t remove_com, int64_t atom_begin, int64_t atom_end,
                     double *sumsq /* host [S][W] */);
+/*
+ * The same with the sums ADDED into a device buffer (it stays in HBM for the ranks' all-reduce) and, optionally, the
+ * per-frame centre of mass handed in (com_dev: device [F][3], NULL = computed here from all atoms; not with unwrap).
+ * amof_msd_com_dev writes rows [frame_begin, frame_end) of that table -- masses @ positions / masses.sum() per frame
+ * (ase get_center_of_mass, amof/msd.py:235-237) -- and leaves the others alone: the ranks of an atom-sharded run
+ * each compute the centre of mass of their FRAME share into a zeroed table and sum the tables (x + 0 = x: exact),
+ * instead of every rank reading every frame.  The element-parallel split this stands in for: amof/msd.py:252-256.
+ */
+int amof_msd_window_dev(amof_ctx *ctx, const amof_traj *traj, const int32_t *windows, int32_t n_windows,
+                        int32_t unwrap, int32_t remove_com, int64_t atom_begin, int64_t atom_end,
+                        const double *com_dev /* device [F][3] or NULL */, double *sumsq_dev /* device [S][W], += */);
+int amof_msd_com_dev(amof_ctx *ctx, const amof_traj *traj, int64_t frame_begin, int64_t frame_end,
+                     double *com_dev /* device [F][3] */);
 
 /*
  * Direct MSD with running unwrap, orthogonal cells only (deprecated in the reference).

@@ -1,11 +1,12 @@
 #!/bin/bash
 # Hardware-counter passes for the kernels of every single-GPU config (run on the GPU box, from the repo root):
-#     bash profiles/tools/collect_pmc.sh [out_dir]
+#     bash profiles/tools/collect_pmc.sh [out_dir] ["rdf msd ..."]
 # One rocprofv3 --pmc run per (workload, counter group); counters only -- no tracing domains in the same run.
 # The program follows `--` directly (python3 script): no env/bash wrapper between rocprofv3 and the process
 # that initialises the GPU.  Raw CSVs land under out_dir; profiles/tools/pmc_to_json.py condenses them.
 set -u
-OUT=${1:-gpurun_out/r02/pmc}
+OUT=${1:-gpurun_out/r03/pmc}
+WLS=${2:-rdf msd bad cn cfg4}
 mkdir -p "$OUT"
 export TMPDIR=/tmp RUN_ONCE_REPS=2
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"
@@ -13,7 +14,7 @@ G2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU_CVT SQ_
 G3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 G4="FETCH_SIZE"
 G5="WRITE_SIZE"
-for wl in rdf msd bad cn cfg4; do
+for wl in $WLS; do
   n=0
   for grp in "$G1" "$G2" "$G3" "$G4" "$G5"; do
     n=$((n+1))

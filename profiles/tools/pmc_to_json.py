@@ -1,6 +1,6 @@
 """Condense the raw rocprofv3 --pmc CSVs of profiles/tools/collect_pmc.sh into the JSON files bench.py reads.
 
-    python profiles/tools/pmc_to_json.py gpurun_out/r02/pmc profiles/r02
+    python profiles/tools/pmc_to_json.py gpurun_out/r03/pmc profiles/r03
 
 Writes, next to a per-kernel table of every counter (``pmc_<workload>.json``, mean per launch):
 
@@ -8,10 +8,15 @@ Writes, next to a per-kernel table of every counter (``pmc_<workload>.json``, me
   MI355X_MICROARCH.md (HBM section): FETCH_SIZE is reported in KB and tallies 128-B requests at 64 B -> x 1024 x 2;
   WRITE_SIZE (KB) is taken as is -> x 1024.  Infinity-Cache hits are included in both.
 * ``profiles/valu_model.json`` -- for the all-pairs RDF tile kernel: VALU instructions per launch by class, the issue
-  cycles they need at the per-instruction costs measured on this box (profiles/r01/ubench_valu_issue.txt), and the
-  share of the kernel's SIMD cycles that is (issue-slot utilisation).  Instructions outside the counted classes
-  (moves, selects, compares, fract, shifts) are priced twice: at the full rate and at the compare rate -- a low and a
-  high figure.  Kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs).
+  cycles they need at the per-instruction costs measured on this box, and the share of the kernel's SIMD cycles that is
+  (issue-slot utilisation).  Costs: ``profiles/r03/ubench2_valu_issue.txt`` (profiles/tools/ubench2.hip: >= 15 ms
+  kernels, cycles from s_memtime per SIMD, 8 waves resident on every SIMD -- 2.19 cycles for the full-rate classes,
+  4.1 for conversions / fract / compares / min / shift-add, 8.1 for sqrt; round 2 priced with a table that carried a
+  fixed launch offset and came out above 1).  Instructions outside the counted classes (min, fract, compares,
+  selects, moves, lane reads/writes) are priced twice: all at the full rate and all at the half rate -- a low and a
+  high figure.  Kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs); the kernel's duration in
+  the same counter run (dispatch timestamps of the CSV) gives the effective clock, with which bench.py turns its
+  LIVE kernel time into cycles.
 """
 import csv
 import glob
@@ -48,17 +53,20 @@ def load(workload):
                 if "amof" not in name:
                     continue
                 acc[short(name)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if row.get("Start_Timestamp") and row.get("End_Timestamp") and row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    acc[short(name)]["_duration_ns"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
     # the first launch of a run includes cold caches; every run does RUN_ONCE_REPS identical calls: keep the mean
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"launches_seen": max(len(v) for v in cs.values())}
             for k, cs in acc.items()}
 
 
-# issue cycles per wave instruction, measured (profiles/r01/ubench_valu_issue.txt, cycles @ 2.4 GHz)
+# issue cycles per wave instruction and SIMD, measured in-kernel (profiles/r03/ubench2_valu_issue.txt; first table
+# only: the occupancy rows further down repeat two names)
 UB = {}
-with open(os.path.join(root, "profiles", "r01", "ubench_valu_issue.txt")) as fh:
+with open(os.path.join(root, "profiles", "r03", "ubench2_valu_issue.txt")) as fh:
     for line in fh:
-        m = re.match(r"(\w+)\s+.*=\s*([\d.]+) cycles", line)
-        if m:
+        m = re.match(r"(\w+)\s+1024 SIMDs, 8\.\.8 waves each.*cycles/wave-instr/SIMD\s+([\d.]+)", line)
+        if m and m.group(1) not in UB:
             UB[m.group(1)] = float(m.group(2))
 
 os.makedirs(dst, exist_ok=True)
@@ -112,18 +120,25 @@ for wl, prefix in (("rdf", "rdf_tile_kernel_fast"), ("cfg4", "rdf_cell_kernel"))
                "f64": c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
                       c.get("SQ_INSTS_VALU_FMA_F64", 0.0)}
         other = c["SQ_INSTS_VALU"] - sum(cls.values())
+        # int32: the chain's own mix is two full-rate v_sub_u32 per half-rate v_lshl_add_u32; priced low / high like "other"
         cost = {"cvt": UB["k_cvt_f32_i32"], "trans_f32": UB["k_sqrt32"], "add_f32": UB["k_add32"],
                 "mul_f32": UB["k_mul32"], "fma_f32": UB["k_fma32"], "int32": UB["k_subu32"], "f64": UB["k_add64"]}
         known = sum(cls[x] * cost[x] for x in cls)
-        issue_lo = known + max(other, 0.0) * UB["k_mul32"]       # the remainder at the full rate ...
-        issue_hi = known + max(other, 0.0) * UB["k_cmp32"]       # ... or all of it at the compare / fract rate
+        issue_lo = known + max(other, 0.0) * UB["k_mul32"]       # the remainder (and every int32) at the full rate ...
+        issue_hi = known + max(other, 0.0) * UB["k_rwlane"] + cls["int32"] * (UB["k_lshladd"] - UB["k_subu32"]) / 3.0
+        # ... or all of it at the half rate (min / fract / compare / select / lane moves), a third of int32 as shift-adds
         gui = c.get("GRBM_GUI_ACTIVE")
         cyc = gui / N_XCC if gui else None
+        dur = c.get("_duration_ns")
         model[prefix] = {
             "kernel": k, "valu_instructions_per_launch": c["SQ_INSTS_VALU"], "by_class": cls, "other_valu": other,
-            "cycles_per_instruction_used": dict(cost, other_low=UB["k_mul32"], other_high=UB["k_cmp32"]),
+            "cycles_per_instruction_used": dict(cost, other_low=UB["k_mul32"], other_high=UB["k_rwlane"],
+                                                int32_shift_add=UB["k_lshladd"]),
+            "cost_table": "profiles/r03/ubench2_valu_issue.txt",
             "valu_issue_cycles_per_simd": [issue_lo / N_SIMD, issue_hi / N_SIMD],
             "kernel_cycles": cyc,
+            "kernel_seconds_in_counter_run": dur * 1e-9 if dur else None,
+            "effective_clock_ghz": (cyc / dur) if (cyc and dur) else None,
             "issue_slot_utilisation": [issue_lo / N_SIMD / cyc, issue_hi / N_SIMD / cyc] if cyc else None,
             "lane_utilisation": (c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0))
                                 if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU") else None,

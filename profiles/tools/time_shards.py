@@ -4,6 +4,11 @@ For N in 1, 2, 4, 8: the first rank's shard of the 5000-frame, 9792-atom traject
 BAD, atoms [0, 9792/N) for MSD -- through the C ABI, kernel seconds (HIP events inside the library) beside wall
 seconds of the call.  The per-call host cost (wall - kernels) is what decides whether 8 GPUs reach >= 7x.
 
+The second table runs the PUBLIC CLASSES as rank 0 of an N-way job: a one-rank RCCL group is initialised
+(AMOF_DIST_FORCE_MERGE=1, so every collective of the N > 1 path is really issued -- in a one-rank group, i.e. without
+the wire time of 7 peers) and ``amof_amd.dist.world`` is patched to answer (0, N), so the classes shard exactly as the
+first rank of N would: host work, device-side merge buffers, collectives' launch cost and DataFrame assembly included.
+
     python profiles/tools/time_shards.py [frames]
 """
 import os
@@ -56,8 +61,36 @@ for n in (1, 2, 4, 8):
     print("%6d  %8.3f  %8.3f | %8.3f  %8.3f | %8.3f  %8.3f | %8.3f   %.2fx" %
           (n, 1e3 * r[0], 1e3 * r[1], 1e3 * b[0], 1e3 * b[1], 1e3 * m[0], 1e3 * m[1], 1e3 * tot, base / tot))
 
-# the same through the public classes (adds the Python / pandas post-processing)
+# the public classes as rank 0 of N (see the header): RDF + MSD per step is the bench's `value`, + BAD is configs[3]
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29541")
+os.environ["AMOF_DIST_FORCE_MERGE"] = "1"
+import torch.distributed as tdist                           # noqa: E402
+from amof_amd import dist as adist                          # noqa: E402
 from amof_amd.rdf import Rdf                                # noqa: E402
+from amof_amd.msd import WindowMsd                          # noqa: E402
+from amof_amd.bad import Bad                                # noqa: E402
+torch.cuda.set_device(0)
+tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+real_world = adist.world
+print("classes as rank 0 of N (one-rank RCCL group): wall ms per call, best of 5")
+print("N_gpus  Rdf_wall  Msd_wall  Bad_wall | rdf+msd   speedup_vs_1 | rdf+msd+bad  speedup_vs_1")
+base2 = base3 = None
+for n in (1, 2, 4, 8):
+    adist.world = (lambda group=None, n=n: (0, n)) if n > 1 else real_world
+    r = timed(lambda: Rdf.from_trajectory(packed, device=0, distributed=None), reps=5)
+    m = timed(lambda: WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=0, distributed=None), reps=5)
+    b = timed(lambda: Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=0, distributed=None), reps=5)
+    t2, t3 = r[0] + m[0], r[0] + m[0] + b[0]
+    base2, base3 = base2 or t2, base3 or t3
+    print("%6d  %8.3f  %8.3f  %8.3f | %8.3f   %.2fx        | %8.3f     %.2fx" %
+          (n, 1e3 * r[0], 1e3 * m[0], 1e3 * b[0], 1e3 * t2, base2 / t2, 1e3 * t3, base3 / t3))
+adist.world = real_world
+tdist.destroy_process_group()
+os.environ.pop("AMOF_DIST_FORCE_MERGE")
+
+# single-process classes (no merge path): kernels vs host share
+from amof_amd.rdf import Rdf                                # noqa: E402,F811
 from amof_amd.msd import WindowMsd                          # noqa: E402
 from amof_amd.bad import Bad                                # noqa: E402
 for name, fn in (("Rdf", lambda: Rdf.from_trajectory(packed, device=0, distributed=False)),

@@ -400,6 +400,36 @@ def test_msd_comb_kernel_equals_generic_and_oracle(hip_ctx, F, d, W):
         np.testing.assert_allclose(got, r, rtol=1e-9, atol=1e-12)
 
 
+def test_msd_device_side_merge_entry_points(hip_ctx):
+    """amof_msd_com_dev + amof_msd_window_dev (what an atom-sharded RCCL run uses): the centre of mass filled in by
+    frame shares into a zeroed table, the sums of two atom shares accumulated in a device buffer -- the same kernels as
+    the plain call, so the same bits; a precomputed centre of mass is refused together with unwrap; volume_sum of the
+    host restatement equals the library's."""
+    import torch
+    packed = H.random_walk(H.zif4_frame(), 600, 0.08, 91, cell_jitter=0.004)
+    dev = packed.to_device(0)
+    window = np.arange(0, 300, 64, dtype=np.int32)
+    F, N = packed.n_frames, packed.n_atoms
+    whole, kinds = hip_ctx.msd_window(dev, window)
+    halves = [hip_ctx.msd_window(dev, window, atom_range=r)[0] for r in ((0, 100), (100, N))]
+    com = torch.zeros((F, 3), dtype=torch.float64, device="cuda:0")
+    for r in ((0, 7), (7, 311), (311, F)):
+        hip_ctx.msd_com(dev, r, com)
+    m = packed.masses
+    np.testing.assert_allclose(com.cpu().numpy(), (packed.pos * m[None, :, None]).sum(axis=1) / m.sum(), rtol=1e-13)
+    out = torch.zeros((len(kinds), len(window)), dtype=torch.float64, device="cuda:0")
+    for r in ((0, 100), (100, N)):
+        hip_ctx.msd_window(dev, window, atom_range=r, com=com, out=out)
+    assert np.array_equal(out.cpu().numpy(), halves[0] + halves[1])
+    np.testing.assert_allclose(out.cpu().numpy(), whole, rtol=1e-12)
+    with pytest.raises(ValueError):
+        hip_ctx.msd_window(dev, window, unwrap=True, com=com, out=out)
+    # the frame-sharded RDF's host-side volume sum is the library's own, bit for bit
+    for fr in ((0, F), (13, 402)):
+        _, vol, _ = hip_ctx.rdf_accumulate(packed, 3.0, 30, frame_range=fr)
+        assert vol == packed.volume_sum(fr)
+
+
 def test_threads_shared_and_separate_contexts(hip_ctx):
     # a Context serialises its callers; two Contexts (own streams and scratch) run concurrently
     import threading

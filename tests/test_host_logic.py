@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.amof_abi_version() == 2
+    assert lib.amof_abi_version() == 3
 
 
 def test_struct_layout_matches_header():
@@ -214,3 +214,24 @@ def test_pack_trajectory_of_ase_shaped_objects():
     assert again.pbc.all() and again.formula_count() == atoms[0].symbols.formula._count
     const = pack_trajectory(H.as_ase_like(H.random_walk(H.zif4_frame(), 3, 0.05, 4)))
     assert const.cell.shape == (1, 3, 3)                     # identical cells collapse to one record
+
+
+def test_volume_sum_is_the_librarys_sum_bit_for_bit():
+    """PackedTrajectory.volume_sum restates csrc/ctx.hip build_geometry (|det| by cofactors along the first row, added
+    frame by frame); the oracle's geom_make follows the same sequence, so its volume_sum must agree to the last bit --
+    for changing (sheared, jittered) cells, for a constant cell added thousands of times, and for frame sub-ranges.
+    A frame-sharded RDF relies on it instead of all-reducing the ranks' partial float sums."""
+    from oracle import clib
+    rng = np.random.default_rng(5)
+    base = np.array([[15.4231, 0, 0], [-0.0001882, 15.4042, 0], [-0.00057924, -0.00012873, 18.43789999]])
+    cells = base[None] * (1.0 + 0.01 * rng.standard_normal((257, 1, 1))) + 0.3 * rng.standard_normal((257, 3, 3))
+    pos = rng.random((257, 2, 3))
+    for cell, F in ((cells, 257), (base, 257), (cells[:1], 1), (np.diag([46.2693, 46.2126, 73.7516]), 4999)):
+        p = np.ascontiguousarray(np.broadcast_to(pos[:1], (F, 2, 3)))
+        packed = PackedTrajectory(p, cell, [1, 1])
+        _, vol = clib.rdf_hist(p, packed.cell, np.zeros(2, np.int32), 1, 0.5, 5)
+        assert packed.volume_sum() == vol
+        if packed.cell.shape[0] > 1:
+            _, vol2 = clib.rdf_hist(p[31:200], packed.cell[31:200], np.zeros(2, np.int32), 1, 0.5, 5)
+            assert packed.volume_sum((31, 200)) == vol2
+    assert PackedTrajectory(pos[:0], base, [1, 1]).volume_sum() == 0.0
