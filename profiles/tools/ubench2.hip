@@ -164,6 +164,43 @@ __global__ __launch_bounds__(1024) void k_cmp32_sgpr(float *out, Stamp *st, int 
     STAMP_END
     out[blockIdx.x * 1024 + threadIdx.x] = (float)(m0 + m1 + m2 + m3);
 }
+// the fixed-point bin form's compare: 16-bit, as SDWA (what the compiler emits) and as v_cmp_lt_u16
+__global__ __launch_bounds__(1024) void k_cmp_sdwa(float *out, Stamp *st, int n)
+{
+    unsigned a0 = threadIdx.x * 977u;
+    unsigned b = 77u;
+    asm volatile("s_mov_b32 %0, %0" : "+s"(b));
+    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    STAMP_BEGIN
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int u_ = 0; u_ < 8; u_++)
+            asm volatile("v_cmp_lt_u32_sdwa %0, %4, %5 src0_sel:WORD_0 src1_sel:DWORD\n v_cmp_lt_u32_sdwa %1, %4, %5 src0_sel:WORD_0 src1_sel:DWORD\n"
+                         "v_cmp_lt_u32_sdwa %2, %4, %5 src0_sel:WORD_0 src1_sel:DWORD\n v_cmp_lt_u32_sdwa %3, %4, %5 src0_sel:WORD_0 src1_sel:DWORD\n"
+                         "v_cmp_lt_u32_sdwa %0, %4, %5 src0_sel:WORD_0 src1_sel:DWORD\n v_cmp_lt_u32_sdwa %1, %4, %5 src0_sel:WORD_0 src1_sel:DWORD\n"
+                         "v_cmp_lt_u32_sdwa %2, %4, %5 src0_sel:WORD_0 src1_sel:DWORD\n v_cmp_lt_u32_sdwa %3, %4, %5 src0_sel:WORD_0 src1_sel:DWORD\n"
+                         : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "s"(b));
+    }
+    STAMP_END
+    out[blockIdx.x * 1024 + threadIdx.x] = (float)(m0 + m1 + m2 + m3);
+}
+__global__ __launch_bounds__(1024) void k_cmp_u16(float *out, Stamp *st, int n)
+{
+    unsigned a0 = threadIdx.x * 977u;
+    unsigned b = 77u;
+    asm volatile("s_mov_b32 %0, %0" : "+s"(b));
+    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    STAMP_BEGIN
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int u_ = 0; u_ < 8; u_++)
+            asm volatile("v_cmp_lt_u16_e64 %0, %4, %5\n v_cmp_lt_u16_e64 %1, %4, %5\n v_cmp_lt_u16_e64 %2, %4, %5\n v_cmp_lt_u16_e64 %3, %4, %5\n"
+                         "v_cmp_lt_u16_e64 %0, %4, %5\n v_cmp_lt_u16_e64 %1, %4, %5\n v_cmp_lt_u16_e64 %2, %4, %5\n v_cmp_lt_u16_e64 %3, %4, %5\n"
+                         : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "s"(b));
+    }
+    STAMP_END
+    out[blockIdx.x * 1024 + threadIdx.x] = (float)(m0 + m1 + m2 + m3);
+}
 __global__ __launch_bounds__(1024) void k_cndmask(float *out, Stamp *st, int n)
 {
     float a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7, b = 3;
@@ -312,7 +349,7 @@ int main(int argc, char **argv)
     printf("# candidates for cheaper forms of the half-rate steps\n");
     R(k_max32, 4); R(k_med3, 4); R(k_minu32, 2); R(k_mini32, 2); R(k_lshr, 4); R(k_ashr, 4); R(k_bfe, 4); R(k_or, 2); R(k_xor, 2);
     R(k_addu32, 2); R(k_add3, 2); R(k_madu24, 4); R(k_mulu24, 4); R(k_and_or, 2); R(k_perm, 4); R(k_ldexp, 4); R(k_cvt_u32_f32, 4);
-    R(k_trunc32, 4); R(k_mul_legacy, 2);
+    R(k_trunc32, 4); R(k_mul_legacy, 2); R(k_cmp_sdwa, 4); R(k_cmp_u16, 4);
     printf("# occupancy: 256 workgroups of 64 x wps x 4 threads with 100 KiB LDS = one per CU, wps waves per SIMD\n");
     for (int wps : {1, 2, 4}) {
         run("k_mul32", k_mul32, out, d_st, 256, 256 * wps, 100 * 1024, 64.0, iters_for(wps >= 4 ? 2.0 : 8.0 / wps, 64.0, wps));
