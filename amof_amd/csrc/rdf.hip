@@ -1385,6 +1385,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                                              (size_t)(2 * nkeys + 1) * sizeof(uint32_t);
                     int64_t FB3 = std::max<int64_t>(1, (int64_t)(1ll << 30) / (int64_t)per_frame);
                     FB3 = std::min<int64_t>(std::min<int64_t>(FB3, 32768), t->n_frames);
+                    // (tests cross a frame-batch boundary without gigabytes of frames)
+                    if (const char *be = getenv("AMOF_RDF_BATCH")) FB3 = std::min<int64_t>(FB3, std::max(1, atoi(be)));
                     AMOF_TRY(ensure(ctx, SLOT_AUX1, (size_t)FB3 * t->n_atoms * sizeof(QAtom), &d_Q3));
                     AMOF_TRY(ensure(ctx, SLOT_AUX7, (size_t)FB3 * (nkeys + 1) * sizeof(uint32_t), &d_start3));
                     AMOF_TRY(ensure(ctx, SLOT_AUX6, (size_t)FB3 * t->n_atoms * sizeof(uint32_t), &d_keys));

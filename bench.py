@@ -169,8 +169,31 @@ def verify(packed, ctx, rdf, msd, frames):
     return out
 
 
-def supplementary(device, local_rank, ctx):
-    """The other single-GPU configs of BASELINE.json, timed by the same process (never `value`)."""
+def verify_rdf_timed(ctx, packed, rmax, nb, timed_hist, frames):
+    """Tie a TIMED RDF histogram to the oracle: for every sampled frame k,  H[0,k) + oracle(k) + H[k+1,F) must equal
+    the timed histogram bit for bit (the partial launches run at the leg's own launch geometry)."""
+    from oracle import clib
+    from tests import helpers as H
+    import torch
+    F = packed.n_frames
+    kinds, sp = H.species_of(packed.numbers)
+    pos_s = packed.pos[torch.as_tensor(np.asarray(frames), device=packed.pos.device)].cpu().numpy()
+    timed = np.asarray(timed_hist).view(np.uint64)
+    ok = True
+    for q, k in enumerate(frames):
+        cell_k = packed.cell if packed.cell.shape[0] == 1 else packed.cell[k:k + 1]
+        acc, _ = clib.rdf_hist(pos_s[q:q + 1], cell_k, sp, len(kinds), rmax, nb, cell_list=True)
+        if k > 0:
+            acc = acc + ctx.rdf_accumulate(packed, rmax, nb, frame_range=(0, k))[0]
+        if k + 1 < F:
+            acc = acc + ctx.rdf_accumulate(packed, rmax, nb, frame_range=(k + 1, F))[0]
+        ok = ok and bool(np.array_equal(acc, timed))
+    return ok
+
+
+def supplementary(device, local_rank, ctx, do_verify=True):
+    """The other single-GPU configs of BASELINE.json, timed by the same process (never `value`); each leg's timed
+    result is tied to the oracle afterwards (`verified`), like the headline's."""
     import torch
     from amof_amd.rdf import Rdf
     from amof_amd.cn import CoordinationNumber
@@ -203,6 +226,24 @@ def supplementary(device, local_rank, ctx):
                         "frac": alg1 / k_c / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg1},
         "cn_first_frame": float(c1.data['Zn-N'].values[0]),
     }
+    if do_verify:
+        try:
+            from oracle import clib
+            from amof_amd import atom as amatom
+            ok_rdf = verify_rdf_timed(ctx, p1, r1.rmax, len(r1.data), r1.hist, [0, 499, 999])
+            kinds1, sp1 = H.species_of(p1.numbers)
+            rcm = amatom.cutoff_matrix(amatom.format_cutoff({'Zn-N': 2.5}), kinds1)
+            zn, n = kinds1.index(30), kinds1.index(7)
+            pick = [0, 333, 999]
+            pos_c = p1.pos[torch.as_tensor(pick, device=p1.pos.device)].cpu().numpy()
+            sums = clib.cn_counts(pos_c, p1.cell, sp1, len(kinds1), rcm, [(zn, n)])
+            n_zn = int((p1.numbers == 30).sum())
+            ok_cn = bool(np.array_equal(sums[:, 0] / n_zn, c1.data['Zn-N'].values[pick]))
+            out["configs1"]["verification"] = {"rdf_frames": [0, 499, 999], "rdf": ok_rdf, "cn_frames": pick, "cn": ok_cn}
+            out["configs1"]["verified"] = bool(ok_rdf and ok_cn)
+        except Exception as exc:
+            out["configs1"]["verification"] = {"error": repr(exc)}
+            out["configs1"]["verified"] = False
     del p1, r1, c1
     # configs[4]: 7x7x8 = 106 624 atoms in a sheared cell, 2000 frames (5.1 GB), cell-list RDF at rmax = 10 A
     base = H.replicate(H.zif4_frame(), (7, 7, 8))
@@ -242,7 +283,20 @@ def supplementary(device, local_rank, ctx):
         "roofline": {"kernel": path4, "bound": "hbm", "achieved": alg4 / k4_dom / 1e9, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": alg4 / k4_dom / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg4,
                      "incl_cell_sort_frac": alg4 / k4_all / 1e9 / HBM_PEAK_GBPS},
+        "kernel_launches": int(ctx.last_kernel_launches()),
     }
+    if do_verify:
+        try:
+            # (the partial launches [0, k) and [k+1, F) cut the frame batches -- 1 GiB of sorted scratch each -- elsewhere
+            #  than the timed launch did: a batch-boundary error would break the identity; tests/test_gpu_large.py
+            #  pins the frames either side of a boundary explicitly)
+            frames4 = [0, F4 // 3 + 1, F4 - 1]
+            ok4 = verify_rdf_timed(ctx, p4, r4.rmax, len(r4.data), r4.hist, frames4)
+            out["configs4"]["verification"] = {"rdf_frames": frames4, "rdf": ok4}
+            out["configs4"]["verified"] = bool(ok4)
+        except Exception as exc:
+            out["configs4"]["verification"] = {"error": repr(exc)}
+            out["configs4"]["verified"] = False
     del p4, r4, pos4
     torch.cuda.empty_cache()
     return out
@@ -546,7 +600,7 @@ def main():
             del packed
             torch.cuda.empty_cache()
             try:
-                out["supplementary"] = supplementary(device, local_rank, ctx)
+                out["supplementary"] = supplementary(device, local_rank, ctx, do_verify=not args.no_verify)
             except Exception as exc:
                 out["supplementary"] = {"error": repr(exc)}
         print(json.dumps(out))

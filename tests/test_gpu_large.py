@@ -1,5 +1,6 @@
 """BASELINE configs[4]-shaped case: ~100k atoms, sheared (triclinic) cell, rmax = 10 A."""
 
+import os
 import time
 
 import numpy as np
@@ -35,3 +36,40 @@ def test_cfg5_100k_triclinic_rdf(hip_ctx):
     # g(r) -> N_b / N at large r for partials normalised with the total density
     tail = rdf.data["X-X"].values[-50:].mean()
     assert 0.9 < tail < 1.1
+
+
+def test_cfg5_device_resident_launch_across_frame_batches(hip_ctx):
+    """configs[4] as the bench runs it: 106 624 atoms in a sheared cell, device resident, the 3-D cell-list kernel over
+    SEVERAL frame batches (the bench's 2000 frames = 5.1 GB take five 1-GiB-of-scratch batches; here AMOF_RDF_BATCH
+    cuts 20 frames into 8 + 8 + 4 so that boundaries are crossed without gigabytes).  The frames either side of the
+    first boundary are tied to the oracle by leave-one-out on the whole launch (H[0,k) + oracle(k) + H[k+1,F) ==
+    H[0,F)), the blocks add up, and the batched launch equals the unbatched one."""
+    import torch
+    base = H.replicate(H.zif4_frame(), (7, 7, 8))
+    shear = np.eye(3) + np.array([[0, 0.15, 0.10], [0, 0, 0.20], [0, 0, 0]])
+    sheared = Frame(base.numbers, base.positions @ shear, base.cell @ shear)
+    F = 20
+    host = H.random_walk(sheared, F, 0.05, 52)
+    packed = PackedTrajectory(torch.as_tensor(host.pos).to("cuda:0"), host.cell, host.numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    whole, _, _ = hip_ctx.rdf_accumulate(packed, 10.0, 999)            # one batch
+    assert hip_ctx.last_path() == "rdf_cell"
+    old = os.environ.get("AMOF_RDF_BATCH")
+    os.environ["AMOF_RDF_BATCH"] = "8"
+    try:
+        batched, _, _ = hip_ctx.rdf_accumulate(packed, 10.0, 999)
+        assert hip_ctx.last_path() == "rdf_cell" and hip_ctx.last_kernel_launches() == 3
+        assert np.array_equal(batched, whole)
+        for k in (7, 8):
+            ref, _ = clib.rdf_hist(host.pos[k:k + 1], host.cell, sp, 4, 10.0, 999, cell_list=True)
+            acc = ref + hip_ctx.rdf_accumulate(packed, 10.0, 999, frame_range=(0, k))[0] + \
+                hip_ctx.rdf_accumulate(packed, 10.0, 999, frame_range=(k + 1, F))[0]
+            assert np.array_equal(acc, batched), k
+        parts = hip_ctx.rdf_accumulate(packed, 10.0, 999, frame_range=(0, 8))[0] + \
+            hip_ctx.rdf_accumulate(packed, 10.0, 999, frame_range=(8, F))[0]
+        assert np.array_equal(parts, batched)
+    finally:
+        if old is None:
+            os.environ.pop("AMOF_RDF_BATCH", None)
+        else:
+            os.environ["AMOF_RDF_BATCH"] = old
