@@ -122,6 +122,31 @@ def angles(pos, cell, species, S, rcm, A, B, pbc=(True, True, True)):
     return np.array(out)
 
 
+def angles_of_triples(pos, cell, triples):
+    """ase.Atoms.get_angles(triples, mic=True) ([3P-memory] of ase 3.20.1, assumption A6): the angle at triples[:, 1]
+    between the minimum-image vectors to triples[:, 0] and triples[:, 2], degrees; the minimum image is searched over
+    the 27 neighbouring lattice translations of the rounded fractional difference."""
+    pos, cell, triples = np.asarray(pos, float), np.asarray(cell, float), np.asarray(triples, int)
+
+    def mic(v):
+        s = np.linalg.solve(cell.T, v.T).T
+        s -= np.round(s)
+        best = s @ cell
+        bestn = (best ** 2).sum(axis=1)
+        for n in np.ndindex(3, 3, 3):
+            cand = s @ cell + (np.array(n) - 1) @ cell
+            cn = (cand ** 2).sum(axis=1)
+            better = cn < bestn - 1e-12
+            best[better], bestn[better] = cand[better], cn[better]
+        return best
+
+    v1 = mic(pos[triples[:, 0]] - pos[triples[:, 1]])
+    v2 = mic(pos[triples[:, 2]] - pos[triples[:, 1]])
+    v1 /= np.linalg.norm(v1, axis=1)[:, None]
+    v2 /= np.linalg.norm(v2, axis=1)[:, None]
+    return 180.0 / np.pi * np.arccos(np.einsum('ij,ij->i', v1, v2).clip(-1.0, 1.0))
+
+
 # --------------------------------------------------------------------------
 # group 2: MSD path (reference-owned numpy, restated)
 # --------------------------------------------------------------------------

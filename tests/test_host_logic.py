@@ -235,3 +235,23 @@ def test_volume_sum_is_the_librarys_sum_bit_for_bit():
             _, vol2 = clib.rdf_hist(p[31:200], packed.cell[31:200], np.zeros(2, np.int32), 1, 0.5, 5)
             assert packed.volume_sum((31, 200)) == vol2
     assert PackedTrajectory(pos[:0], base, [1, 1]).volume_sum() == 0.0
+
+
+def test_rdf_shell_switch(monkeypatch):
+    """AMOF_RDF_SHELL: midpoint shell 4 pi r^2 dr (default) or the exact shell volume (4 pi / 3)(r_hi^3 - r_lo^3) --
+    assumption A1 about asap3's get_rdf, made a visible switch because it cannot be settled here."""
+    from amof_amd.rdf import normalize_rdf, normalize_rdf_shell
+    hist = np.arange(1, 51, dtype=np.uint64) * 1000
+    args = (hist, 4 * 272.0, 272, 4380.486, 5.0, 50)
+    mid = normalize_rdf(*args)
+    monkeypatch.setenv("AMOF_RDF_SHELL", "exact")
+    exact = normalize_rdf(*args)
+    monkeypatch.setenv("AMOF_RDF_SHELL", "bogus")
+    with pytest.raises(ValueError):
+        normalize_rdf(*args)
+    dr = 5.0 / 50
+    r = (np.arange(50) + 0.5) * dr
+    np.testing.assert_allclose(mid / exact, 1.0 + dr * dr / (12.0 * r * r), rtol=1e-14)
+    lo, hi = r - dr / 2, r + dr / 2
+    np.testing.assert_allclose(exact, hist * (4380.486 / (272 * 4 * 272.0)) / (4 * np.pi / 3 * (hi ** 3 - lo ** 3)), rtol=1e-13)
+    assert np.array_equal(mid, normalize_rdf_shell(*args, "midpoint"))
