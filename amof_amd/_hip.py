@@ -33,7 +33,7 @@ EXPORTS = [
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_bad_hist_by_cn",
     "amof_msd_window", "amof_msd_window_dev", "amof_msd_com_dev", "amof_msd_direct",
-    "amof_xyz_scan", "amof_xyz_read", "amof_cp2k_cell_read", "amof_ingest_last_error",
+    "amof_xyz_scan", "amof_xyz_read", "amof_xyz_open", "amof_xyz_read_frames", "amof_xyz_close", "amof_cp2k_cell_read", "amof_ingest_last_error",
 ]
 
 
@@ -116,6 +116,12 @@ def load_library():
         lib.amof_xyz_scan.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         lib.amof_xyz_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                       P, P, P, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]
+        lib.amof_xyz_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(P), ctypes.POINTER(ctypes.c_int64),
+                                      ctypes.POINTER(ctypes.c_int64)]
+        lib.amof_xyz_read_frames.argtypes = [P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                             P, P, P, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32]
+        lib.amof_xyz_close.argtypes = [P]
+        lib.amof_xyz_close.restype = None
         lib.amof_cp2k_cell_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, P, ctypes.POINTER(ctypes.c_int64)]
         lib.amof_ingest_last_error.restype = ctypes.c_char_p
         if lib.amof_abi_version() != ABI_VERSION:
@@ -154,7 +160,9 @@ class _TrajHandle(object):
         assert isinstance(packed, PackedTrajectory)
         f0, f1 = (0, packed.n_frames) if frame_range is None else frame_range
         self.kinds, self.species = packed_species(packed)
-        pos = packed.pos
+        pos = getattr(packed, "_dev_pos", None)        # (PackedTrajectory.keep_on_device: resident copy of a host array)
+        if pos is None:
+            pos = packed.pos
         cell = packed.cell if packed.cell.shape[0] == 1 else packed.cell[f0:f1]
         self.cell = np.ascontiguousarray(cell, dtype=np.float64)
         self.masses = np.ascontiguousarray(packed.masses, dtype=np.float64)

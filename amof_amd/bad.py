@@ -111,9 +111,17 @@ class Bad(CoreBad):
         merge = distributed is not False and _dist.merging(world)
         F = len(packed)
         frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
-        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        dev = device if device is not None else getattr(packed, "device_index", None)
         ctx = _hip.get_context(dev)
-        if triples and merge and _dist.device_collectives():
+        if getattr(packed, "is_stream", False):
+            if merge:
+                raise ValueError("a streamed trajectory is analysed by one process (distributed=False)")
+            hist, nang = np.zeros((len(triples), bins + 1), dtype=np.uint64), np.zeros(len(triples), dtype=np.uint64)
+            for batch in packed.batches():
+                if triples:
+                    h, a = ctx.bad_hist(batch, rcm, triples, theta_bins)
+                    hist, nang = hist + h, nang + a
+        elif triples and merge and _dist.device_collectives():
             # counts stay in HBM from the kernels through ONE RCCL all-reduce (amof_bad_hist_dev)
             import torch
             T, nb = len(triples), bins + 1
@@ -203,7 +211,7 @@ class BadByCn(CoreBad):
         merge = distributed is not False and _dist.merging(world)
         F = len(packed)
         frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
-        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        dev = device if device is not None else getattr(packed, "device_index", None)
         ctx = _hip.get_context(dev)
         # the last slot (cn_max) also collects every larger neighbour count: when it is populated, count again with
         # more slots -- the reference has no limit on the coordination number (amof/bad.py:190-224)

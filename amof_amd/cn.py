@@ -69,10 +69,17 @@ class CoordinationNumber(object):
         merge = distributed is not False and _dist.merging(world)
         F = len(packed)
         frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
-        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        dev = device if device is not None else getattr(packed, "device_index", None)
         ctx = _hip.get_context(dev)
-        sums = ctx.cn_count(packed, rcm, live, frame_range=frame_range) if live else \
-            np.zeros((frame_range[1] - frame_range[0], 0), dtype=np.int64)
+        if getattr(packed, "is_stream", False):
+            if merge:
+                raise ValueError("a streamed trajectory is analysed by one process (distributed=False)")
+            rows = [ctx.cn_count(batch, rcm, live) if live else np.zeros((len(batch), 0), dtype=np.int64)
+                    for batch in packed.batches()]
+            sums = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(live)), dtype=np.int64)
+        else:
+            sums = ctx.cn_count(packed, rcm, live, frame_range=frame_range) if live else \
+                np.zeros((frame_range[1] - frame_range[0], 0), dtype=np.int64)
         if merge and distributed != 'local':
             sums = _dist.all_gather_rows(sums, device=ctx.device)
 

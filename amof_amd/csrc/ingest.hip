@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -174,6 +175,7 @@ int parse_frame(const Mapped &m, size_t off, int64_t N, double *pos, char *symbo
             }
         }
     }
+    if (!pos) return AMOF_OK;                     // (lattice-only pass: the cells of a stream, known before its frames)
     c = ce < e ? ce + 1 : e;
     for (int64_t k = 0; k < N; k++) {
         const char *le = line_end(c, e);
@@ -211,16 +213,10 @@ extern "C" int amof_xyz_scan(const char *path, int64_t *n_frames, int64_t *n_ato
     return AMOF_OK;
 }
 
-extern "C" int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, int64_t n_atoms,
-                             double *pos, char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads)
+// frames first, first + step, ... of an indexed mapping into pos (shared by the one-shot and the handle entry points)
+static int read_frames(const Mapped &m, const FrameIndex &ix, int64_t first, int64_t count, int64_t step, int64_t n_atoms,
+                       double *pos, char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads)
 {
-    if (!path || !pos || count < 0 || step == 0 || n_atoms < 0) return ingest_fail(AMOF_EINVAL, "bad argument");
-    Mapped m;
-    int rc = m.open_file(path);
-    if (rc) return rc;
-    FrameIndex ix;
-    rc = index_frames(m, ix);
-    if (rc) return rc;
     const int64_t F = (int64_t)ix.off.size(), N = ix.n_atoms;
     // the caller sized pos / symbols for n_atoms per frame (amof_xyz_scan): a file rewritten in between must not
     // make this call write past those buffers
@@ -242,7 +238,7 @@ extern "C" int amof_xyz_read(const char *path, int64_t first, int64_t count, int
     auto worker = [&](int w) {
         for (int64_t k = w; k < count; k += nt) {
             int hl = 0;
-            int r = parse_frame(m, ix.off[(size_t)(first + k * step)], N, pos + (size_t)k * N * 3,
+            int r = parse_frame(m, ix.off[(size_t)(first + k * step)], N, pos ? pos + (size_t)k * N * 3 : nullptr,
                                 (k == 0) ? symbols : nullptr, lattice ? lattice + 9 * k : nullptr, &hl);
             lat_all[(size_t)k] = hl;
             if (r) { rcs[(size_t)w] = r; errs[(size_t)w] = g_err; return; }
@@ -260,6 +256,58 @@ extern "C" int amof_xyz_read(const char *path, int64_t first, int64_t count, int
         *has_lattice = lattice ? all : 0;
     }
     return AMOF_OK;
+}
+
+extern "C" int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, int64_t n_atoms,
+                             double *pos, char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads)
+{
+    if (!path || !pos || count < 0 || step == 0 || n_atoms < 0) return ingest_fail(AMOF_EINVAL, "bad argument");
+    Mapped m;
+    int rc = m.open_file(path);
+    if (rc) return rc;
+    FrameIndex ix;
+    rc = index_frames(m, ix);
+    if (rc) return rc;
+    return read_frames(m, ix, first, count, step, n_atoms, pos, symbols, lattice, has_lattice, n_threads);
+}
+
+// An open trajectory file: the mapping and the frame index are built once and serve any number of batch reads (a
+// streamed analysis reads a 2.6 GB file in a few dozen batches; re-indexing it for every batch would cost 0.3 s each).
+struct amof_xyz_file {
+    Mapped m;
+    FrameIndex ix;
+};
+
+extern "C" int amof_xyz_open(const char *path, amof_xyz_file **out, int64_t *n_frames, int64_t *n_atoms)
+{
+    if (!path || !out) return ingest_fail(AMOF_EINVAL, "NULL argument");
+    *out = nullptr;
+    amof_xyz_file *f = new (std::nothrow) amof_xyz_file;
+    if (!f) return ingest_fail(AMOF_ENOMEM, "out of memory");
+    int rc = f->m.open_file(path);
+    if (!rc) rc = index_frames(f->m, f->ix);
+    if (rc) {
+        delete f;
+        return rc;
+    }
+    // batches are read at random offsets, several threads each: no sequential read-ahead hint
+    if (f->m.p && f->m.n) madvise((void *)f->m.p, f->m.n, MADV_NORMAL);
+    if (n_frames) *n_frames = (int64_t)f->ix.off.size();
+    if (n_atoms) *n_atoms = f->ix.n_atoms < 0 ? 0 : f->ix.n_atoms;
+    *out = f;
+    return AMOF_OK;
+}
+
+extern "C" int amof_xyz_read_frames(amof_xyz_file *f, int64_t first, int64_t count, int64_t step, int64_t n_atoms,
+                                    double *pos, char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads)
+{
+    if (!f || (!pos && !lattice) || count < 0 || step == 0 || n_atoms < 0) return ingest_fail(AMOF_EINVAL, "bad argument");
+    return read_frames(f->m, f->ix, first, count, step, n_atoms, pos, symbols, lattice, has_lattice, n_threads);
+}
+
+extern "C" void amof_xyz_close(amof_xyz_file *f)
+{
+    delete f;
 }
 
 // CP2K cell log: "# Step Time Ax Ay Az Bx By Bz Cx Cy Cz Volume"; the reference keeps columns

@@ -83,7 +83,7 @@ class DirectMsd(Msd):
         packed = pack_trajectory(trajectory)
         logger.info("Start computing msd for %s frames", len(packed))
         elements = packed.unique_numbers()
-        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        dev = device if device is not None else getattr(packed, "device_index", None)
         msd, kinds = _hip.get_context(dev).msd_direct(packed)
         self.data = pd.DataFrame({"Step": step})
         self.data["X"] = msd[:, 0]
@@ -134,6 +134,8 @@ class WindowMsd(Msd):
     def compute_msd(self, trajectory, window, time, parallel=False, unwrap=False, device=None, distributed=None):
         """compute the window MSD (reference amof/msd.py:207-268)"""
         packed = pack_trajectory(trajectory)
+        if getattr(packed, "is_stream", False):
+            packed = packed.read_all()      # a window couples frames half a trajectory apart: nothing to stream
         elements = packed.unique_numbers()
         if unwrap == True:  # noqa: E712  (the reference compares with ==)
             logger.info("Unwrap trajectory before computing msd")
@@ -143,7 +145,7 @@ class WindowMsd(Msd):
         merge = distributed is not False and _dist.merging(world)
         N, F = packed.n_atoms, len(packed)
         atom_range = _dist.shard_range(N, rank, world) if merge and distributed != 'local' else (0, N)
-        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        dev = device if device is not None else getattr(packed, "device_index", None)
         ctx = _hip.get_context(dev)
         sharded = merge and distributed != 'local'
         if sharded and _dist.device_collectives():
@@ -177,7 +179,7 @@ class WindowMsd(Msd):
         for e in elements:
             cols[_data.chemical_symbols[int(e)]] = sumsq[idx[int(e)]] / counts[int(e)] / denom
         # formula-weighted total (amof/msd.py:263-268)
-        if isinstance(trajectory, PackedTrajectory):
+        if isinstance(trajectory, PackedTrajectory) or getattr(trajectory, "is_stream", False):
             formula_dict = packed.formula_count()
         else:
             formula_dict = trajectory[0].symbols.formula._count

@@ -99,7 +99,7 @@ class Rdf(object):
         N_species = len(atomic_numbers_unique)
         rank, world = (0, 1) if distributed is False else _dist.world()
         merge = distributed is not False and _dist.merging(world)
-        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        dev = device if device is not None else getattr(packed, "device_index", None)
         ctx = _hip.get_context(dev)
 
         # min over ALL frames of the three cell lengths, halved (amof/rdf.py:74)
@@ -121,6 +121,20 @@ class Rdf(object):
             raise ValueError("rmax // dr gives no bin")
 
         F_local = len(packed)
+        if getattr(packed, "is_stream", False):
+            # frames are independent: the integer counts of the batches add up (the parse of the next batch runs in the
+            # stream's background thread while this one is on the GPU)
+            if merge:
+                raise ValueError("a streamed trajectory is analysed by one process (distributed=False)")
+            hist, vol_sum, kinds = None, 0.0, None
+            for batch in packed.batches():
+                h, v, kinds = ctx.rdf_accumulate(batch, rmax, bins)
+                hist = h if hist is None else hist + h
+                vol_sum += v
+            if packed.cell is not None:
+                vol_sum = packed.volume_sum()      # (the library's own left-to-right sum: identical to the unstreamed result)
+            self._finish(packed, hist, vol_sum, F_local, kinds, atomic_numbers_unique, rmax, bins, r)
+            return
         if merge and distributed != 'local':
             frame_range = _dist.shard_range(F_local, rank, world)
         else:
@@ -158,6 +172,11 @@ class Rdf(object):
                 hist = _dist.all_reduce_sum(hist, device=ctx.device)
                 tot = _dist.all_reduce_sum(np.array([vol_sum, float(n_frames)]), device=ctx.device)
                 vol_sum, n_frames = float(tot[0]), int(round(tot[1]))
+        self._finish(packed, hist, vol_sum, n_frames, kinds, atomic_numbers_unique, rmax, bins, r)
+
+    def _finish(self, packed, hist, vol_sum, n_frames, kinds, atomic_numbers_unique, rmax, bins, r):
+        """normalisation and column assembly (amof/rdf.py:96-114) from the integer counts"""
+        N_species = len(atomic_numbers_unique)
         self.hist = hist                      # integer ordered-pair counts [S][S][bins]
         self.kinds = kinds
         self.n_frames = n_frames
@@ -291,7 +310,7 @@ class CoordinationNumber(object):
         logger.info("Start computing coordination number for %s frames with dr = %s and rmax = %s", len(packed), dr, rmax)
         bins = int(rmax // dr)
         r = np.arange(bins) * dr
-        dev = device if device is not None else (packed.pos.device.index if packed.on_device else None)
+        dev = device if device is not None else getattr(packed, "device_index", None)
         ctx = _hip.get_context(dev)
         natoms = packed.n_atoms
         rows = []

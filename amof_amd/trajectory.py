@@ -39,6 +39,21 @@ def _ingest_error(lib, rc):
     raise RuntimeError("libamofhip ingest error %d: %s" % (rc, msg))
 
 
+def default_parser_threads():
+    """threads for the native text reader: the CPUs this process may USE (affinity mask, cgroup quota), not the
+    machine's -- a GPU box hands a job a share of its 256 hardware threads, and 64 parser threads on a 16-CPU share
+    run at a third of the speed of 16"""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                # container CPU quota (cgroup v2), e.g. "1600000 100000"
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return int(max(1, min(n, 64)))
+
+
 def read_xyz(path, index=None, n_threads=0):
     """Read an XYZ / extended-XYZ trajectory into packed arrays.
 
@@ -75,7 +90,7 @@ def read_xyz(path, index=None, n_threads=0):
     if count:
         rc = lib.amof_xyz_read(bpath, first, count, step, N, ctypes.c_void_p(pos.ctypes.data),
                                ctypes.c_void_p(symbols.ctypes.data), ctypes.c_void_p(lattice.ctypes.data),
-                               ctypes.byref(has), int(n_threads))
+                               ctypes.byref(has), int(n_threads) if int(n_threads) > 0 else default_parser_threads())
         if rc:
             _ingest_error(lib, rc)
     names = [bytes(row).split(b"\0")[0].decode() for row in symbols]

@@ -299,6 +299,54 @@ def supplementary(device, local_rank, ctx, do_verify=True):
             out["configs4"]["verified"] = False
     del p4, r4, pos4
     torch.cuda.empty_cache()
+    # from_text: the headline system from an XYZ text file (53 bytes per atom line) -- read at once, then analysed (the
+    # reference's order: amof/trajectory.py:37-60 -> amof/rdf.py:88-93) versus streamed in frame batches whose parse
+    # overlaps the previous batch's analysis (amof_amd.stream.XyzStream)
+    try:
+        import tempfile
+        import pandas as pd
+        from amof_amd import trajectory as T
+        from amof_amd import data as eldata
+        from amof_amd.stream import XyzStream
+        Ft = 400
+        pt = make_trajectory(device, (3, 3, 4), Ft, 0.05, 20261003)
+        host = pt.pos.cpu().numpy()
+        syms = np.array([eldata.chemical_symbols[int(z)] for z in pt.numbers])
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+            path = os.path.join(tmp, "headline_%d.xyz" % Ft)
+            with open(path, "w") as fh:
+                for k in range(Ft):
+                    fh.write("%d\nframe %d\n" % (pt.n_atoms, k))
+                    pd.DataFrame({"s": syms, "x": host[k, :, 0], "y": host[k, :, 1], "z": host[k, :, 2]}).to_csv(
+                        fh, sep=" ", header=False, index=False, float_format="%.10f")
+            size = os.path.getsize(path)
+            cell = pt.cell[0]
+            res = {}
+            for rep in range(2):
+                t0 = time.perf_counter()
+                whole = T.read_lammps_traj(path, ":", cell=cell)
+                t_parse = time.perf_counter() - t0
+                r_a = Rdf.from_trajectory(whole, device=local_rank, distributed=False)
+                t_serial = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                r_b = Rdf.from_trajectory(XyzStream(path, cell=cell, batch_frames=50), device=local_rank, distributed=False)
+                t_stream = time.perf_counter() - t0
+            same = bool(np.array_equal(np.asarray(r_a.hist), np.asarray(r_b.hist)) and r_a.data.equals(r_b.data))
+            ok_t = None
+            if do_verify:
+                pd_dev = PackedTrajectory(torch.as_tensor(whole.pos).to(device), whole.cell, whole.numbers)
+                ok_t = verify_rdf_timed(ctx, pd_dev, r_b.rmax, len(r_b.data), r_b.hist, [0, Ft - 1])
+                del pd_dev
+            out["from_text"] = {
+                "workload": "headline system from a %d-frame XYZ text file (%.0f MB): Rdf(dr=0.01, half cell)" % (Ft, size / 1e6),
+                "read_then_analyse_frames_per_s": Ft / t_serial, "streamed_frames_per_s": Ft / t_stream,
+                "parse_only_frames_per_s": Ft / t_parse, "parse_GB_per_s": size / t_parse / 1e9,
+                "host_threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+                "streamed_equals_whole": same, "verified": (bool(ok_t and same) if do_verify else None)}
+        del pt, host, whole
+    except Exception as exc:
+        out["from_text"] = {"error": repr(exc)}
+    torch.cuda.empty_cache()
     return out
 
 

@@ -229,8 +229,16 @@ int amof_msd_direct(amof_ctx *ctx, const amof_traj *traj, double *msd /* host [F
  *       n_threads <= 0: all hardware threads.  Numbers are parsed correctly rounded.
  *   amof_cp2k_cell_read: columns [2:-1] (Ax..Cz) of every data row into cell[rows][9];
  *       cell == NULL only counts rows.
+ *   amof_xyz_open / amof_xyz_read_frames / amof_xyz_close: the same reader on an OPEN file -- mapping and frame index
+ *       are built once and serve any number of batch reads (streamed analyses: amof_amd/stream.py); a handle may be
+ *       read from several threads at once.  pos == NULL with lattice != NULL reads the Lattice of the frames only.
  * Errors: negative code, message via amof_ingest_last_error() (thread local).
  */
+typedef struct amof_xyz_file amof_xyz_file;
+int amof_xyz_open(const char *path, amof_xyz_file **out, int64_t *n_frames, int64_t *n_atoms);
+int amof_xyz_read_frames(amof_xyz_file *file, int64_t first, int64_t count, int64_t step, int64_t n_atoms, double *pos,
+                         char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads);
+void amof_xyz_close(amof_xyz_file *file);
 int amof_xyz_scan(const char *path, int64_t *n_frames, int64_t *n_atoms);
 int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, int64_t n_atoms, double *pos,
                   char *symbols, double *lattice, int32_t *has_lattice, int32_t n_threads);

@@ -86,3 +86,58 @@ def test_files_to_resident_trajectory_to_analyses(tmp_path, hip_ctx):
     tr.set_cell(cells)
     again = Rdf.from_trajectory(tr.get_traj().to_device(0), dr=0.02)
     assert np.array_equal(again.hist, rdf.hist)
+
+
+def test_streamed_file_equals_whole_trajectory(tmp_path, hip_ctx):
+    """file -> pinned batches (parsed one ahead) -> GPU: Rdf / CoordinationNumber / Bad on an XyzStream give exactly what
+    they give on the trajectory read at once -- integer counts add over the batches; WindowMsd reads the stream whole"""
+    from amof_amd.stream import XyzStream
+    from amof_amd.bad import Bad
+    from amof_amd.msd import WindowMsd
+    packed = H.random_walk(H.zif4_frame(), 41, 0.05, 9)
+    path = str(tmp_path / "t.xyz")
+    T.write_xyz(path, packed, comment_lattice=False, fmt="%.17g")
+    whole = T.read_lammps_traj(path, ":", cell=packed.cell[0])
+    assert np.array_equal(whole.pos, packed.pos)
+    cut = {'Zn-N': 2.5, 'C-N': 1.6}
+    for bf in (7, 16, 64):
+        st = XyzStream(path, cell=packed.cell[0], batch_frames=bf)
+        a, b = Rdf.from_trajectory(st), Rdf.from_trajectory(whole)
+        assert np.array_equal(a.hist, b.hist) and a.data.equals(b.data)
+        assert CoordinationNumber.from_trajectory(st, cut).data.equals(CoordinationNumber.from_trajectory(whole, cut).data)
+        assert Bad.from_trajectory(st, cut, dtheta=0.5).data.equals(Bad.from_trajectory(whole, cut, dtheta=0.5).data)
+    assert WindowMsd.from_trajectory(XyzStream(path, cell=packed.cell[0]), delta_time=2, timestep=1).data.equals(
+        WindowMsd.from_trajectory(whole, delta_time=2, timestep=1).data)
+    npt = H.random_walk(H.zif4_frame(), 12, 0.05, 10, cell_jitter=0.01)
+    path2 = str(tmp_path / "npt.xyz")
+    T.write_xyz(path2, npt, comment_lattice=True, fmt="%.17g")
+    # cells from the file (extended XYZ, changing): read ahead of the frames, so the half-cell default works too
+    for kw in ({}, {"rmax": 6.0}):
+        a = Rdf.from_trajectory(XyzStream(path2, batch_frames=5), **kw)
+        b = Rdf.from_trajectory(T.read_lammps_traj(path2, ":"), **kw)
+        assert np.array_equal(a.hist, b.hist) and a.data.equals(b.data)
+    plain = str(tmp_path / "plain.xyz")
+    T.write_xyz(plain, npt, comment_lattice=False, fmt="%.17g")
+    with pytest.raises(ValueError):
+        Rdf.from_trajectory(XyzStream(plain, batch_frames=5))
+
+
+def test_host_trajectory_keeps_its_device_copy(hip_ctx):
+    """PackedTrajectory.keep_on_device: one upload serves every later analysis; the host array is read-only meanwhile"""
+    from amof_amd.msd import WindowMsd
+    packed = H.random_walk(H.zif4_frame(), 30, 0.05, 12)
+    ref_r = Rdf.from_trajectory(packed).data
+    ref_m = WindowMsd.from_trajectory(packed, delta_time=2, timestep=1).data
+    assert packed.device_index is None
+    packed.keep_on_device(0)
+    assert packed.device_index == 0 and not packed.on_device
+    with pytest.raises(ValueError):
+        packed.pos[0, 0, 0] = 1.0
+    assert Rdf.from_trajectory(packed).data.equals(ref_r)
+    assert WindowMsd.from_trajectory(packed, delta_time=2, timestep=1).data.equals(ref_m)
+    # the copy is what the kernels read: scribble on it and the result changes; drop it and the host array is back
+    packed._dev_pos[:, 0, 0] += 0.25          # (one atom: a uniform shift would change nothing)
+    assert not Rdf.from_trajectory(packed).data.equals(ref_r)
+    packed.release_device()
+    packed.pos[0, 0, 0] += 0.0
+    assert Rdf.from_trajectory(packed).data.equals(ref_r)

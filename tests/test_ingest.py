@@ -151,3 +151,43 @@ def test_xyz_read_refuses_a_file_that_changed_since_the_scan(tmp_path):
                            None, ctypes.byref(has), 2)
     assert rc == _hip.AMOF_EINVAL and b"atoms per frame" in lib.amof_ingest_last_error()
     assert (pos == -7.0).all()                                   # nothing was written
+
+
+@pytest.mark.parametrize("lattice", [True, False])
+def test_xyz_stream_batches_equal_the_whole_read(tmp_path, lattice):
+    """amof_amd.stream.XyzStream: the batches (parsed one ahead in a background thread) concatenate to what one read of
+    the file gives -- every batch size, ragged last batch, a frame selection, cells from the file or handed in"""
+    from amof_amd.stream import XyzStream
+    packed = H.random_walk(H.zif4_frame(), 23, 0.05, 5, cell_jitter=0.01 if lattice else 0.0)
+    path = str(tmp_path / "s.xyz")
+    T.write_xyz(path, packed, comment_lattice=lattice, fmt="%.17g")
+    whole = T.read_lammps_traj(path, ":", cell=None if lattice else packed.cell[0])
+    for bf, index in ((1, None), (5, None), (8, "3:21:2"), (23, None), (100, None)):
+        st = XyzStream(path, cell=None if lattice else packed.cell[0], batch_frames=bf, index=index, pinned=False)
+        sel = slice(None) if index is None else T.string2index(index)
+        assert len(st) == len(range(*sel.indices(23))) and st.n_atoms == 272
+        assert np.array_equal(st.numbers, whole.numbers)
+        got = list(st.batches())
+        assert [len(b) for b in got] == [min(bf, len(st) - k) for k in range(0, len(st), min(bf, len(st)))]
+        # (two buffers: a batch is only valid until the next is requested -- compare as they arrive)
+        k = 0
+        for b in st.batches():
+            want = whole.pos[sel][k:k + len(b)]
+            assert np.array_equal(b.pos, want)
+            assert np.array_equal(b.cells_full(), whole.cells_full()[sel][k:k + len(b)])
+            k += len(b)
+        assert k == len(st)
+        assert np.array_equal(st.read_all().pos, whole.pos[sel])
+    if lattice:
+        st = XyzStream(path, pinned=False)                         # the Lattice of every frame, read ahead of the frames
+        assert np.array_equal(st.cell, whole.cell) and st.volume_sum() == whole.volume_sum()
+        plain = str(tmp_path / "plain.xyz")
+        T.write_xyz(plain, packed, comment_lattice=False, fmt="%.17g")
+        with pytest.raises(ValueError):
+            XyzStream(plain, pinned=False).cell_lengths()
+    else:
+        st = XyzStream(path, cell=packed.cell[0], pinned=False)
+        assert np.array_equal(st.cell_lengths(), whole.cell_lengths())
+        assert st.volume_sum() == whole.volume_sum()
+    with pytest.raises(ValueError):
+        list(XyzStream(str(tmp_path / "missing.xyz"), pinned=False).batches())
