@@ -377,9 +377,10 @@ def main():
         # (rank 0's JSON line) and the exit code.
         raise SystemExit(self_launch(args.gpus))
     if args.rank_probe is not None:
-        print(json.dumps({"probe": True, "rank": int(os.environ.get("RANK", "0")),
-                          "world": int(os.environ.get("WORLD_SIZE", "1")), "gpus": args.gpus,
-                          "master_addr": os.environ.get("MASTER_ADDR")}), flush=True)
+        # (one write per rank: the ranks share the launcher's pipe, and a line split over two writes can interleave)
+        os.write(1, (json.dumps({"probe": True, "rank": int(os.environ.get("RANK", "0")),
+                                 "world": int(os.environ.get("WORLD_SIZE", "1")), "gpus": args.gpus,
+                                 "master_addr": os.environ.get("MASTER_ADDR")}) + "\n").encode())
         raise SystemExit(args.rank_probe)
 
     import torch
