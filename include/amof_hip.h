@@ -107,7 +107,7 @@ int64_t amof_last_kernel_launches(const amof_ctx *ctx);
  *   BAD  "bad_cell", "bad_fast", "bad_exact", "bad_exact_biglist"
  *   MSD  "msd_stream" (register-ring comb, window spacing 64..256), "msd_comb" (block comb kernels incl. the
  *        double-buffered and > 32-window passes), "msd_group" (arbitrary window lists), "msd_comb_global" /
- *        "msd_global" (series too long for LDS), "msd_direct" */
+ *        "msd_global" (series too long for LDS), "msd_direct", "msd_com" (amof_msd_com_dev alone) */
 const char *amof_last_path(const amof_ctx *ctx);
 
 /*

@@ -303,6 +303,7 @@ def test_direct_msd_matches_reference_restatement(hip_ctx):
     from oracle import numpy_oracle as no
     packed = H.random_walk(H.zif4_frame(), 25, 0.3, 43, ortho=True, cell_jitter=0.005)
     d = DirectMsd.from_trajectory(packed, delta_Step=5, first_frame=100)
+    assert hip_ctx.last_path() == "msd_direct"
     elements, ref = no.direct_msd(packed.pos, packed.cell, packed.numbers)
     assert list(d.data.columns)[:2] == ["Step", "X"] and d.data["Step"][3] == 115
     np.testing.assert_allclose(d.data["X"].values, ref[None], rtol=1e-9, atol=1e-12)
@@ -415,6 +416,7 @@ def test_msd_device_side_merge_entry_points(hip_ctx):
     com = torch.zeros((F, 3), dtype=torch.float64, device="cuda:0")
     for r in ((0, 7), (7, 311), (311, F)):
         hip_ctx.msd_com(dev, r, com)
+        assert hip_ctx.last_path() == "msd_com"
     m = packed.masses
     np.testing.assert_allclose(com.cpu().numpy(), (packed.pos * m[None, :, None]).sum(axis=1) / m.sum(), rtol=1e-13)
     out = torch.zeros((len(kinds), len(window)), dtype=torch.float64, device="cuda:0")

@@ -255,3 +255,33 @@ def test_rdf_shell_switch(monkeypatch):
     lo, hi = r - dr / 2, r + dr / 2
     np.testing.assert_allclose(exact, hist * (4380.486 / (272 * 4 * 272.0)) / (4 * np.pi / 3 * (hi ** 3 - lo ** 3)), rtol=1e-13)
     assert np.array_equal(mid, normalize_rdf_shell(*args, "midpoint"))
+
+
+def test_every_kernel_family_is_pinned_by_a_forced_path_test():
+    """Variant sprawl guard: every path name the library can report (amof_last_path, the strings in csrc/*.hip) is
+    documented in include/amof_hip.h AND asserted by at least one `-m gpu` test that forces it and compares with the
+    oracle -- a kernel family nobody selects any more, or one nobody tests, fails here."""
+    csrc = os.path.join(ROOT, "amof_amd", "csrc")
+    emitted = set()
+    for fn in os.listdir(csrc):
+        if fn.endswith(".hip"):
+            src = open(os.path.join(csrc, fn)).read()
+            emitted |= set(re.findall(r'last_path = [^;]*?"([a-z_0-9]+)"', src))
+            emitted |= set(re.findall(r'last_path = [^;]*\? "([a-z_0-9]+)" : "([a-z_0-9]+)"', src) and
+                           [x for pair in re.findall(r'\? "([a-z_0-9]+)" : "([a-z_0-9]+)"', src) for x in pair])
+            emitted |= set(re.findall(r'timing_dom_begin\(ctx, "([a-z_0-9]+)"', src))
+            for args in re.findall(r'timing_dom_begin\(ctx, ([^;]*)\);', src):
+                emitted |= set(re.findall(r'"([a-z_0-9]+)"', args))
+    emitted = {p for p in emitted if re.match(r"(rdf|cn|bad|msd)_", p)}
+    header = open(os.path.join(ROOT, "include", "amof_hip.h")).read()
+    doc = header[header.index("kernel family that produced the result of the last call"):header.index("const char *amof_last_path")]
+    documented = set(re.findall(r'"((?:rdf|cn|bad|msd)_[a-z_0-9]+)"', doc))
+    assert emitted == documented, (sorted(emitted - documented), sorted(documented - emitted))
+    tested = set()
+    for fn in os.listdir(os.path.join(ROOT, "tests")):
+        if fn.startswith("test_gpu") and fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "tests", fn)).read()
+            for line in src.splitlines():
+                if "last_path()" in line or "want" in line:
+                    tested |= set(re.findall(r'"((?:rdf|cn|bad|msd)_[a-z_0-9]+)"', line))
+    assert emitted <= tested, sorted(emitted - tested)
