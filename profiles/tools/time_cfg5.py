@@ -13,4 +13,4 @@ dev = PackedTrajectory(torch.tensor(packed.pos, device="cuda:0"), packed.cell, p
 ctx = _hip.get_context(0)
 for rep in range(2):
     t0 = time.perf_counter(); h, _, _ = ctx.rdf_accumulate(dev, 10.0, 999); dt = time.perf_counter() - t0
-    print("F=%d wall %.2f ms/frame, tile kernel %.2f ms/frame, all kernels %.2f ms/frame, pairs in range %d" % (F, 1e3*dt/F, 1e3*ctx.last_kernel_seconds(True)/F, 1e3*ctx.last_kernel_seconds(False)/F, int(h.sum())//F))
+    print("F=%d wall %.2f ms/frame, dominant kernel %.4f ms/frame, all kernels %.4f ms/frame, pairs in range %d" % (F, 1e3*dt/F, 1e3*ctx.last_kernel_seconds(True)/F, 1e3*ctx.last_kernel_seconds(False)/F, int(h.sum())//F))
