@@ -639,7 +639,7 @@ def main():
             # supplementary: packing a list of ase.Atoms-like frames into the arrays above (pure Python + memcpy,
             # identical for a CPU and a GPU path; SURVEY 8d asks for it separately)
             from amof_amd.frames import Frame, pack_trajectory
-            nfr = min(F, 200)
+            nfr = min(F, 600)                # (>= 64 MB: the threaded copy path of pack_trajectory)
             frames = [Frame(host.numbers, host.pos[k], host.cell_of(k)) for k in range(nfr)]
             t0 = time.perf_counter()
             pack_trajectory(frames)

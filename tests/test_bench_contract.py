@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line(name):
-    with open(os.path.join(ROOT, "profiles", "r02", name)) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03", name)) as fh:
         rows = [l for l in fh.read().splitlines() if l.startswith("{")]
     assert len(rows) == 1, "exactly one JSON line"
     return json.loads(rows[0])
