@@ -57,7 +57,20 @@ struct NbrArgs {
     int32_t ncap;
     int32_t count_only;        // 1: only find the largest neighbour count (flags[2])
     int32_t global_hist;       // 1: more angle bins than LDS holds -- count with global atomics
+    // Transposed neighbour lists (fast BAD kernels).  When both triples B-A-B and A-B-A of a species pair are asked
+    // for, only the side with FEWER centres is searched; every pair it finds is also appended to the list of its
+    // partner, and the angles around the other species' centres are formed from those lists (bad_transposed_kernel)
+    // instead of a second search -- in ZIF-4 every N has one Zn neighbour and no angle at all, yet searching from the
+    // 2304 N cost as much as the whole Zn-centred triple.  The neighbour test is symmetric (same fixed-point
+    // differences negated, same canonical arithmetic), so the lists are the ones the search would have found.
+    const int32_t *tr_off;     // [T] first slot of the derived triple's centres, for a searched triple; -1: none (or null)
+    const int32_t *inv_rank;   // [N] position of an atom inside its species segment
+    uint32_t *tcount;          // [frames of the batch][tr_total]
+    uint32_t *tlist;           // [frames of the batch][tr_total][TR_CAP] partner atom indices
+    int32_t tr_total;
 };
+
+constexpr int TR_CAP = 16;     // = NBRF_NLIST: a fuller centre sends the call to the exact kernels either way
 
 // ------------------------------------------------------------------- CN ----
 template <bool ORTHO, bool EXTRA>
@@ -543,6 +556,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int4 w = a.work[blockIdx.x];          // (triple, first centre (species-relative), centre species, B)
     const int trip = w.x, c0 = w.y, sa = w.z, B = w.w;
+    const int troff = a.tr_off ? a.tr_off[trip] : -1;
     const int64_t segA = fa.sp_first[sa];
     const int nA = (int)(fa.sp_first[sa + 1] - segA);
     const int cnt_c = min(NBRF_TILE, nA - c0);
@@ -628,6 +642,16 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
             }
         }
         n = has ? min(n, NBRF_NLIST) : 0;
+        if (troff >= 0) {
+            // the same pairs, seen from the partners: appended to their transposed lists AFTER the search (the returning
+            // atomics of a lane are independent of each other here; inside the search loop each one stalled the lane)
+            for (int u = 0; u < n; u++) {
+                const uint32_t idx_j = nlist[u * NBRF_TILE + tid];
+                const size_t slot = (size_t)fl * a.tr_total + (size_t)(troff + a.inv_rank[idx_j]);
+                const uint32_t c = atomicAdd(&a.tcount[slot], 1u);
+                if (c < (uint32_t)TR_CAP) a.tlist[slot * TR_CAP + c] = own_idx;
+            }
+        }
         // a centre with a single neighbour -- every N of ZIF-4 -- forms no angle: only centres with >= 2 enter
         const int n_ent = n >= 2 ? n : 0;
         // (barrier: the previous frame's angle phase has finished with pref / uv / ec)  no angle in this tile and
@@ -690,6 +714,84 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
     unsigned long long *H = a.hist + (size_t)trip * nb;
     for (int k = tid; k < nb && !direct; k += NBRF_TILE) {
         unsigned v = hist[k];
+        if (v) atomicAdd(&H[k], (unsigned long long)v);
+    }
+    for (int off = 32; off > 0; off >>= 1) nang += __shfl_down(nang, off, 64);
+    if ((tid & 63) == 0 && nang) atomicAdd(&a.n_angles[trip], nang);
+}
+
+// Angles around the centres whose neighbour lists were written by the search from the OTHER side (see NbrArgs).  One
+// lane per centre, frames in chunks per workgroup (LDS histogram, one flush); a centre with fewer than two partners --
+// every N of an intact ZIF-4 -- is done after reading its count.  Same arithmetic per angle as the searching kernels
+// (canonical minimum-image vectors, ase get_angles order, numpy.histogram edges).
+struct TrDerived {
+    int32_t trip, species, off, count;
+};
+
+template <bool ORTHO>
+__global__ __launch_bounds__(256) void bad_transposed_kernel(NbrFastArgs fa, const TrDerived *__restrict__ der,
+                                                             const int2 *__restrict__ twork)
+{
+    const NbrArgs &a = fa.a;
+    extern __shared__ unsigned thist[];                 // [nb] unless the counts go straight to global memory
+    const int tid = threadIdx.x;
+    const int2 w = twork[blockIdx.x];                   // (derived triple record, first centre of its species)
+    const TrDerived dr = der[w.x];
+    const int trip = dr.trip;
+    const int rank = w.y + tid;
+    const bool has = rank < dr.count;
+    const int g = dr.off + min(rank, dr.count - 1);
+    const int64_t centre = a.perm[fa.sp_first[dr.species] + min(rank, dr.count - 1)];
+    const int nb = a.nb;
+    const bool direct = a.cn_max > 0 || a.global_hist;
+    for (int k = tid; k < nb && !direct; k += 256) thist[k] = 0u;
+    __syncthreads();
+    const double hb_e0 = a.edges[0], hb_en = a.edges[nb], hb_inv_w = (double)nb / (hb_en - hb_e0);
+    unsigned long long nang = 0;
+    const int f0 = blockIdx.y * a.frames_per_chunk, f1 = min(f0 + a.frames_per_chunk, fa.nf);
+    for (int fl = f0; fl < f1; fl++) {
+        const size_t slot = (size_t)fl * a.tr_total + g;
+        const int n = has ? (int)a.tcount[slot] : 0;
+        if (n < 2) continue;
+        if (n > TR_CAP) {           // fuller than the lists: the whole call goes to the exact kernels
+            a.flags[1] = 1;
+            continue;
+        }
+        const int f = fa.f_base + fl;
+        const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+        const double *__restrict__ geo = a.geom + (size_t)(a.n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+        const double *pc = p + (size_t)centre * 3;
+        const uint32_t *__restrict__ lst = a.tlist + slot * TR_CAP;
+        const size_t hslot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
+        for (int u = 0; u < n; u++) {
+            const double *pu = p + (size_t)lst[u] * 3;
+            double vx, vy, vz, ax, ay, az;
+            pair_base<ORTHO>(geo, pu[0] - pc[0], pu[1] - pc[1], pu[2] - pc[2], vx, vy, vz);
+            if (!unit_vec(vx, vy, vz, ax, ay, az)) { a.flags[0] = 1; break; }
+            for (int v = u + 1; v < n; v++) {
+                const double *pv = p + (size_t)lst[v] * 3;
+                double wx, wy, wz, bx, by, bz;
+                pair_base<ORTHO>(geo, pv[0] - pc[0], pv[1] - pc[1], pv[2] - pc[2], wx, wy, wz);
+                if (!unit_vec(wx, wy, wz, bx, by, bz)) { a.flags[0] = 1; break; }
+                double dot = ax * bx + ay * by + az * bz;
+                if (dot > 1.0) dot = 1.0;
+                if (dot < -1.0) dot = -1.0;
+                const double ang = (180.0 / M_PI) * acos(dot);
+                const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w);
+                if (direct) {
+                    atomicAdd(&a.n_angles[hslot], 1ull);
+                    if (k >= 0) atomicAdd(&a.hist[hslot * nb + k], 1ull);
+                } else {
+                    nang++;
+                    if (k >= 0) atomicAdd(&thist[k], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long *H = a.hist + (size_t)trip * nb;
+    for (int k = tid; k < nb && !direct; k += 256) {
+        const unsigned v = thist[k];
         if (v) atomicAdd(&H[k], (unsigned long long)v);
     }
     for (int off = 32; off > 0; off >>= 1) nang += __shfl_down(nang, off, 64);
@@ -1104,9 +1206,27 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
     int32_t flags[4] = {0, 0, 0, 0};
     if (nf.ok && t->n_frames > 0) {
         const int S = t->n_species;
+        // transposed lists: of two triples B-A-B / A-B-A over one species pair, only the side with fewer centres searches
+        std::vector<int32_t> derived_from((size_t)T, -1), tr_off((size_t)T, -1);
+        std::vector<TrDerived> der;
+        int32_t tr_total = 0;
+        if (!getenv("AMOF_BAD_NOTRANSPOSE")) {
+            for (int k = 0; k < T; k++) {
+                const int A = triples[2 * k], B = triples[2 * k + 1];
+                if (A < 0 || B < 0 || A == B || !(cutoff[A * S + B] > 0.0) || !(st.tiles.nsp[A] > st.tiles.nsp[B])) continue;
+                for (int k2 = 0; k2 < T && derived_from[(size_t)k] < 0; k2++)
+                    if (triples[2 * k2] == B && triples[2 * k2 + 1] == A && tr_off[(size_t)k2] < 0) {
+                        derived_from[(size_t)k] = k2;
+                        tr_off[(size_t)k2] = tr_total;
+                        der.push_back(TrDerived{k, A, tr_total, (int32_t)st.tiles.nsp[A]});
+                        tr_total += (int32_t)st.tiles.nsp[A];
+                    }
+            }
+        }
         std::vector<int4> fwork;
         for (int k = 0; k < T; k++) {
             int A = triples[2 * k], B = triples[2 * k + 1];
+            if (derived_from[(size_t)k] >= 0) continue;      // (its angles come from the lists of the triple searched from the other side)
             for (int sa = 0; sa < S; sa++) {
                 if (!(A < 0 || sa == A)) continue;
                 // centres of a species that has no cutoff with any partner species of this triple find nothing
@@ -1119,8 +1239,39 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         }
         void *d_fwork;
         AMOF_TRY(upload(ctx, SLOT_AUX6, fwork.data(), fwork.size() * sizeof(int4), &d_fwork));
+        void *d_trtab = nullptr, *d_trlists = nullptr;
+        int n_twork = 0;
+        if (tr_total > 0) {
+            // one small table: tr_off[T] | inv_rank[N] | derived records | their work list; the lists shrink the frame
+            // batch if they must
+            std::vector<int2> twork;
+            for (size_t dd = 0; dd < der.size(); dd++)
+                for (int32_t c0 = 0; c0 < der[dd].count; c0 += 256) twork.push_back(make_int2((int)dd, c0));
+            n_twork = (int)twork.size();
+            std::vector<int32_t> tab((size_t)T + (size_t)t->n_atoms + 4 * der.size() + 2 * twork.size());
+            for (int k = 0; k < T; k++) tab[(size_t)k] = tr_off[(size_t)k];
+            for (int64_t x = 0; x < t->n_atoms; x++) {
+                const int32_t atom = st.tiles.perm[(size_t)x];
+                tab[(size_t)T + (size_t)atom] = (int32_t)(x - nf.sp_first[t->species[atom]]);
+            }
+            memcpy(&tab[(size_t)T + (size_t)t->n_atoms], der.data(), der.size() * sizeof(TrDerived));
+            memcpy(&tab[(size_t)T + (size_t)t->n_atoms + 4 * der.size()], twork.data(), twork.size() * sizeof(int2));
+            AMOF_TRY(upload(ctx, SLOT_AUX8, tab.data(), tab.size() * sizeof(int32_t), &d_trtab));
+            const size_t per_frame = (size_t)tr_total * (1 + TR_CAP) * sizeof(uint32_t);
+            const int64_t fit = std::max<int64_t>(1, (int64_t)((size_t)1 << 30) / (int64_t)per_frame);
+            nf.FB = std::min<int64_t>(nf.FB, fit);
+            nf.FB0 = std::min<int64_t>(nf.FB0, nf.FB);
+            AMOF_TRY(ensure(ctx, SLOT_AUX9, (size_t)nf.FB * per_frame, &d_trlists));
+        }
         nf.fa.a = a;
         nf.fa.a.work = (const int4 *)d_fwork;
+        nf.fa.a.tr_total = tr_total;
+        if (tr_total > 0) {
+            nf.fa.a.tr_off = (const int32_t *)d_trtab;
+            nf.fa.a.inv_rank = (const int32_t *)d_trtab + T;
+            nf.fa.a.tcount = (uint32_t *)d_trlists;
+            nf.fa.a.tlist = (uint32_t *)d_trlists + (size_t)nf.FB * tr_total;
+        }
         size_t lds = 3 * (size_t)NBRF_UVCAP * sizeof(double) +
                      (size_t)NBRF_NLIST * NBRF_TILE * sizeof(uint32_t) + NBRF_TILE * sizeof(uint32_t) +
                      (NBRF_TILE + 4) * sizeof(int) + NBRF_UVCAP * sizeof(unsigned short) + lds_bins * sizeof(unsigned);
@@ -1129,6 +1280,8 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
             AMOF_TRY(stager_need(st.stage, fb + nfr));
             AMOF_TRY(nbr_fast_batch(ctx, t, st, nf, fb, nfr));
+            if (tr_total > 0)
+                AMOF_HIP_TRY(ctx, hipMemsetAsync(nf.fa.a.tcount, 0, (size_t)nfr * tr_total * sizeof(uint32_t), ctx->stream));
             unsigned chunks;
             pick_chunks(nfr, fwork.size(), nf.fa.a.frames_per_chunk, chunks);
             dim3 grid((unsigned)fwork.size(), chunks);
@@ -1145,6 +1298,25 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             else e = launch(bad_fast_kernel<false, false>);
             AMOF_HIP_TRY(ctx, e);
             AMOF_HIP_TRY(ctx, hipGetLastError());
+            if (tr_total > 0) {     // the angles of the triples that were not searched, from the lists just written
+                const TrDerived *d_der = reinterpret_cast<const TrDerived *>((const int32_t *)d_trtab + T + t->n_atoms);
+                const int2 *d_twork = reinterpret_cast<const int2 *>((const int32_t *)d_trtab + T + t->n_atoms + 4 * der.size());
+                NbrFastArgs ta = nf.fa;
+                unsigned tchunks;
+                pick_chunks(nfr, (size_t)n_twork, ta.a.frames_per_chunk, tchunks);
+                dim3 tgrid((unsigned)n_twork, tchunks);
+                const size_t tlds = lds_bins * sizeof(unsigned);
+                hipError_t e3;
+                if (nf.ortho) {
+                    e3 = allow_max_lds((const void *)bad_transposed_kernel<true>);
+                    if (e3 == hipSuccess) hipLaunchKernelGGL(bad_transposed_kernel<true>, tgrid, dim3(256), tlds, ctx->stream, ta, d_der, d_twork);
+                } else {
+                    e3 = allow_max_lds((const void *)bad_transposed_kernel<false>);
+                    if (e3 == hipSuccess) hipLaunchKernelGGL(bad_transposed_kernel<false>, tgrid, dim3(256), tlds, ctx->stream, ta, d_der, d_twork);
+                }
+                AMOF_HIP_TRY(ctx, e3);
+                AMOF_HIP_TRY(ctx, hipGetLastError());
+            }
             launches++;
         }
         timing_dom_end(ctx, launches);

@@ -200,6 +200,52 @@ def test_bad_fast_list_overflow_takes_the_lds_exact_kernel_first(hip_ctx):
         assert np.array_equal(ab, ar) and np.array_equal(hb, hr)
 
 
+@pytest.mark.parametrize("kind", ["hot", "intact", "npt_tri"])
+def test_bad_transposed_lists_equal_the_second_search(hip_ctx, kind):
+    """both triples of a species pair (N-Zn-N and Zn-N-Zn, C-N-C and N-C-N ...): only the side with fewer centres is
+    searched, the other side's angles come from the transposed lists -- identical counts to searching both sides
+    (AMOF_BAD_NOTRANSPOSE=1) and to the oracle, on the cell-list and the slab-list kernels, with BadByCn's cn keys, on a
+    hot system where N atoms hold 0 .. 3 Zn, and when a list overflows (generous cutoff: exact kernels take over)"""
+    if kind == "hot":
+        packed = H.random_walk(H.replicate(H.zif4_frame(), (2, 1, 2)), 5, 0.3, 61, ortho=True)
+    elif kind == "intact":
+        packed = H.random_walk(H.replicate(H.zif4_frame(), (2, 2, 1)), 3, 0.02, 62, ortho=True)
+    else:
+        packed = H.random_walk(H.replicate(H.zif4_frame(), (1, 2, 2)), 4, 0.2, 63, cell_jitter=0.01)
+    kinds, sp = H.species_of(packed.numbers)
+    S = len(kinds)
+    h, c, n, zn = (kinds.index(z) for z in (1, 6, 7, 30))
+    rcm = np.zeros((S, S))
+    rcm[zn, n] = rcm[n, zn] = 2.6
+    rcm[c, n] = rcm[n, c] = 1.7
+    rcm[c, h] = rcm[h, c] = 1.35
+    triples = [(zn, n), (n, zn), (c, n), (n, c), (h, c), (c, h), (n, -1)]
+    edges = np.arange(int(180 // 1.0) + 2) * 1.0
+    h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
+    assert a_ref[1] > 0 or kind == "intact"                     # Zn-N-Zn angles exist in the hot systems
+    for env, path in (({"AMOF_NBR_FORCE_CELL": "1"}, "bad_cell"), ({"AMOF_NBR_NOCELL": "1"}, "bad_fast")):
+        with _env(**env):
+            hip_ctx.debug_poison(0xA5)
+            h_tr, a_tr = hip_ctx.bad_hist(packed, rcm, triples, edges)
+            assert hip_ctx.last_path() == path
+            with _env(AMOF_BAD_NOTRANSPOSE="1"):
+                h_two, a_two = hip_ctx.bad_hist(packed, rcm, triples, edges)
+            by_tr = hip_ctx.bad_hist_by_cn(packed, rcm, triples, edges, cn_max=6)
+        assert np.array_equal(a_tr, a_ref) and np.array_equal(h_tr, h_ref), (kind, path)
+        assert np.array_equal(a_two, a_ref) and np.array_equal(h_two, h_ref)
+        by_ref = clib.bad_hist_by_cn(packed.pos, packed.cell, sp, S, rcm, triples, edges, 6)
+        assert np.array_equal(by_tr[1], by_ref[1]) and np.array_equal(by_tr[0], by_ref[0]), (kind, path)
+    # a list fuller than its capacity (17+ partners of the other species): the exact kernels answer
+    big = np.zeros((S, S))
+    big[h, c] = big[c, h] = 4.6
+    hb, ab = hip_ctx.bad_hist(packed, big, [(h, c), (c, h)], edges, frame_range=(0, 1))
+    _, pa = clib.cn_counts(packed.pos[:1], packed.cell[:1], sp, S, big, [(h, c), (c, h)], per_atom=True)
+    if pa.max() > 16:
+        assert hip_ctx.last_path() in ("bad_exact", "bad_exact_biglist")
+    hr, ar = clib.bad_hist(packed.pos[:1], packed.cell[:1], sp, S, big, [(h, c), (c, h)], edges)
+    assert np.array_equal(ab, ar) and np.array_equal(hb, hr)
+
+
 def test_cell_list_neighbours_on_lattices_and_sheared_cells(hip_ctx):
     """the 3-D cell-list CN / BAD kernels where the cell grid is tight: atoms exactly on cell faces (integer
     lattice, cells a whole number of lattice constants thick), pairs exactly at the cutoff, a strongly sheared
