@@ -520,6 +520,203 @@ __global__ __launch_bounds__(NBRF_TILE) void cn_fast_kernel(NbrFastArgs fa)
     }
 }
 
+// ---- whole frame in LDS ------------------------------------------------------------------------------------------------
+// The cell-list kernels above read a frame three times from global memory (quantise + sort into Q, the cell-start tables,
+// then ~45 divergent gathers per centre through L1) and are bound by those round trips, not by arithmetic: 0.25 ms
+// (quantize_cells_kernel) + 0.31 ms (cn_fast_kernel<., true>) per 5000 frames for 576 Zn centres x 13 N candidates each.
+// When the two species of a pair fit in LDS (16 B per atom + 4 B per cell and species, <= 152 KB: up to ~8000 atoms
+// per pair), ONE workgroup does the whole frame: fold + quantise the positions (read once, coalesced by species
+// segment), counting-sort them by cell with the counters in LDS, and search from LDS -- nothing is written back but
+// the result.  Every item (species pair) has its own grid, as fine as its own cutoff and the LDS budget allow.
+// Decisions are those of the gather kernels: f32 distance of the wrapped fixed-point differences, pairs inside the guard
+// band re-decided by the canonical float64 arithmetic on the original positions.
+constexpr int NBRW_THREADS = 1024;
+constexpr int NBRW_MAX_ATOMS = NBRW_THREADS * 8;      // atoms of one item (a thread folds up to 8: frame_sort<PT>)
+constexpr uint32_t NBRW_SLOT1 = 0x80000000u;          // record idx word: atom index | second species of the item
+
+struct FrameItem {
+    int32_t sa, sb;            // centre species, partner species (sa == sb: one species staged)
+    int32_t nx, ny, nz;        // this item's cell grid (cells >= its cutoff, >= 3 per axis)
+    int32_t set;               // CN: output set
+    int32_t reg_ab, reg_ba;    // lists: first row of region (sa, sb) / (sb, sa); -1: direction not wanted
+};
+
+struct FrameArgs {
+    const FrameItem *items;
+    const NbrCell *cells;      // [n_cells] cell rows * 2^-32, own axis order
+    const int64_t *sp_first;   // [S+1]
+    int32_t *qflag;            // raised for atoms absurdly far from the cell
+    int32_t f_base, nf;
+    int32_t cap_atoms;         // LDS records
+    float guard_rel, guard_abs;
+};
+
+struct FrameLds {
+    uint4 *rec;                // [cap_atoms] sorted records: species slot 0 first (cells x fastest), then slot 1
+    uint32_t *cell_end;        // [slots * ncell] end of every cell (its start = the entry before it; 0 for the first)
+};
+
+// fold, quantise and cell-sort the item's one or two species of frame f into LDS.  PT = atoms per thread (records wait
+// in registers between the counting and the placement pass); the index and position loads of a thread's atoms are
+// issued together -- one round trip each instead of one per atom
+template <int PT>
+__device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr, const FrameItem &it, const FrameLds &L,
+                                           int f, int nA, int nB, unsigned *wsum)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nx = it.nx, ny = it.ny, nz = it.nz, ncell = nx * ny * nz;
+    const int n = nA + nB, ntab = (nB > 0 ? 2 : 1) * ncell;
+    const double *__restrict__ g = a.geom + (size_t)(a.n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const int64_t segA = fr.sp_first[it.sa], segB = fr.sp_first[it.sb];
+    int32_t atom[PT];
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const int k = min(tid + i * NBRW_THREADS, n - 1);
+        atom[i] = a.perm[k >= nA ? segB + (k - nA) : segA + k];
+    }
+    for (int c = tid; c < ntab; c += NBRW_THREADS) L.cell_end[c] = 0u;
+    double px[PT], py[PT], pz[PT];
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const double *__restrict__ pp = a.pos + ((size_t)f * (size_t)a.N + (size_t)atom[i]) * 3;
+        px[i] = pp[0]; py[i] = pp[1]; pz[i] = pp[2];
+    }
+    __syncthreads();
+    uint4 rec[PT];
+    uint32_t key[PT];
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const int k = tid + i * NBRW_THREADS;
+        uint32_t u[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {       // (quantize_atom's arithmetic on the positions already loaded)
+            double sf = fma(pz[i], g[15 + c], fma(py[i], g[12 + c], px[i] * g[9 + c]));
+            if (!(fabs(sf) < 1.0e4)) *fr.qflag = 1;
+            sf = sf - floor(sf);
+            const double t = sf * 4294967296.0;
+            u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+        }
+        const bool second = k >= nA;
+        rec[i] = make_uint4(u[0], u[1], u[2], (uint32_t)atom[i] | (second ? NBRW_SLOT1 : 0u));
+        key[i] = (second ? (uint32_t)ncell : 0u) +
+                 (__umulhi(u[2], (unsigned)nz) * (unsigned)ny + __umulhi(u[1], (unsigned)ny)) * (unsigned)nx +
+                 __umulhi(u[0], (unsigned)nx);
+        if (k < n) atomicAdd(&L.cell_end[key[i]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the counters, in place: one contiguous chunk per thread, chunk totals scanned by waves
+    const int chunk = (ntab + NBRW_THREADS - 1) / NBRW_THREADS;
+    const int c0 = min(tid * chunk, ntab), c1 = min(c0 + chunk, ntab);
+    unsigned sum = 0;
+    for (int c = c0; c < c1; c++) sum += L.cell_end[c];
+    unsigned incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (int q = 0; q < wave; q++) run += wsum[q];
+    for (int c = c0; c < c1; c++) {
+        const unsigned v = L.cell_end[c];
+        L.cell_end[c] = run;                // (cursor of the placement pass; ends as the cell's end)
+        run += v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const int k = tid + i * NBRW_THREADS;
+        if (k < n) L.rec[atomicAdd(&L.cell_end[key[i]], 1u)] = rec[i];
+    }
+    __syncthreads();
+}
+
+// One task = one centre x one of the 9 rows (dz, dy) of cells around it: its x-run cx-1 .. cx+1 (two index ranges when
+// the run wraps) among the partners of species slot `slot` (0 / 1) of the sorted frame.  Nine lanes share a centre, so a
+// wave's trip count is the fullest ROW of its lanes, not the fullest neighbourhood (per-lane loops over all 27 cells ran
+// at a third of the issue rate: 18 us of a 31 us frame).
+template <bool ORTHO, typename F>
+__device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const FrameItem &it, const FrameLds &L, int slot,
+                                                     const float *sc, const double *__restrict__ geo,
+                                                     const double *__restrict__ p, const uint4 qc, int r9, double rc, F &&found)
+{
+    const int nx = it.nx, ny = it.ny, nz = it.nz;
+    const float rcf = (float)rc;
+    const float gd = rcf * fr.guard_rel + fr.guard_abs;
+    const float r_in = rcf - gd, r_out = rcf + gd;
+    const uint32_t own_idx = qc.w & ~NBRW_SLOT1;
+    const int cx = (int)__umulhi(qc.x, (unsigned)nx), cy = (int)__umulhi(qc.y, (unsigned)ny), cz = (int)__umulhi(qc.z, (unsigned)nz);
+    const int dz = r9 / 3 - 1, dy = r9 - 3 * (r9 / 3) - 1;
+    int cz2 = cz + dz, cy2 = cy + dy;
+    cz2 += cz2 < 0 ? nz : 0; cz2 -= cz2 >= nz ? nz : 0;
+    cy2 += cy2 < 0 ? ny : 0; cy2 -= cy2 >= ny ? ny : 0;
+    const int row = slot * nx * ny * nz + (cz2 * ny + cy2) * nx;
+    // cells xa .. xb of the row, plus the wrapped piece (nx >= 3: three distinct cells)
+    int xa = cx - 1, xb = cx + 1, wa = 0, wb = -1;
+    if (xa < 0) { xa = 0; wa = nx - 1; wb = nx - 1; }
+    else if (xb >= nx) { xb = nx - 1; wa = 0; wb = 0; }
+    const int lo0 = row + xa > 0 ? (int)L.cell_end[row + xa - 1] : 0, hi0 = (int)L.cell_end[row + xb];
+    int lo1 = 0, hi1 = 0;
+    if (wa <= wb) { lo1 = row + wa > 0 ? (int)L.cell_end[row + wa - 1] : 0; hi1 = (int)L.cell_end[row + wb]; }
+    const int len0 = hi0 - lo0, total = len0 + hi1 - lo1;
+    for (int q = 0; q < total; q++) {
+        const uint4 qj = L.rec[q < len0 ? lo0 + q : lo1 + (q - len0)];
+        const uint32_t idx_j = qj.w & ~NBRW_SLOT1;
+        if (idx_j == own_idx) continue;                         // (no zero-shift self pair)
+        const float d = nbr_fast_dist<ORTHO>(sc, qc.x, qc.y, qc.z, qj);
+        bool nbr = d < r_in;
+        if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, own_idx, idx_j, rc);
+        if (nbr) found(idx_j);
+    }
+}
+
+// PT = 4: up to 4096 atoms per item, two workgroups per CU (64 VGPRs); PT = 8: up to 8192, one
+template <bool ORTHO, int PT>
+__global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void cn_frame_kernel(NbrArgs a, FrameArgs fr)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ unsigned wsum[NBRW_THREADS / 64];
+    __shared__ unsigned long long wsum64[NBRW_THREADS / 64];
+    FrameLds L;
+    L.rec = reinterpret_cast<uint4 *>(lds_raw);
+    L.cell_end = reinterpret_cast<uint32_t *>(L.rec + fr.cap_atoms);
+    const int tid = threadIdx.x;
+    const FrameItem it = fr.items[blockIdx.x];
+    const int f = fr.f_base + (int)blockIdx.y;
+    const int nA = (int)(fr.sp_first[it.sa + 1] - fr.sp_first[it.sa]);
+    const int nB = it.sa == it.sb ? 0 : (int)(fr.sp_first[it.sb + 1] - fr.sp_first[it.sb]);
+    const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+    int32_t *__restrict__ pa = a.per_atom ? a.per_atom + ((size_t)f * a.n_sets + it.set) * (size_t)a.N : nullptr;
+    if (pa)     // every centre starts at zero (the barriers of the sort order these stores before the atomics below)
+        for (int c = tid; c < nA; c += NBRW_THREADS) pa[a.perm[fr.sp_first[it.sa] + c]] = 0;
+    frame_sort<PT>(a, fr, it, L, f, nA, nB, wsum);
+    const int gi = a.n_cells == 1 ? 0 : f;
+    const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
+    float sc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) sc[k] = fr.cells[gi].sc[k];
+    const double rc = a.cutoff[it.sa * a.S + it.sb];
+    unsigned long long sum = 0;
+    const int tasks = nA * 9;
+    for (int t = tid; t < tasks; t += NBRW_THREADS) {
+        const int c = t / 9, r9 = t - 9 * c;
+        const uint4 qc = L.rec[c];
+        int cnt = 0;
+        frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, qc, r9, rc, [&](uint32_t) { cnt++; });
+        if (pa && cnt) atomicAdd(&pa[qc.w & ~NBRW_SLOT1], cnt);
+        sum += (unsigned long long)cnt;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((tid & 63) == 0) wsum64[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long s2 = 0;
+        for (int k = 0; k < NBRW_THREADS / 64; k++) s2 += wsum64[k];
+        if (s2) atomicAdd(&a.sums[(size_t)f * a.n_sets + it.set], s2);
+    }
+}
+
 // ase.geometry.get_angles on two canonical minimum-image vectors (normalise, dot, clip, acos)
 __device__ __forceinline__ bool unit_vec(double x, double y, double z, double &ux, double &uy, double &uz)
 {
@@ -1050,6 +1247,105 @@ static int nbr_fast_prepare(amof_ctx *ctx, const amof_traj *t, const double *cut
     return AMOF_OK;
 }
 
+// ---- whole-frame-in-LDS tier: per-item grids and the few constants the kernels need ----
+struct NbrFrame {
+    bool ok = false;
+    bool ortho = false;
+    std::vector<FrameItem> items;
+    size_t lds = 0;
+    FrameArgs fr;
+    void *d_items = nullptr, *d_cells = nullptr, *d_spfirst = nullptr, *d_qflag = nullptr;
+};
+
+// a grid for one species pair: cells at least rc thick, >= 3 per axis, as fine as the LDS left beside n records allows
+static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slots, int64_t densest, FrameItem &it, size_t &lds)
+{
+    if (n > NBRW_MAX_ATOMS || n <= 0) return false;
+    int nk[3];
+    for (int x = 0; x < 3; x++) {
+        nk[x] = (int)std::min(1024.0, floor(hmin[x] / (rc * (1.0 + 1e-5))));
+        if (nk[x] < 3) return false;
+    }
+    const size_t rec_bytes = (size_t)n * sizeof(uint4);
+    // two workgroups per CU when the records leave room for a useful table, one otherwise
+    size_t budget = 76 * 1024;
+    if (rec_bytes + (size_t)slots * 4 * std::min<int64_t>(densest / 2 + 27, 4096) > budget) budget = 152 * 1024;
+    if (rec_bytes + (size_t)slots * 4 * 27 > budget) return false;
+    const int64_t cells_budget = (int64_t)((budget - rec_bytes) / ((size_t)slots * 4));
+    // no point in cells emptier than ~1 atom of the denser species
+    const int64_t want = std::max<int64_t>(27, std::min<int64_t>(cells_budget, densest));
+    while ((int64_t)nk[0] * nk[1] * nk[2] > want) {
+        int big = 0;
+        for (int x = 1; x < 3; x++)
+            if (nk[x] > nk[big]) big = x;
+        if (nk[big] <= 3) break;
+        nk[big]--;
+    }
+    if ((int64_t)nk[0] * nk[1] * nk[2] > cells_budget) return false;
+    it.nx = nk[0]; it.ny = nk[1]; it.nz = nk[2];
+    lds = std::max(lds, rec_bytes + (size_t)slots * 4 * (size_t)nk[0] * nk[1] * nk[2]);
+    return true;
+}
+
+// shared constants of the tier (after the items are known); ok stays false when the tier cannot take the call
+static int nbr_frame_prepare(amof_ctx *ctx, const amof_traj *t, const double *cutoff, NbrSetup &st, NbrFrame &nw, double hmin[3])
+{
+    const int S = t->n_species;
+    const int64_t nc = t->n_cells;
+    double R = 0.0, csum = 0.0;
+    for (int k = 0; k < S * S; k++) R = std::max(R, cutoff[k]);
+    nw.ok = st.max_img == 0 && t->pbc[0] && t->pbc[1] && t->pbc[2] && R > 0.0 && t->n_atoms > 0 &&
+            t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && !getenv("AMOF_NBR_NOFRAME") &&
+            !getenv("AMOF_NBR_NOCELL") && !getenv("AMOF_NBR_FORCE_CELL") &&      // (those name the gather kernels)
+            !(getenv("AMOF_NBR_KERNEL") && strcmp(getenv("AMOF_NBR_KERNEL"), "v1") == 0);
+    for (int x = 0; x < 3; x++) hmin[x] = 1e300;
+    for (int64_t k = 0; k < nc; k++) {
+        const double *c = t->cell + 9 * k;
+        for (int x = 0; x < 3; x++) hmin[x] = std::min(hmin[x], st.geom.rec[(size_t)k * GEOM_STRIDE + 18 + x]);
+        csum = std::max(csum, sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + sqrt(c[3] * c[3] + c[4] * c[4] + c[5] * c[5]) +
+                                  sqrt(c[6] * c[6] + c[7] * c[7] + c[8] * c[8]));
+    }
+    if (!nw.ok) return AMOF_OK;
+    nw.ortho = st.geom.all_ortho;
+    const double grel = fast_guard_rel(st.geom, nc);
+    if (!nw.ortho)
+        for (int x = 0; x < 3; x++)
+            if (R * (1.0 + 4.0 * grel + 1e-6) >= 0.5 * hmin[x]) nw.ok = false;     // (as in nbr_fast_prepare)
+    if (!nw.ok) return AMOF_OK;
+    const double two32 = 1.0 / 4294967296.0;
+    std::vector<NbrCell> cells((size_t)nc);
+    for (int64_t k = 0; k < nc; k++) {
+        const double *c = t->cell + 9 * k;
+        NbrCell &r = cells[(size_t)k];
+        for (int q = 0; q < 9; q++) r.sc[q] = 0.f;
+        if (nw.ortho) {
+            for (int q = 0; q < 3; q++) r.sc[q] = (float)(c[4 * q] * two32);
+        } else {
+            for (int q = 0; q < 9; q++) r.sc[q] = (float)(c[q] * two32);
+        }
+        r._pad = 0.f;
+        r.gap_per_len = 0.0;
+    }
+    std::vector<int64_t> sp_first((size_t)S + 1, 0);
+    for (int x = 0; x < S; x++) sp_first[(size_t)x + 1] = sp_first[(size_t)x] + st.tiles.nsp[(size_t)x];
+    AMOF_TRY(upload(ctx, SLOT_AUX4, cells.data(), cells.size() * sizeof(NbrCell), &nw.d_cells));
+    AMOF_TRY(upload(ctx, SLOT_AUX5, sp_first.data(), sp_first.size() * sizeof(int64_t), &nw.d_spfirst));
+    AMOF_TRY(ensure(ctx, SLOT_SPEC, sizeof(int32_t), &nw.d_qflag));
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(nw.d_qflag, 0, sizeof(int32_t), ctx->stream));
+    FrameArgs &fr = nw.fr;
+    fr.cells = (const NbrCell *)nw.d_cells;
+    fr.sp_first = (const int64_t *)nw.d_spfirst;
+    fr.qflag = (int32_t *)nw.d_qflag;
+    {
+        const double want = grel + 3.0 / 16777216.0;     // (+ 3u: see nbr_fast_prepare)
+        float fg = (float)want;
+        if ((double)fg < want) fg = nextafterf(fg, INFINITY);
+        fr.guard_rel = fg;
+    }
+    fr.guard_abs = (float)(csum * (1.0 / 2147483648.0));
+    return AMOF_OK;
+}
+
 }  // namespace amof
 
 using namespace amof;
@@ -1087,14 +1383,71 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
     a.n_sets = n_sets;
     a.sums = (unsigned long long *)d_sums;
     a.per_atom = (int32_t *)d_pa;
+    bool done = false;
+    {
+        // whole-frame-in-LDS tier: every set with a cutoff is one item (a zero-cutoff set with per-atom output keeps the
+        // gather kernels: its centres still want their zeros)
+        NbrFrame nw;
+        double hmin[3];
+        AMOF_TRY(nbr_frame_prepare(ctx, t, cutoff, st, nw, hmin));
+        for (int s2 = 0; s2 < n_sets && nw.ok; s2++) {
+            const int A = sets[2 * s2], B = sets[2 * s2 + 1];
+            const int64_t nA = st.tiles.nsp[A], nB = st.tiles.nsp[B];
+            if (!(cutoff[A * S + B] > 0.0) || nA == 0 || nB == 0) { nw.ok = !per_atom; continue; }
+            FrameItem it{};
+            it.sa = A; it.sb = B; it.set = s2; it.reg_ab = it.reg_ba = -1;
+            nw.ok = frame_item_grid(hmin, cutoff[A * S + B], A == B ? nA : nA + nB, A == B ? 1 : 2, std::max(nA, nB), it, nw.lds);
+            if (nw.ok) nw.items.push_back(it);
+        }
+        if (nw.ok && !nw.items.empty()) {
+            AMOF_TRY(upload(ctx, SLOT_AUX3, nw.items.data(), nw.items.size() * sizeof(FrameItem), &nw.d_items));
+            nw.fr.items = (const FrameItem *)nw.d_items;
+            int64_t most = 0;
+            for (const FrameItem &it : nw.items)
+                most = std::max<int64_t>(most, st.tiles.nsp[it.sa] + (it.sa == it.sb ? 0 : st.tiles.nsp[it.sb]));
+            nw.fr.cap_atoms = (int32_t)most;
+            int64_t launches = 0;
+            const int64_t FB = std::min<int64_t>(t->n_frames, 32768), FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
+            for (int64_t fb = 0, cur = FB0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
+                const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
+                AMOF_TRY(stager_need(st.stage, fb + nfr));
+                nw.fr.f_base = (int32_t)fb;
+                nw.fr.nf = (int32_t)nfr;
+                if (launches == 0) timing_dom_begin(ctx, "cn_frame");
+                const dim3 grid((unsigned)nw.items.size(), (unsigned)nfr);
+                auto launch = [&](auto kern) -> hipError_t {
+                    hipError_t e2 = allow_max_lds((const void *)kern);
+                    if (e2 == hipSuccess) hipLaunchKernelGGL(kern, grid, dim3(NBRW_THREADS), nw.lds, ctx->stream, a, nw.fr);
+                    return e2;
+                };
+                hipError_t e;
+                if (most <= 4 * NBRW_THREADS) e = nw.ortho ? launch(cn_frame_kernel<true, 4>) : launch(cn_frame_kernel<false, 4>);
+                else e = nw.ortho ? launch(cn_frame_kernel<true, 8>) : launch(cn_frame_kernel<false, 8>);
+                AMOF_HIP_TRY(ctx, e);
+                AMOF_HIP_TRY(ctx, hipGetLastError());
+                launches++;
+            }
+            timing_dom_end(ctx, launches);
+            int32_t qflag = 0;
+            AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nw.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
+            AMOF_HIP_TRY(ctx, sync_stream(ctx));
+            if (qflag) {    // atoms absurdly far from the cell: the exact kernel answers (via the fast path's own check)
+                AMOF_HIP_TRY(ctx, hipMemsetAsync(d_sums, 0, F * n_sets * sizeof(int64_t), ctx->stream));
+                if (per_atom) AMOF_HIP_TRY(ctx, hipMemsetAsync(d_pa, 0xFF, F * n_sets * N * sizeof(int32_t), ctx->stream));
+            } else {
+                done = true;
+            }
+        } else if (nw.ok) {
+            done = true;        // no set has a cutoff and both species: every count is zero
+        }
+    }
     NbrFast nf;
     unsigned long long centre_mask = 0ull;
     if (per_atom)
         for (int s2 = 0; s2 < n_sets; s2++)
             if (sets[2 * s2] < 64) centre_mask |= 1ull << sets[2 * s2];
-    AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf, centre_mask));
-    bool done = false;
-    if (nf.ok) {
+    if (!done) AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf, centre_mask));
+    if (nf.ok && !done) {
         std::vector<int4> fwork;
         for (int s2 = 0; s2 < n_sets; s2++) {
             int A = sets[2 * s2], B = sets[2 * s2 + 1];

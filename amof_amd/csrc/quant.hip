@@ -7,27 +7,6 @@
 
 namespace amof {
 
-__device__ __forceinline__ QAtom quantize_atom(const double *__restrict__ pos, const double *__restrict__ g,
-                                                int64_t N, int f, int64_t a, int ax0, int ax1, int ax2,
-                                                int32_t *flag)
-{
-    const double *__restrict__ p = pos + ((size_t)f * N + a) * 3;
-    const double x = p[0], y = p[1], z = p[2];
-    uint32_t u[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        double s = fma(z, g[15 + c], fma(y, g[12 + c], x * g[9 + c]));
-        if (!(fabs(s) < 1.0e4)) *flag = 1;   // absurdly far from the cell (or NaN): caller falls back
-        s = s - floor(s);
-        double t = s * 4294967296.0;
-        u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
-    }
-    // components are stored in the order (ax0, ax1, ax2): the host puts the slab axis last
-    QAtom q;
-    q.ux = u[ax0]; q.uy = u[ax1]; q.uz = u[ax2]; q.idx = (uint32_t)a;
-    return q;
-}
-
 // One workgroup per (species, frame): fold the atoms into the cell, quantise to 2^-32 of
 // the cell vectors, and counting-sort the species segment into 256 slabs along cell axis
 // `axis` (order inside a slab is arbitrary -- every result downstream is an integer count,

@@ -131,11 +131,14 @@ def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
         assert hip_ctx.last_path() == "cn_exact"
         h_ex, a_ex = hip_ctx.bad_hist(packed, rcm, triples, edges)
         assert hip_ctx.last_path() == "bad_exact"
+    s_frame, pa_frame = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)      # whole frame in LDS (the default tier)
+    assert hip_ctx.last_path() == "cn_frame"
     s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
     h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
     assert np.array_equal(s_fast, s_ref) and np.array_equal(pa_fast, pa_ref)
     assert np.array_equal(s_cell, s_ref) and np.array_equal(pa_cell, pa_ref)
     assert np.array_equal(s_ex, s_ref) and np.array_equal(pa_ex, pa_ref)
+    assert np.array_equal(s_frame, s_ref) and np.array_equal(pa_frame, pa_ref)
     assert np.array_equal(a_fast, a_ref) and np.array_equal(h_fast, h_ref)
     assert np.array_equal(a_cell, a_ref) and np.array_equal(h_cell, h_ref)
     assert np.array_equal(a_ex, a_ref) and np.array_equal(h_ex, h_ref)
@@ -168,7 +171,7 @@ def test_cell_list_sparse_cutoff_matrix_on_poisoned_scratch(hip_ctx, poison):
         with _env(AMOF_NBR_FORCE_CELL="1"):
             hip_ctx.debug_poison(poison)
             s_cell, pa_cell = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
-            assert hip_ctx.last_path() == "cn_cell"
+            assert hip_ctx.last_path() in ("cn_cell", "cn_frame")
             hip_ctx.debug_poison(poison)
             s_only = hip_ctx.cn_count(packed, rcm, sets)
             hip_ctx.debug_poison(poison)
@@ -274,7 +277,7 @@ def test_cell_list_neighbours_on_lattices_and_sheared_cells(hip_ctx):
             assert np.array_equal(a_cell, a_ref) and np.array_equal(h_cell, h_ref), (rc, path_bad)
             if np.array_equal(cell, np.diag(np.diag(cell))):
                 # (a centre with 17 .. 32 neighbours sends the call to the exact kernel's LDS lists, beyond that to the big list)
-                assert path_cn == "cn_cell" and path_bad in ("bad_cell", "bad_exact", "bad_exact_biglist")
+                assert path_cn in ("cn_cell", "cn_frame") and path_bad in ("bad_cell", "bad_exact", "bad_exact_biglist")
 
 
 def test_pairs_exactly_at_the_cutoff(hip_ctx):
