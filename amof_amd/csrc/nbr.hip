@@ -57,6 +57,7 @@ struct NbrArgs {
     int32_t ncap;
     int32_t count_only;        // 1: only find the largest neighbour count (flags[2])
     int32_t global_hist;       // 1: more angle bins than LDS holds -- count with global atomics
+    double edge_step;          // > 0: edges[k] == (double)k * edge_step exactly (hist_bin recomputes them); 0: read the table
     // Transposed neighbour lists (fast BAD kernels).  When both triples B-A-B and A-B-A of a species pair are asked
     // for, only the side with FEWER centres is searched; every pair it finds is also appended to the list of its
     // partner, and the angles around the other species' centres are formed from those lists (bad_transposed_kernel)
@@ -148,11 +149,19 @@ __global__ __launch_bounds__(CN_TILE) void cn_kernel(NbrArgs a)
 // numpy.histogram with explicit edges: bin k holds edges[k] <= x < edges[k+1],
 // the last bin is right-closed; outside -> -1.
 // (e0, en = first / last edge, inv_w = nb / (en - e0): the first guess only -- the comparisons with the edges decide)
-__device__ __forceinline__ int hist_bin(const double *__restrict__ edges, int nb, double x, double e0, double en, double inv_w)
+// step > 0: the host has verified edges[k] == (double)k * step bit for bit (numpy.arange(n) * dtheta, amof/bad.py:143):
+// the edges are then recomputed instead of loaded -- two dependent global loads per angle otherwise
+__device__ __forceinline__ int hist_bin(const double *__restrict__ edges, int nb, double x, double e0, double en, double inv_w,
+                                        double step = 0.0)
 {
     if (!(x >= e0) || !(x <= en)) return -1;
     int k = (int)((x - e0) * inv_w);
     k = max(0, min(k, nb - 1));
+    if (step > 0.0) {
+        while (k > 0 && x < (double)k * step) k--;
+        while (k < nb - 1 && x >= (double)(k + 1) * step) k++;
+        return k;
+    }
     while (k > 0 && x < edges[k]) k--;
     while (k < nb - 1 && x >= edges[k + 1]) k++;
     return k;
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
                 if (dot > 1.0) dot = 1.0;
                 if (dot < -1.0) dot = -1.0;
                 double ang = (180.0 / M_PI) * acos(dot);
-                int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w);
+                int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
                 if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
                     const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
                     atomicAdd(&a.n_angles[slot], 1ull);
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(NBRF_TILE) void cn_fast_kernel(NbrFastArgs fa)
 // band re-decided by the canonical float64 arithmetic on the original positions.
 constexpr int NBRW_THREADS = 1024;
 constexpr int NBRW_MAX_ATOMS = NBRW_THREADS * 8;      // atoms of one item (a thread folds up to 8: frame_sort<PT>)
-constexpr uint32_t NBRW_SLOT1 = 0x80000000u;          // record idx word: atom index | second species of the item
+constexpr uint32_t NBRW_SLOT1 = 0x80000000u;          // record idx word: rank of the atom inside its species | second species of the item
 
 struct FrameItem {
     int32_t sa, sb;            // centre species, partner species (sa == sb: one species staged)
@@ -547,12 +556,11 @@ struct FrameArgs {
     const int64_t *sp_first;   // [S+1]
     int32_t *qflag;            // raised for atoms absurdly far from the cell
     int32_t f_base, nf;
-    int32_t cap_atoms;         // LDS records
     float guard_rel, guard_abs;
 };
 
 struct FrameLds {
-    uint4 *rec;                // [cap_atoms] sorted records: species slot 0 first (cells x fastest), then slot 1
+    uint4 *rec;                // [atoms of the item] sorted records: species slot 0 first (cells x fastest), then slot 1
     uint32_t *cell_end;        // [slots * ncell] end of every cell (its start = the entry before it; 0 for the first)
 };
 
@@ -597,7 +605,7 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
             u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
         }
         const bool second = k >= nA;
-        rec[i] = make_uint4(u[0], u[1], u[2], (uint32_t)atom[i] | (second ? NBRW_SLOT1 : 0u));
+        rec[i] = make_uint4(u[0], u[1], u[2], second ? (uint32_t)(k - nA) | NBRW_SLOT1 : (uint32_t)k);
         key[i] = (second ? (uint32_t)ncell : 0u) +
                  (__umulhi(u[2], (unsigned)nz) * (unsigned)ny + __umulhi(u[1], (unsigned)ny)) * (unsigned)nx +
                  __umulhi(u[0], (unsigned)nx);
@@ -635,17 +643,20 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
 // One task = one centre x one of the 9 rows (dz, dy) of cells around it: its x-run cx-1 .. cx+1 (two index ranges when
 // the run wraps) among the partners of species slot `slot` (0 / 1) of the sorted frame.  Nine lanes share a centre, so a
 // wave's trip count is the fullest ROW of its lanes, not the fullest neighbourhood (per-lane loops over all 27 cells ran
-// at a third of the issue rate: 18 us of a 31 us frame).
+// at a third of the issue rate: 18 us of a 31 us frame).  perm_c / perm_p: the species segments of the centre and of the
+// partners in the species-sorted permutation (records carry ranks; the rare exact re-decision needs the atoms).
+// found(sorted position of the partner, its record).
 template <bool ORTHO, typename F>
 __device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const FrameItem &it, const FrameLds &L, int slot,
                                                      const float *sc, const double *__restrict__ geo,
-                                                     const double *__restrict__ p, const uint4 qc, int r9, double rc, F &&found)
+                                                     const double *__restrict__ p, const int32_t *__restrict__ perm_c,
+                                                     const int32_t *__restrict__ perm_p, const uint4 qc, int r9, double rc,
+                                                     F &&found)
 {
     const int nx = it.nx, ny = it.ny, nz = it.nz;
     const float rcf = (float)rc;
     const float gd = rcf * fr.guard_rel + fr.guard_abs;
     const float r_in = rcf - gd, r_out = rcf + gd;
-    const uint32_t own_idx = qc.w & ~NBRW_SLOT1;
     const int cx = (int)__umulhi(qc.x, (unsigned)nx), cy = (int)__umulhi(qc.y, (unsigned)ny), cz = (int)__umulhi(qc.z, (unsigned)nz);
     const int dz = r9 / 3 - 1, dy = r9 - 3 * (r9 / 3) - 1;
     int cz2 = cz + dz, cy2 = cy + dy;
@@ -661,13 +672,14 @@ __device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const 
     if (wa <= wb) { lo1 = row + wa > 0 ? (int)L.cell_end[row + wa - 1] : 0; hi1 = (int)L.cell_end[row + wb]; }
     const int len0 = hi0 - lo0, total = len0 + hi1 - lo1;
     for (int q = 0; q < total; q++) {
-        const uint4 qj = L.rec[q < len0 ? lo0 + q : lo1 + (q - len0)];
-        const uint32_t idx_j = qj.w & ~NBRW_SLOT1;
-        if (idx_j == own_idx) continue;                         // (no zero-shift self pair)
+        const int j = q < len0 ? lo0 + q : lo1 + (q - len0);
+        const uint4 qj = L.rec[j];
+        if (qj.w == qc.w) continue;                             // (no zero-shift self pair: same species, same rank)
         const float d = nbr_fast_dist<ORTHO>(sc, qc.x, qc.y, qc.z, qj);
         bool nbr = d < r_in;
-        if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, own_idx, idx_j, rc);
-        if (nbr) found(idx_j);
+        if (!nbr && d < r_out)
+            nbr = nbr_exact<ORTHO>(geo, p, (uint32_t)perm_c[qc.w & ~NBRW_SLOT1], (uint32_t)perm_p[qj.w & ~NBRW_SLOT1], rc);
+        if (nbr) found(j, qj);
     }
 }
 
@@ -679,17 +691,18 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void cn_frame_kernel
     __shared__ unsigned wsum[NBRW_THREADS / 64];
     __shared__ unsigned long long wsum64[NBRW_THREADS / 64];
     FrameLds L;
-    L.rec = reinterpret_cast<uint4 *>(lds_raw);
-    L.cell_end = reinterpret_cast<uint32_t *>(L.rec + fr.cap_atoms);
     const int tid = threadIdx.x;
     const FrameItem it = fr.items[blockIdx.x];
     const int f = fr.f_base + (int)blockIdx.y;
     const int nA = (int)(fr.sp_first[it.sa + 1] - fr.sp_first[it.sa]);
     const int nB = it.sa == it.sb ? 0 : (int)(fr.sp_first[it.sb + 1] - fr.sp_first[it.sb]);
+    L.rec = reinterpret_cast<uint4 *>(lds_raw);                         // (every item lays LDS out for its own atom count)
+    L.cell_end = reinterpret_cast<uint32_t *>(L.rec + nA + nB);
     const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+    const int32_t *__restrict__ perm_c = a.perm + fr.sp_first[it.sa], *__restrict__ perm_p = a.perm + fr.sp_first[it.sb];
     int32_t *__restrict__ pa = a.per_atom ? a.per_atom + ((size_t)f * a.n_sets + it.set) * (size_t)a.N : nullptr;
     if (pa)     // every centre starts at zero (the barriers of the sort order these stores before the atomics below)
-        for (int c = tid; c < nA; c += NBRW_THREADS) pa[a.perm[fr.sp_first[it.sa] + c]] = 0;
+        for (int c = tid; c < nA; c += NBRW_THREADS) pa[perm_c[c]] = 0;
     frame_sort<PT>(a, fr, it, L, f, nA, nB, wsum);
     const int gi = a.n_cells == 1 ? 0 : f;
     const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
@@ -703,8 +716,9 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void cn_frame_kernel
         const int c = t / 9, r9 = t - 9 * c;
         const uint4 qc = L.rec[c];
         int cnt = 0;
-        frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, qc, r9, rc, [&](uint32_t) { cnt++; });
-        if (pa && cnt) atomicAdd(&pa[qc.w & ~NBRW_SLOT1], cnt);
+        frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, perm_c, perm_p, qc, r9, rc,
+                                    [&](int, const uint4 &) { cnt++; });
+        if (pa && cnt) atomicAdd(&pa[perm_c[qc.w]], cnt);
         sum += (unsigned long long)cnt;
     }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
@@ -769,7 +783,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
         if (dot > 1.0) dot = 1.0;
         if (dot < -1.0) dot = -1.0;
         const double ang = (180.0 / M_PI) * acos(dot);
-        const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w);
+        const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
         if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
             const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n_centre, a.cn_max) : (size_t)trip;
             atomicAdd(&a.n_angles[slot], 1ull);
@@ -974,7 +988,7 @@ __global__ __launch_bounds__(256) void bad_transposed_kernel(NbrFastArgs fa, con
                 if (dot > 1.0) dot = 1.0;
                 if (dot < -1.0) dot = -1.0;
                 const double ang = (180.0 / M_PI) * acos(dot);
-                const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w);
+                const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
                 if (direct) {
                     atomicAdd(&a.n_angles[hslot], 1ull);
                     if (k >= 0) atomicAdd(&a.hist[hslot * nb + k], 1ull);
@@ -989,6 +1003,234 @@ __global__ __launch_bounds__(256) void bad_transposed_kernel(NbrFastArgs fa, con
     unsigned long long *H = a.hist + (size_t)trip * nb;
     for (int k = tid; k < nb && !direct; k += 256) {
         const unsigned v = thist[k];
+        if (v) atomicAdd(&H[k], (unsigned long long)v);
+    }
+    for (int off = 32; off > 0; off >>= 1) nang += __shfl_down(nang, off, 64);
+    if ((tid & 63) == 0 && nang) atomicAdd(&a.n_angles[trip], nang);
+}
+
+// ---- BAD on the whole-frame tier: rows of unit vectors in HBM, every triple from the rows -------------------------------
+//   lists_frame_kernel  one workgroup per (species pair, frame): sort as cn_frame_kernel, search from the species with
+//                       FEWER atoms, and for every pair found compute the canonical unit vector once (the positions are
+//                       still warm in L2) and append it to the centre's row and, negated, to the partner's -- the
+//                       canonical arithmetic is sign-symmetric (rint, fma, sqrt, division), so the negated vector IS the
+//                       one the partner-centred search would have computed.  Slots are claimed with LDS byte counters:
+//                       no global atomics.  Rows: [frame][R][16] (ux, uy, uz) + [frame][R] counts; R = the centres of
+//                       every ordered pair (A, B) some triple needs, indexed by rank inside species A.
+//   bad_rows_kernel     one lane per centre of a triple B-A-B / X-A-X: streams its rows (one per partner species) and
+//                       bins the angle of every unordered pair of unit vectors (ase get_angles: dot, clip, acos;
+//                       numpy.histogram edges) into an LDS histogram.  No gathers, no barriers inside the loop.
+// The 17 triples the reference asks for with three cutoffs (amof/bad.py:126-131: every ordered species pair + X) share
+// three sorts and three LDS searches.
+constexpr int NBRL_CAP = NBRF_NLIST;      // a fuller centre sends the call to the exact kernels, as in bad_fast_kernel
+constexpr int NBRL_EW = 4;                // doubles per row entry: (ux, uy, uz, -) -- one aligned 32-byte sector per unit vector
+constexpr int NBRW_HITS = 3072;           // pairs lists_frame_kernel buffers in LDS (flushed once half full)
+
+struct NbrListArgs {
+    const int32_t *region_of;  // [S][S] first row of the ordered pair (centre species, partner species); -1: not kept
+    uint32_t *count;           // [frames of the batch][R]
+    double *rows;              // [frames of the batch][R][NBRL_CAP][NBRL_EW] unit vectors centre -> neighbour
+    int32_t R;
+};
+
+template <bool ORTHO, int PT>
+__global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_kernel(NbrArgs a, FrameArgs fr, NbrListArgs la)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ unsigned wsum[NBRW_THREADS / 64];
+    FrameLds L;
+    const int tid = threadIdx.x;
+    const FrameItem it = fr.items[blockIdx.x];          // (sa = the species with fewer atoms: it searches)
+    const int fl = (int)blockIdx.y, f = fr.f_base + fl;
+    const int nA = (int)(fr.sp_first[it.sa + 1] - fr.sp_first[it.sa]);
+    const int nB = it.sa == it.sb ? 0 : (int)(fr.sp_first[it.sb + 1] - fr.sp_first[it.sb]);
+    L.rec = reinterpret_cast<uint4 *>(lds_raw);
+    L.cell_end = reinterpret_cast<uint32_t *>(L.rec + nA + nB);
+    const int n = nA + nB, ntab = (nB > 0 ? 2 : 1) * it.nx * it.ny * it.nz;
+    // neighbours found so far, one BYTE per atom (sorted position), four to a word: a lane claims a slot with
+    // atomicAdd(word, 1 << 8 * (c & 3)) (an atom past 16 fails the call anyway, so a carry into the next byte is harmless)
+    uint32_t *cnt = L.cell_end + ntab;
+    // pairs found, (centre << 13 | partner) by sorted position, waiting for their unit vector: computing it inside the
+    // search loop made every wave pay the float64 path on every trip (some lane always has a hit)
+    uint32_t *hits = cnt + (n + 3) / 4;
+    __shared__ unsigned nhits;
+    for (int c = tid; c < (n + 3) / 4; c += NBRW_THREADS) cnt[c] = 0u;
+    if (tid == 0) nhits = 0u;
+    frame_sort<PT>(a, fr, it, L, f, nA, nB, wsum);
+    const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+    const int32_t *__restrict__ perm_c = a.perm + fr.sp_first[it.sa], *__restrict__ perm_p = a.perm + fr.sp_first[it.sb];
+    const int gi = a.n_cells == 1 ? 0 : f;
+    const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
+    float sc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) sc[k] = fr.cells[gi].sc[k];
+    const double rc = a.cutoff[it.sa * a.S + it.sb];
+    const size_t base = (size_t)fl * la.R;
+    auto claim = [&](int c) -> unsigned {       // next free slot of the atom at sorted position c
+        const unsigned sh = 8u * ((unsigned)c & 3u);
+        return (atomicAdd(&cnt[c >> 2], 1u << sh) >> sh) & 0xffu;
+    };
+    const int tasks = nA * 9;
+    for (int t0 = 0; t0 < tasks; t0 += NBRW_THREADS) {
+        const int t = t0 + tid;
+        if (t < tasks) {
+            const int c = t / 9, r9 = t - 9 * c;
+            frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, perm_c, perm_p, L.rec[c], r9, rc,
+                                        [&](int j, const uint4 &) {
+                const unsigned h = atomicAdd(&nhits, 1u);
+                if (h < (unsigned)NBRW_HITS) hits[h] = ((uint32_t)c << 13) | (uint32_t)j;
+                else a.flags[1] = 1;        // (absurdly many pairs per task: the exact kernels take the call)
+            });
+        }
+        // flush once the buffer is half full, and after the last round (the OR makes the decision uniform: a thread may
+        // read the counter while slower ones still append)
+        const bool half_full = __syncthreads_or(nhits > (unsigned)NBRW_HITS / 2);
+        if (!half_full && t0 + NBRW_THREADS < tasks) continue;
+        // one lane per pair: the canonical unit vector once, to the centre's row and, negated, to the partner's
+        const unsigned nh = min(nhits, (unsigned)NBRW_HITS);
+        for (unsigned h = tid; h < nh; h += NBRW_THREADS) {
+            const int c = (int)(hits[h] >> 13), j = (int)(hits[h] & 0x1fffu);
+            const uint32_t rank_c = L.rec[c].w, rank_j = L.rec[j].w & ~NBRW_SLOT1;
+            const double *pc = p + (size_t)perm_c[rank_c] * 3, *pj = p + (size_t)perm_p[rank_j] * 3;
+            double vx, vy, vz, ux = 0.0, uy = 0.0, uz = 0.0;
+            pair_base<ORTHO>(geo, pj[0] - pc[0], pj[1] - pc[1], pj[2] - pc[2], vx, vy, vz);
+            if (!unit_vec(vx, vy, vz, ux, uy, uz)) a.flags[0] = 1;          // (the call fails: results are discarded)
+            if (it.reg_ab >= 0) {       // (one species: the pair is found from both ends, each end fills its own row)
+                const unsigned k = claim(c);
+                if (k < (unsigned)NBRL_CAP) {
+                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((base + (size_t)(it.reg_ab + (int)rank_c)) * NBRL_CAP + k) * NBRL_EW);
+                    e[0] = make_double2(ux, uy); e[1] = make_double2(uz, 0.0);
+                } else {
+                    a.flags[1] = 1;
+                }
+            }
+            if (it.reg_ba >= 0 && nB > 0) {
+                const unsigned k = claim(j);
+                if (k < (unsigned)NBRL_CAP) {
+                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((base + (size_t)(it.reg_ba + (int)rank_j)) * NBRL_CAP + k) * NBRL_EW);
+                    e[0] = make_double2(-ux, -uy); e[1] = make_double2(-uz, 0.0);
+                } else {
+                    a.flags[1] = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) nhits = 0u;
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += NBRW_THREADS) {
+        const int reg = c < nA ? it.reg_ab : it.reg_ba;
+        if (reg < 0) continue;
+        const uint32_t k = (cnt[c >> 2] >> (8u * ((unsigned)c & 3u))) & 0xffu;
+        la.count[base + (size_t)(reg + (int)(L.rec[c].w & ~NBRW_SLOT1))] = min(k, (uint32_t)NBRL_CAP);
+    }
+}
+
+// work item (blockIdx.y): (triple, centre species, B or -1, -); blockIdx.x strides over the tiles of 256 (frame, centre)
+// pairs of the batch; one LDS histogram per workgroup, no barrier inside the loop (a lane owns its centre)
+template <bool ORTHO>
+__global__ __launch_bounds__(NBRF_TILE) void bad_rows_kernel(NbrArgs a, NbrListArgs la, const int4 *__restrict__ aw,
+                                                             const int64_t *__restrict__ sp_first, int nf)
+{
+    extern __shared__ unsigned hist[];                                    // [nb] unless the counts go straight to global memory
+    const int tid = threadIdx.x;
+    const int4 w = aw[blockIdx.y];
+    const int trip = w.x, sa = w.y, B = w.z;
+    const uint32_t nA = (uint32_t)(sp_first[sa + 1] - sp_first[sa]);
+    const uint32_t total = (uint32_t)nf * nA;                             // (< 2^31: the host sizes the frame batch)
+    const uint32_t tiles = (total + NBRF_TILE - 1) / NBRF_TILE;
+    const int nb = a.nb;
+    const double hb_e0 = a.edges[0], hb_en = a.edges[nb], hb_inv_w = (double)nb / (hb_en - hb_e0);
+    const bool direct = a.cn_max > 0 || a.global_hist;
+    for (int k = tid; k < nb && !a.global_hist; k += NBRF_TILE) hist[k] = 0u;
+    __syncthreads();
+    // the partner species of the triple that keep rows for this centre species (B >= 0: one), in species order
+    int n_reg = 0, reg0 = 0, reg1 = 0, reg2 = 0;
+    for (int sb = 0; sb < a.S; sb++)
+        if ((B < 0 || sb == B) && la.region_of[sa * a.S + sb] >= 0) {
+            const int reg = la.region_of[sa * a.S + sb];
+            if (n_reg == 0) reg0 = reg; else if (n_reg == 1) reg1 = reg; else if (n_reg == 2) reg2 = reg;
+            n_reg++;
+        }
+    auto reg_sb = [&](int q) {          // species of the q-th such partner (q >= 3 only: rare)
+        int seen = 0;
+        for (int sb = 0; sb < a.S; sb++)
+            if ((B < 0 || sb == B) && la.region_of[sa * a.S + sb] >= 0 && seen++ == q) return sb;
+        return 0;
+    };
+    unsigned long long nang = 0;
+    // a centre's rows: the counts of its first three partner species in registers, any further ones re-read
+    struct Centre {
+        size_t cbase;
+        int n, c0, c1, c2;
+    };
+    auto load_centre = [&](uint32_t tile) -> Centre {
+        Centre ce{0, 0, 0, 0, 0};
+        const uint32_t flat = tile * (uint32_t)NBRF_TILE + tid;
+        if (tile >= tiles || flat >= total) return ce;
+        const uint32_t fl = flat / nA, r = flat - fl * nA;
+        ce.cbase = (size_t)fl * la.R + r;
+        for (int q = 0; q < n_reg; q++) {
+            const int c = (int)la.count[ce.cbase + (q == 0 ? reg0 : q == 1 ? reg1 : q == 2 ? reg2 : la.region_of[sa * a.S + reg_sb(q)])];
+            if (q == 0) ce.c0 = c; else if (q == 1) ce.c1 = c; else if (q == 2) ce.c2 = c;
+            ce.n += c;
+        }
+        return ce;
+    };
+    auto angles_of = [&](const Centre &ce) {
+        const int n = ce.n;
+        if (n < 2) return;          // a centre with a single neighbour -- every N of ZIF-4 -- forms no angle
+        if (n > NBRL_CAP) { a.flags[1] = 1; return; }        // (as bad_fast_kernel: more than 16 in all -> the exact kernels)
+        // entry e of the centre = the e-th unit vector over its rows in species order
+        auto entry = [&](int e) -> const double * {
+            if (e < ce.c0) return la.rows + ((ce.cbase + reg0) * NBRL_CAP + e) * NBRL_EW;
+            e -= ce.c0;
+            if (e < ce.c1) return la.rows + ((ce.cbase + reg1) * NBRL_CAP + e) * NBRL_EW;
+            e -= ce.c1;
+            if (e < ce.c2) return la.rows + ((ce.cbase + reg2) * NBRL_CAP + e) * NBRL_EW;
+            e -= ce.c2;
+            for (int q = 3; q < n_reg; q++) {
+                const int reg = la.region_of[sa * a.S + reg_sb(q)];
+                const int c = (int)la.count[ce.cbase + reg];
+                if (e < c) return la.rows + ((ce.cbase + reg) * NBRL_CAP + e) * NBRL_EW;
+                e -= c;
+            }
+            return la.rows;     // (not reached: e < n)
+        };
+        const size_t hslot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
+        for (int u = 0; u + 1 < n; u++) {
+            const double2 *eu = reinterpret_cast<const double2 *>(entry(u));
+            const double2 a01 = eu[0], a2 = eu[1];
+            const double ax = a01.x, ay = a01.y, az = a2.x;
+            for (int v = u + 1; v < n; v++) {
+                const double2 *ev = reinterpret_cast<const double2 *>(entry(v));
+                const double2 b01 = ev[0], b2 = ev[1];
+                double dot = ax * b01.x + ay * b01.y + az * b2.x;
+                if (dot > 1.0) dot = 1.0;
+                if (dot < -1.0) dot = -1.0;
+                const double ang = (180.0 / M_PI) * acos(dot);
+                const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
+                if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
+                    atomicAdd(&a.n_angles[hslot], 1ull);
+                    if (k >= 0) atomicAdd(&a.hist[hslot * nb + k], 1ull);
+                } else {
+                    nang++;
+                    if (k >= 0) atomicAdd(&hist[k], 1u);
+                }
+            }
+        }
+    };
+    // two tiles per trip: the counts of the second are in flight while the first forms its angles
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += 2 * gridDim.x) {
+        const Centre c_a = load_centre(tile), c_b = load_centre(tile + gridDim.x);
+        angles_of(c_a);
+        angles_of(c_b);
+    }
+    __syncthreads();
+    unsigned long long *H = a.hist + (size_t)trip * nb;
+    for (int k = tid; k < nb && !direct; k += NBRF_TILE) {
+        const unsigned v = hist[k];
         if (v) atomicAdd(&H[k], (unsigned long long)v);
     }
     for (int off = 32; off > 0; off >>= 1) nang += __shfl_down(nang, off, 64);
@@ -1258,7 +1500,8 @@ struct NbrFrame {
 };
 
 // a grid for one species pair: cells at least rc thick, >= 3 per axis, as fine as the LDS left beside n records allows
-static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slots, int64_t densest, FrameItem &it, size_t &lds)
+static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slots, int64_t densest, FrameItem &it, size_t &lds,
+                            size_t extra_bytes = 0)
 {
     if (n > NBRW_MAX_ATOMS || n <= 0) return false;
     int nk[3];
@@ -1266,7 +1509,7 @@ static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slot
         nk[x] = (int)std::min(1024.0, floor(hmin[x] / (rc * (1.0 + 1e-5))));
         if (nk[x] < 3) return false;
     }
-    const size_t rec_bytes = (size_t)n * sizeof(uint4);
+    const size_t rec_bytes = (size_t)n * sizeof(uint4) + extra_bytes;      // (+ whatever else the kernel keeps per atom)
     // two workgroups per CU when the records leave room for a useful table, one otherwise
     size_t budget = 76 * 1024;
     if (rec_bytes + (size_t)slots * 4 * std::min<int64_t>(densest / 2 + 27, 4096) > budget) budget = 152 * 1024;
@@ -1405,7 +1648,6 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
             int64_t most = 0;
             for (const FrameItem &it : nw.items)
                 most = std::max<int64_t>(most, st.tiles.nsp[it.sa] + (it.sa == it.sb ? 0 : st.tiles.nsp[it.sb]));
-            nw.fr.cap_atoms = (int32_t)most;
             int64_t launches = 0;
             const int64_t FB = std::min<int64_t>(t->n_frames, 32768), FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
             for (int64_t fb = 0, cur = FB0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
@@ -1527,6 +1769,16 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
     a.work = (const int4 *)d_work;
     a.edges = (const double *)d_edges;
     a.nb = nb;
+    a.edge_step = 0.0;
+    if (edges[0] == 0.0 && !getenv("AMOF_BAD_EDGE_TABLE")) {
+        volatile double step = edges[1];
+        bool uniform = true;
+        for (int k = 0; k <= nb && uniform; k++) {
+            volatile double e = (double)k * step;      // (one IEEE multiplication, as numpy and the kernels do it)
+            uniform = e == edges[k];
+        }
+        if (uniform) a.edge_step = step;
+    }
     a.flags = (int32_t *)d_flags;
     a.cn_max = cn_max;
     a.nbuf = nullptr;
@@ -1553,11 +1805,128 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 4 * sizeof(int32_t), ctx->stream));
         return AMOF_OK;
     };
-    NbrFast nf;
-    AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf));
     bool done = false, overflow = false;
     int32_t flags[4] = {0, 0, 0, 0};
-    if (nf.ok && t->n_frames > 0) {
+    {
+        // ---- whole-frame-in-LDS tier: one sort + LDS search per species pair into neighbour rows, every triple from the rows
+        const int S = t->n_species;
+        NbrFrame nw;
+        double hmin[3];
+        AMOF_TRY(nbr_frame_prepare(ctx, t, cutoff, st, nw, hmin));
+        if (getenv("AMOF_BAD_NOTRANSPOSE")) nw.ok = false;      // (names the two-search gather kernels)
+        auto live_pair = [&](int x, int y) { return cutoff[x * S + y] > 0.0 && st.tiles.nsp[x] > 0 && st.tiles.nsp[y] > 0; };
+        std::vector<char> needed((size_t)S * S, 0);
+        std::vector<int4> awork;
+        for (int k = 0; k < T && nw.ok; k++) {
+            const int A = triples[2 * k], B = triples[2 * k + 1];
+            for (int sa = 0; sa < S; sa++) {
+                if (!(A < 0 || sa == A)) continue;
+                bool live = false;
+                for (int sb = 0; sb < S; sb++)
+                    if ((B < 0 || sb == B) && live_pair(sa, sb)) { needed[(size_t)sa * S + sb] = 1; live = true; }
+                if (live) awork.push_back(make_int4(k, sa, B, 0));
+            }
+        }
+        std::vector<int32_t> region_of((size_t)S * S, -1);
+        int64_t R = 0;
+        for (int x = 0; x < S * S && nw.ok; x++)
+            if (needed[(size_t)x]) { region_of[(size_t)x] = (int32_t)R; R += st.tiles.nsp[(size_t)(x / S)]; }
+        int64_t most = 0;
+        for (int x = 0; x < S && nw.ok; x++)
+            for (int y = x; y < S && nw.ok; y++) {
+                if (!needed[(size_t)x * S + y] && !needed[(size_t)y * S + x]) continue;
+                FrameItem it{};
+                it.sa = st.tiles.nsp[y] < st.tiles.nsp[x] ? y : x;      // the species with fewer atoms searches
+                it.sb = it.sa == x ? y : x;
+                it.set = 0;
+                it.reg_ab = region_of[(size_t)it.sa * S + it.sb];
+                it.reg_ba = x == y ? -1 : region_of[(size_t)it.sb * S + it.sa];
+                const int64_t n = st.tiles.nsp[x] + (x == y ? 0 : st.tiles.nsp[y]);
+                size_t lds_it = 0;
+                nw.ok = frame_item_grid(hmin, cutoff[x * S + y], n, x == y ? 1 : 2, std::max(st.tiles.nsp[x], st.tiles.nsp[y]), it, lds_it,
+                                        (size_t)((n + 3) / 4) * 4 + (size_t)NBRW_HITS * sizeof(uint32_t));
+                nw.lds = std::max(nw.lds, lds_it);
+                most = std::max(most, n);
+                if (nw.ok) nw.items.push_back(it);
+            }
+        if (nw.ok && !awork.empty() && R > 0 && R < (1ll << 30) && t->n_frames > 0) {
+            // one small table: angle work | region_of[S*S]; the items beside it
+            std::vector<int32_t> tab(4 * awork.size() + (size_t)S * S);
+            memcpy(tab.data(), awork.data(), awork.size() * sizeof(int4));
+            memcpy(&tab[4 * awork.size()], region_of.data(), region_of.size() * sizeof(int32_t));
+            void *d_tab, *d_lists;
+            AMOF_TRY(upload(ctx, SLOT_AUX8, tab.data(), tab.size() * sizeof(int32_t), &d_tab));
+            AMOF_TRY(upload(ctx, SLOT_AUX6, nw.items.data(), nw.items.size() * sizeof(FrameItem), &nw.d_items));
+            nw.fr.items = (const FrameItem *)nw.d_items;
+            const size_t per_frame = (size_t)R * (sizeof(uint32_t) + (size_t)NBRL_CAP * NBRL_EW * sizeof(double));
+            int64_t FB = std::max<int64_t>(1, (int64_t)((size_t)4 << 30) / (int64_t)per_frame);                 // <= 4 GiB of rows
+            FB = std::min<int64_t>(FB, std::max<int64_t>(1, 0x7fffff00ll / std::max<int64_t>(1, t->n_atoms)));    // flat (frame, centre) index
+            FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), t->n_frames);
+            const int64_t FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
+            AMOF_TRY(ensure(ctx, SLOT_AUX9, (size_t)FB * per_frame, &d_lists));
+            NbrListArgs la;
+            const int4 *d_aw = (const int4 *)d_tab;
+            la.region_of = (const int32_t *)d_tab + 4 * awork.size();
+            la.rows = (double *)d_lists;                                   // (doubles first: 8-byte aligned)
+            la.count = (uint32_t *)(la.rows + (size_t)FB * R * NBRL_CAP * NBRL_EW);
+            la.R = (int32_t)R;
+            const size_t lds_rows = lds_bins * sizeof(unsigned);
+            int64_t launches = 0;
+            for (int64_t fb = 0, cur = FB0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
+                const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
+                AMOF_TRY(stager_need(st.stage, fb + nfr));
+                nw.fr.f_base = (int32_t)fb;
+                nw.fr.nf = (int32_t)nfr;
+                if (launches == 0) timing_dom_begin(ctx, "bad_frame");
+                const dim3 sgrid((unsigned)nw.items.size(), (unsigned)nfr);
+                auto launch = [&](auto kern) -> hipError_t {
+                    hipError_t e2 = allow_max_lds((const void *)kern);
+                    if (e2 == hipSuccess) hipLaunchKernelGGL(kern, sgrid, dim3(NBRW_THREADS), nw.lds, ctx->stream, a, nw.fr, la);
+                    return e2;
+                };
+                hipError_t e;
+                if (most <= 4 * NBRW_THREADS) e = nw.ortho ? launch(lists_frame_kernel<true, 4>) : launch(lists_frame_kernel<false, 4>);
+                else e = nw.ortho ? launch(lists_frame_kernel<true, 8>) : launch(lists_frame_kernel<false, 8>);
+                AMOF_HIP_TRY(ctx, e);
+                AMOF_HIP_TRY(ctx, hipGetLastError());
+                // angle kernel: about eight workgroups per CU in all work items together, each striding over the tiles of its own
+                int64_t widest = 0;
+                for (const int4 &w : awork) widest = std::max<int64_t>(widest, (nfr * st.tiles.nsp[(size_t)w.y] + NBRF_TILE - 1) / NBRF_TILE);
+                // (every workgroup ends with one global atomic per non-empty bin of its histogram, all on the same few
+                //  addresses: 16 384 workgroups spent more time there than on the angles)
+                const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(widest, (2048 + (int64_t)awork.size() - 1) / (int64_t)awork.size()));
+                const dim3 agrid((unsigned)gx, (unsigned)awork.size());
+                if (nw.ortho) {
+                    e = allow_max_lds((const void *)bad_rows_kernel<true>);
+                    if (e == hipSuccess) hipLaunchKernelGGL(bad_rows_kernel<true>, agrid, dim3(NBRF_TILE), lds_rows, ctx->stream, a, la, d_aw,
+                                                            (const int64_t *)nw.d_spfirst, (int)nfr);
+                } else {
+                    e = allow_max_lds((const void *)bad_rows_kernel<false>);
+                    if (e == hipSuccess) hipLaunchKernelGGL(bad_rows_kernel<false>, agrid, dim3(NBRF_TILE), lds_rows, ctx->stream, a, la, d_aw,
+                                                            (const int64_t *)nw.d_spfirst, (int)nfr);
+                }
+                AMOF_HIP_TRY(ctx, e);
+                AMOF_HIP_TRY(ctx, hipGetLastError());
+                launches++;
+            }
+            timing_dom_end(ctx, launches);
+            int32_t qflag = 0;
+            AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nw.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
+            AMOF_TRY(read_flags(flags));
+            if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
+            if (qflag || flags[1]) {
+                // atoms absurdly far from the cell, or a centre with more than NBRL_CAP neighbours: the gather / exact kernels
+                AMOF_TRY(clear_scratch());
+            } else {
+                done = true;
+            }
+        } else if (nw.ok && awork.empty()) {
+            done = true;            // no triple has a centre with a cutoff to any of its partners: no angle
+        }
+    }
+    NbrFast nf;
+    if (!done) AMOF_TRY(nbr_fast_prepare(ctx, t, cutoff, st, nf));
+    if (nf.ok && !done && t->n_frames > 0) {
         const int S = t->n_species;
         // transposed lists: of two triples B-A-B / A-B-A over one species pair, only the side with fewer centres searches
         std::vector<int32_t> derived_from((size_t)T, -1), tr_off((size_t)T, -1);

@@ -198,7 +198,7 @@ def test_config3_bad_and_cn_at_9792_atoms(hip_ctx, traj544):
     edges = np.arange(bins + 2) * 0.05
     triples = [(n, zn), (zn, n)]          # Zn-N-Zn (centre N), N-Zn-N (centre Zn)
     full, nang = hip_ctx.bad_hist(packed, rcm, triples, edges)
-    assert hip_ctx.last_path() == "bad_cell"       # 3-D cell list: cutoff 2.5 A in a 46 x 46 x 74 A cell
+    assert hip_ctx.last_path() == "bad_frame"      # Zn + N of a frame fit in LDS: one workgroup sorts and searches it there
     sample = [0, 67, 68, 271, 272, 543]
     pos_s = _host_frames(packed, sample)
     for q, k in enumerate(sample):

@@ -133,6 +133,8 @@ def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
         assert hip_ctx.last_path() == "bad_exact"
     s_frame, pa_frame = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)      # whole frame in LDS (the default tier)
     assert hip_ctx.last_path() == "cn_frame"
+    h_frame, a_frame = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_frame"
     s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
     h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
     assert np.array_equal(s_fast, s_ref) and np.array_equal(pa_fast, pa_ref)
@@ -142,6 +144,7 @@ def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
     assert np.array_equal(a_fast, a_ref) and np.array_equal(h_fast, h_ref)
     assert np.array_equal(a_cell, a_ref) and np.array_equal(h_cell, h_ref)
     assert np.array_equal(a_ex, a_ref) and np.array_equal(h_ex, h_ref)
+    assert np.array_equal(a_frame, a_ref) and np.array_equal(h_frame, h_ref)
     assert a_ref.sum() > 0
 
 
@@ -266,18 +269,28 @@ def test_cell_list_neighbours_on_lattices_and_sheared_cells(hip_ctx):
             rcm[0, 0] = 0.0
             sets = [(x, y) for x in range(3) for y in range(3)]
             triples = [(2, 1), (1, -1), (-1, -1)]
+            s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, 3, rcm, sets, per_atom=True)
+            h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, 3, rcm, triples, edges)
             with _env(AMOF_NBR_FORCE_CELL="1"):
                 s_cell, pa_cell = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
                 path_cn = hip_ctx.last_path()
                 h_cell, a_cell = hip_ctx.bad_hist(packed, rcm, triples, edges)
                 path_bad = hip_ctx.last_path()
-            s_ref, pa_ref = clib.cn_counts(packed.pos, packed.cell, sp, 3, rcm, sets, per_atom=True)
-            h_ref, a_ref = clib.bad_hist(packed.pos, packed.cell, sp, 3, rcm, triples, edges)
             assert np.array_equal(s_cell, s_ref) and np.array_equal(pa_cell, pa_ref), (rc, path_cn)
             assert np.array_equal(a_cell, a_ref) and np.array_equal(h_cell, h_ref), (rc, path_bad)
             if np.array_equal(cell, np.diag(np.diag(cell))):
                 # (a centre with 17 .. 32 neighbours sends the call to the exact kernel's LDS lists, beyond that to the big list)
-                assert path_cn in ("cn_cell", "cn_frame") and path_bad in ("bad_cell", "bad_exact", "bad_exact_biglist")
+                assert path_cn == "cn_cell" and path_bad in ("bad_cell", "bad_exact", "bad_exact_biglist")
+            # the whole-frame-in-LDS tier on the same inputs (sets with a cutoff only: a zero-cutoff set with per-atom
+            # output keeps the gather kernels)
+            live = [(x, y) for (x, y) in sets if rcm[x, y] > 0]
+            s_fr, pa_fr = hip_ctx.cn_count(packed, rcm, live, per_atom=True)
+            assert hip_ctx.last_path() == "cn_frame"
+            keep = [k for k, xy in enumerate(sets) if rcm[xy] > 0]
+            assert np.array_equal(s_fr, s_ref[:, keep]) and np.array_equal(pa_fr, pa_ref[:, keep]), rc
+            h_fr, a_fr = hip_ctx.bad_hist(packed, rcm, triples, edges)
+            assert hip_ctx.last_path() in ("bad_frame", "bad_exact", "bad_exact_biglist")
+            assert np.array_equal(a_fr, a_ref) and np.array_equal(h_fr, h_ref), rc
 
 
 def test_pairs_exactly_at_the_cutoff(hip_ctx):
