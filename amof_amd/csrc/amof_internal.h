@@ -212,6 +212,29 @@ int stager_begin(amof_ctx *ctx, const amof_traj *t, bool allow_lazy, Stager &st)
 int stager_need(Stager &st, int64_t f1);
 int upload(amof_ctx *ctx, Slot s, const void *src, size_t bytes, void **out);
 
+// Several small tables in ONE device buffer with ONE host-to-device copy: however small, a copy costs ~5 us of queue time and
+// a dozen of them in front of a 0.25 ms kernel were a third of a call.  add() the pieces, upload_pack(), then ptr<T>(i).
+struct UploadPack {
+    struct Piece {
+        const void *src;
+        size_t bytes, off;
+    };
+    std::vector<Piece> pieces;
+    size_t total = 0;
+    void *base = nullptr;
+    int add(const void *src, size_t bytes)
+    {
+        pieces.push_back(Piece{src, bytes, total});
+        total += (bytes + 255) & ~(size_t)255;
+        return (int)pieces.size() - 1;
+    }
+    template <typename T> const T *ptr(int i) const
+    {
+        return reinterpret_cast<const T *>(static_cast<const unsigned char *>(base) + pieces[(size_t)i].off);
+    }
+};
+int upload_pack(amof_ctx *ctx, Slot s, UploadPack &pk);
+
 // fixed-point atom record of the fast paths: fractional coordinates * 2^32 in the stored
 // axis order (slab axis last), original atom index
 struct QAtom {

@@ -70,6 +70,26 @@ int upload(amof_ctx *ctx, Slot s, const void *src, size_t bytes, void **out)
     return AMOF_OK;
 }
 
+int upload_pack(amof_ctx *ctx, Slot s, UploadPack &pk)
+{
+    AMOF_TRY(ensure(ctx, s, pk.total, &pk.base));
+    if (!pk.total) return AMOF_OK;
+    if (ctx->pin && pk.total <= ctx->pin_cap - ctx->pin_off) {
+        unsigned char *stage = ctx->pin + ctx->pin_off;
+        for (const UploadPack::Piece &pc : pk.pieces)
+            if (pc.bytes) memcpy(stage + pc.off, pc.src, pc.bytes);
+        ctx->pin_off += pk.total;
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(pk.base, stage, pk.total, hipMemcpyHostToDevice, ctx->stream));
+        return AMOF_OK;
+    }
+    // too big for the staging ring: piece by piece (pageable-host copies return once the source has been consumed)
+    for (const UploadPack::Piece &pc : pk.pieces)
+        if (pc.bytes)
+            AMOF_HIP_TRY(ctx, hipMemcpyAsync(static_cast<unsigned char *>(pk.base) + pc.off, pc.src, pc.bytes, hipMemcpyHostToDevice,
+                                             ctx->stream));
+    return AMOF_OK;
+}
+
 int stage_positions(amof_ctx *ctx, const amof_traj *t, const double **pos_dev)
 {
     if (t->pos_on_device) {

@@ -1266,26 +1266,27 @@ static int nbr_setup(amof_ctx *ctx, const amof_traj *t, const double *cutoff, in
     timing_begin(ctx);
     AMOF_TRY(stager_begin(ctx, t, true, s.stage));
     const double *pos_dev = s.stage.dev;
-    void *d_geom, *d_img, *d_nimg, *d_perm, *d_tiles, *d_ft, *d_nt, *d_cut;
-    AMOF_TRY(upload(ctx, SLOT_GEOM, s.geom.rec.data(), s.geom.rec.size() * sizeof(double), &d_geom));
-    AMOF_TRY(upload(ctx, SLOT_IMG, s.img.data(), s.img.size() * sizeof(double), &d_img));
-    AMOF_TRY(upload(ctx, SLOT_NIMG, s.nimg.data(), s.nimg.size() * sizeof(int32_t), &d_nimg));
-    AMOF_TRY(upload(ctx, SLOT_PERM, s.tiles.perm.data(), s.tiles.perm.size() * sizeof(int32_t), &d_perm));
-    AMOF_TRY(upload(ctx, SLOT_TILES, s.tiles.tiles.data(), s.tiles.tiles.size() * sizeof(Tile), &d_tiles));
-    AMOF_TRY(upload(ctx, SLOT_AUX0, s.tiles.sp_first_tile.data(), S * sizeof(int32_t), &d_ft));
-    AMOF_TRY(upload(ctx, SLOT_AUX1, s.tiles.sp_ntiles.data(), S * sizeof(int32_t), &d_nt));
-    AMOF_TRY(upload(ctx, SLOT_AUX2, cutoff, (size_t)S * S * sizeof(double), &d_cut));
+    UploadPack pk;      // (one copy for the eight tables)
+    const int i_geom = pk.add(s.geom.rec.data(), s.geom.rec.size() * sizeof(double));
+    const int i_img = pk.add(s.img.data(), s.img.size() * sizeof(double));
+    const int i_nimg = pk.add(s.nimg.data(), s.nimg.size() * sizeof(int32_t));
+    const int i_perm = pk.add(s.tiles.perm.data(), s.tiles.perm.size() * sizeof(int32_t));
+    const int i_tiles = pk.add(s.tiles.tiles.data(), s.tiles.tiles.size() * sizeof(Tile));
+    const int i_ft = pk.add(s.tiles.sp_first_tile.data(), S * sizeof(int32_t));
+    const int i_nt = pk.add(s.tiles.sp_ntiles.data(), S * sizeof(int32_t));
+    const int i_cut = pk.add(cutoff, (size_t)S * S * sizeof(double));
+    AMOF_TRY(upload_pack(ctx, SLOT_GEOM, pk));
     NbrArgs &a = s.a;
     a = NbrArgs{};
     a.pos = pos_dev;
-    a.geom = (const double *)d_geom;
-    a.img = (const double *)d_img;
-    a.nimg = (const int32_t *)d_nimg;
-    a.perm = (const int32_t *)d_perm;
-    a.tiles = (const Tile *)d_tiles;
-    a.sp_first_tile = (const int32_t *)d_ft;
-    a.sp_ntiles = (const int32_t *)d_nt;
-    a.cutoff = (const double *)d_cut;
+    a.geom = pk.ptr<double>(i_geom);
+    a.img = pk.ptr<double>(i_img);
+    a.nimg = pk.ptr<int32_t>(i_nimg);
+    a.perm = pk.ptr<int32_t>(i_perm);
+    a.tiles = pk.ptr<Tile>(i_tiles);
+    a.sp_first_tile = pk.ptr<int32_t>(i_ft);
+    a.sp_ntiles = pk.ptr<int32_t>(i_nt);
+    a.cutoff = pk.ptr<double>(i_cut);
     a.N = t->n_atoms;
     a.F = (int32_t)t->n_frames;
     a.n_cells = (int32_t)t->n_cells;
@@ -1496,7 +1497,11 @@ struct NbrFrame {
     std::vector<FrameItem> items;
     size_t lds = 0;
     FrameArgs fr;
-    void *d_items = nullptr, *d_cells = nullptr, *d_spfirst = nullptr, *d_qflag = nullptr;
+    std::vector<NbrCell> cells;
+    std::vector<int64_t> sp_first;
+    UploadPack pk;          // cells | sp_first | items (| whatever the caller adds first): one copy (nbr_frame_commit)
+    const int64_t *d_spfirst = nullptr;
+    void *d_qflag = nullptr;
 };
 
 // a grid for one species pair: cells at least rc thick, >= 3 per axis, as fine as the LDS left beside n records allows
@@ -1556,10 +1561,10 @@ static int nbr_frame_prepare(amof_ctx *ctx, const amof_traj *t, const double *cu
             if (R * (1.0 + 4.0 * grel + 1e-6) >= 0.5 * hmin[x]) nw.ok = false;     // (as in nbr_fast_prepare)
     if (!nw.ok) return AMOF_OK;
     const double two32 = 1.0 / 4294967296.0;
-    std::vector<NbrCell> cells((size_t)nc);
+    nw.cells.assign((size_t)nc, NbrCell{});
     for (int64_t k = 0; k < nc; k++) {
         const double *c = t->cell + 9 * k;
-        NbrCell &r = cells[(size_t)k];
+        NbrCell &r = nw.cells[(size_t)k];
         for (int q = 0; q < 9; q++) r.sc[q] = 0.f;
         if (nw.ortho) {
             for (int q = 0; q < 3; q++) r.sc[q] = (float)(c[4 * q] * two32);
@@ -1569,16 +1574,9 @@ static int nbr_frame_prepare(amof_ctx *ctx, const amof_traj *t, const double *cu
         r._pad = 0.f;
         r.gap_per_len = 0.0;
     }
-    std::vector<int64_t> sp_first((size_t)S + 1, 0);
-    for (int x = 0; x < S; x++) sp_first[(size_t)x + 1] = sp_first[(size_t)x] + st.tiles.nsp[(size_t)x];
-    AMOF_TRY(upload(ctx, SLOT_AUX4, cells.data(), cells.size() * sizeof(NbrCell), &nw.d_cells));
-    AMOF_TRY(upload(ctx, SLOT_AUX5, sp_first.data(), sp_first.size() * sizeof(int64_t), &nw.d_spfirst));
-    AMOF_TRY(ensure(ctx, SLOT_SPEC, sizeof(int32_t), &nw.d_qflag));
-    AMOF_HIP_TRY(ctx, hipMemsetAsync(nw.d_qflag, 0, sizeof(int32_t), ctx->stream));
+    nw.sp_first.assign((size_t)S + 1, 0);
+    for (int x = 0; x < S; x++) nw.sp_first[(size_t)x + 1] = nw.sp_first[(size_t)x] + st.tiles.nsp[(size_t)x];
     FrameArgs &fr = nw.fr;
-    fr.cells = (const NbrCell *)nw.d_cells;
-    fr.sp_first = (const int64_t *)nw.d_spfirst;
-    fr.qflag = (int32_t *)nw.d_qflag;
     {
         const double want = grel + 3.0 / 16777216.0;     // (+ 3u: see nbr_fast_prepare)
         float fg = (float)want;
@@ -1586,6 +1584,22 @@ static int nbr_frame_prepare(amof_ctx *ctx, const amof_traj *t, const double *cu
         fr.guard_rel = fg;
     }
     fr.guard_abs = (float)(csum * (1.0 / 2147483648.0));
+    return AMOF_OK;
+}
+
+// the tier takes the call: its tables (and whatever the caller added to nw.pk before) to the device in one copy
+static int nbr_frame_commit(amof_ctx *ctx, NbrFrame &nw)
+{
+    const int i_cells = nw.pk.add(nw.cells.data(), nw.cells.size() * sizeof(NbrCell));
+    const int i_sp = nw.pk.add(nw.sp_first.data(), nw.sp_first.size() * sizeof(int64_t));
+    const int i_items = nw.pk.add(nw.items.data(), nw.items.size() * sizeof(FrameItem));
+    AMOF_TRY(upload_pack(ctx, SLOT_AUX4, nw.pk));
+    AMOF_TRY(ensure(ctx, SLOT_SPEC, sizeof(int32_t), &nw.d_qflag));
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(nw.d_qflag, 0, sizeof(int32_t), ctx->stream));
+    nw.fr.cells = nw.pk.ptr<NbrCell>(i_cells);
+    nw.fr.sp_first = nw.d_spfirst = nw.pk.ptr<int64_t>(i_sp);
+    nw.fr.items = nw.pk.ptr<FrameItem>(i_items);
+    nw.fr.qflag = (int32_t *)nw.d_qflag;
     return AMOF_OK;
 }
 
@@ -1613,8 +1627,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
             work.push_back(make_int4(s, st.tiles.sp_first_tile[A] + k, A, B));
     }
     const size_t F = (size_t)t->n_frames, N = (size_t)t->n_atoms;
-    void *d_work, *d_sums, *d_pa = nullptr;
-    AMOF_TRY(upload(ctx, SLOT_PAIRS, work.data(), work.size() * sizeof(int4), &d_work));
+    void *d_sums, *d_pa = nullptr;
     AMOF_TRY(ensure(ctx, SLOT_OUT0, F * n_sets * sizeof(int64_t), &d_sums));
     AMOF_HIP_TRY(ctx, hipMemsetAsync(d_sums, 0, F * n_sets * sizeof(int64_t), ctx->stream));
     if (per_atom) {
@@ -1622,7 +1635,6 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         AMOF_HIP_TRY(ctx, hipMemsetAsync(d_pa, 0xFF, F * n_sets * N * sizeof(int32_t), ctx->stream));
     }
     NbrArgs &a = st.a;
-    a.work = (const int4 *)d_work;
     a.n_sets = n_sets;
     a.sums = (unsigned long long *)d_sums;
     a.per_atom = (int32_t *)d_pa;
@@ -1643,8 +1655,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
             if (nw.ok) nw.items.push_back(it);
         }
         if (nw.ok && !nw.items.empty()) {
-            AMOF_TRY(upload(ctx, SLOT_AUX3, nw.items.data(), nw.items.size() * sizeof(FrameItem), &nw.d_items));
-            nw.fr.items = (const FrameItem *)nw.d_items;
+            AMOF_TRY(nbr_frame_commit(ctx, nw));
             int64_t most = 0;
             for (const FrameItem &it : nw.items)
                 most = std::max<int64_t>(most, st.tiles.nsp[it.sa] + (it.sa == it.sb ? 0 : st.tiles.nsp[it.sb]));
@@ -1728,6 +1739,9 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
     }
     AMOF_TRY(stager_need(st.stage, t->n_frames));   // (no-op unless the fast path was skipped)
     if (!done && !work.empty()) {
+        void *d_work;       // (the exact kernel's work list: uploaded only when it runs)
+        AMOF_TRY(upload(ctx, SLOT_PAIRS, work.data(), work.size() * sizeof(int4), &d_work));
+        a.work = (const int4 *)d_work;
         unsigned chunks;
         pick_chunks(t->n_frames, work.size(), a.frames_per_chunk, chunks);
         dim3 grid((unsigned)work.size(), chunks);
@@ -1760,13 +1774,11 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         for (int tl = 0; tl < (int)st.tiles.tiles.size(); tl++)
             if (A < 0 || st.tiles.tiles[tl].species == A) work.push_back(make_int4(k, tl, A, B));
     }
-    void *d_work, *d_edges, *d_flags;
-    AMOF_TRY(upload(ctx, SLOT_PAIRS, work.data(), work.size() * sizeof(int4), &d_work));
+    void *d_edges, *d_flags;
     AMOF_TRY(upload(ctx, SLOT_AUX3, edges, (size_t)(nb + 1) * sizeof(double), &d_edges));
     AMOF_TRY(ensure(ctx, SLOT_FLAGS, 4 * sizeof(int32_t), &d_flags));
     AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flags, 0, 4 * sizeof(int32_t), ctx->stream));
     NbrArgs &a = st.a;
-    a.work = (const int4 *)d_work;
     a.edges = (const double *)d_edges;
     a.nb = nb;
     a.edge_step = 0.0;
@@ -1854,10 +1866,10 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             std::vector<int32_t> tab(4 * awork.size() + (size_t)S * S);
             memcpy(tab.data(), awork.data(), awork.size() * sizeof(int4));
             memcpy(&tab[4 * awork.size()], region_of.data(), region_of.size() * sizeof(int32_t));
-            void *d_tab, *d_lists;
-            AMOF_TRY(upload(ctx, SLOT_AUX8, tab.data(), tab.size() * sizeof(int32_t), &d_tab));
-            AMOF_TRY(upload(ctx, SLOT_AUX6, nw.items.data(), nw.items.size() * sizeof(FrameItem), &nw.d_items));
-            nw.fr.items = (const FrameItem *)nw.d_items;
+            void *d_lists;
+            const int i_tab = nw.pk.add(tab.data(), tab.size() * sizeof(int32_t));
+            AMOF_TRY(nbr_frame_commit(ctx, nw));
+            const int32_t *d_tab = nw.pk.ptr<int32_t>(i_tab);
             const size_t per_frame = (size_t)R * (sizeof(uint32_t) + (size_t)NBRL_CAP * NBRL_EW * sizeof(double));
             int64_t FB = std::max<int64_t>(1, (int64_t)((size_t)4 << 30) / (int64_t)per_frame);                 // <= 4 GiB of rows
             FB = std::min<int64_t>(FB, std::max<int64_t>(1, 0x7fffff00ll / std::max<int64_t>(1, t->n_atoms)));    // flat (frame, centre) index
@@ -1899,11 +1911,11 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 if (nw.ortho) {
                     e = allow_max_lds((const void *)bad_rows_kernel<true>);
                     if (e == hipSuccess) hipLaunchKernelGGL(bad_rows_kernel<true>, agrid, dim3(NBRF_TILE), lds_rows, ctx->stream, a, la, d_aw,
-                                                            (const int64_t *)nw.d_spfirst, (int)nfr);
+                                                            nw.d_spfirst, (int)nfr);
                 } else {
                     e = allow_max_lds((const void *)bad_rows_kernel<false>);
                     if (e == hipSuccess) hipLaunchKernelGGL(bad_rows_kernel<false>, agrid, dim3(NBRF_TILE), lds_rows, ctx->stream, a, la, d_aw,
-                                                            (const int64_t *)nw.d_spfirst, (int)nfr);
+                                                            nw.d_spfirst, (int)nfr);
                 }
                 AMOF_HIP_TRY(ctx, e);
                 AMOF_HIP_TRY(ctx, hipGetLastError());
@@ -2060,6 +2072,11 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
     const bool extra = st.max_img > 0, ortho = st.geom.all_ortho;
     const size_t lds_exact = (size_t)(3 * AMOF_MAX_NEIGHBOURS * BAD_TILE + 3 * BAD_TILE) * sizeof(double) +
                              BAD_TILE * sizeof(int) + lds_bins * sizeof(unsigned);
+    if (!done && !work.empty() && t->n_frames > 0) {      // (the exact kernels' work list: uploaded only when they run)
+        void *d_work;
+        AMOF_TRY(upload(ctx, SLOT_PAIRS, work.data(), work.size() * sizeof(int4), &d_work));
+        a.work = (const int4 *)d_work;
+    }
     auto launch_exact = [&](dim3 grid) -> hipError_t {
         auto launch = [&](auto kern) -> hipError_t {
             hipError_t e = allow_max_lds((const void *)kern);
