@@ -541,7 +541,7 @@ __global__ __launch_bounds__(NBRF_TILE) void cn_fast_kernel(NbrFastArgs fa)
 // band re-decided by the canonical float64 arithmetic on the original positions.
 constexpr int NBRW_THREADS = 1024;
 constexpr int NBRW_MAX_ATOMS = NBRW_THREADS * 8;      // atoms of one item (a thread folds up to 8: frame_sort<PT>)
-constexpr uint32_t NBRW_SLOT1 = 0x80000000u;          // record idx word: rank of the atom inside its species | second species of the item
+constexpr uint32_t NBRW_SLOT1 = 0x80000000u;          // record idx word: atom index | second species of the item
 
 struct FrameItem {
     int32_t sa, sb;            // centre species, partner species (sa == sb: one species staged)
@@ -605,7 +605,7 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
             u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
         }
         const bool second = k >= nA;
-        rec[i] = make_uint4(u[0], u[1], u[2], second ? (uint32_t)(k - nA) | NBRW_SLOT1 : (uint32_t)k);
+        rec[i] = make_uint4(u[0], u[1], u[2], (uint32_t)atom[i] | (second ? NBRW_SLOT1 : 0u));
         key[i] = (second ? (uint32_t)ncell : 0u) +
                  (__umulhi(u[2], (unsigned)nz) * (unsigned)ny + __umulhi(u[1], (unsigned)ny)) * (unsigned)nx +
                  __umulhi(u[0], (unsigned)nx);
@@ -643,15 +643,12 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
 // One task = one centre x one of the 9 rows (dz, dy) of cells around it: its x-run cx-1 .. cx+1 (two index ranges when
 // the run wraps) among the partners of species slot `slot` (0 / 1) of the sorted frame.  Nine lanes share a centre, so a
 // wave's trip count is the fullest ROW of its lanes, not the fullest neighbourhood (per-lane loops over all 27 cells ran
-// at a third of the issue rate: 18 us of a 31 us frame).  perm_c / perm_p: the species segments of the centre and of the
-// partners in the species-sorted permutation (records carry ranks; the rare exact re-decision needs the atoms).
-// found(sorted position of the partner, its record).
+// at a third of the issue rate: 18 us of a 31 us frame).  visit(is a neighbour, sorted position of the partner) is called
+// for EVERY candidate by all lanes still in the loop, so that a caller may aggregate over the wave.
 template <bool ORTHO, typename F>
 __device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const FrameItem &it, const FrameLds &L, int slot,
                                                      const float *sc, const double *__restrict__ geo,
-                                                     const double *__restrict__ p, const int32_t *__restrict__ perm_c,
-                                                     const int32_t *__restrict__ perm_p, const uint4 qc, int r9, double rc,
-                                                     F &&found)
+                                                     const double *__restrict__ p, const uint4 qc, int r9, double rc, F &&visit)
 {
     const int nx = it.nx, ny = it.ny, nz = it.nz;
     const float rcf = (float)rc;
@@ -674,12 +671,10 @@ __device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const 
     for (int q = 0; q < total; q++) {
         const int j = q < len0 ? lo0 + q : lo1 + (q - len0);
         const uint4 qj = L.rec[j];
-        if (qj.w == qc.w) continue;                             // (no zero-shift self pair: same species, same rank)
         const float d = nbr_fast_dist<ORTHO>(sc, qc.x, qc.y, qc.z, qj);
         bool nbr = d < r_in;
-        if (!nbr && d < r_out)
-            nbr = nbr_exact<ORTHO>(geo, p, (uint32_t)perm_c[qc.w & ~NBRW_SLOT1], (uint32_t)perm_p[qj.w & ~NBRW_SLOT1], rc);
-        if (nbr) found(j, qj);
+        if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, qc.w & ~NBRW_SLOT1, qj.w & ~NBRW_SLOT1, rc);
+        visit(nbr && qj.w != qc.w, j);                          // (no zero-shift self pair: same species, same atom)
     }
 }
 
@@ -699,10 +694,9 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void cn_frame_kernel
     L.rec = reinterpret_cast<uint4 *>(lds_raw);                         // (every item lays LDS out for its own atom count)
     L.cell_end = reinterpret_cast<uint32_t *>(L.rec + nA + nB);
     const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
-    const int32_t *__restrict__ perm_c = a.perm + fr.sp_first[it.sa], *__restrict__ perm_p = a.perm + fr.sp_first[it.sb];
     int32_t *__restrict__ pa = a.per_atom ? a.per_atom + ((size_t)f * a.n_sets + it.set) * (size_t)a.N : nullptr;
     if (pa)     // every centre starts at zero (the barriers of the sort order these stores before the atomics below)
-        for (int c = tid; c < nA; c += NBRW_THREADS) pa[perm_c[c]] = 0;
+        for (int c = tid; c < nA; c += NBRW_THREADS) pa[a.perm[fr.sp_first[it.sa] + c]] = 0;
     frame_sort<PT>(a, fr, it, L, f, nA, nB, wsum);
     const int gi = a.n_cells == 1 ? 0 : f;
     const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
@@ -716,9 +710,8 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void cn_frame_kernel
         const int c = t / 9, r9 = t - 9 * c;
         const uint4 qc = L.rec[c];
         int cnt = 0;
-        frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, perm_c, perm_p, qc, r9, rc,
-                                    [&](int, const uint4 &) { cnt++; });
-        if (pa && cnt) atomicAdd(&pa[perm_c[qc.w]], cnt);
+        frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, qc, r9, rc, [&](bool nbr, int) { cnt += nbr ? 1 : 0; });
+        if (pa && cnt) atomicAdd(&pa[qc.w], cnt);
         sum += (unsigned long long)cnt;
     }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
@@ -1028,6 +1021,7 @@ constexpr int NBRW_HITS = 3072;           // pairs lists_frame_kernel buffers in
 
 struct NbrListArgs {
     const int32_t *region_of;  // [S][S] first row of the ordered pair (centre species, partner species); -1: not kept
+    const int32_t *inv_rank;   // [N] rank of an atom inside its species
     uint32_t *count;           // [frames of the batch][R]
     double *rows;              // [frames of the batch][R][NBRL_CAP][NBRL_EW] unit vectors centre -> neighbour
     int32_t R;
@@ -1058,7 +1052,6 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
     if (tid == 0) nhits = 0u;
     frame_sort<PT>(a, fr, it, L, f, nA, nB, wsum);
     const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
-    const int32_t *__restrict__ perm_c = a.perm + fr.sp_first[it.sa], *__restrict__ perm_p = a.perm + fr.sp_first[it.sb];
     const int gi = a.n_cells == 1 ? 0 : f;
     const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
     float sc[9];
@@ -1066,6 +1059,7 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
     for (int k = 0; k < 9; k++) sc[k] = fr.cells[gi].sc[k];
     const double rc = a.cutoff[it.sa * a.S + it.sb];
     const size_t base = (size_t)fl * la.R;
+    const int lane = tid & 63;
     auto claim = [&](int c) -> unsigned {       // next free slot of the atom at sorted position c
         const unsigned sh = 8u * ((unsigned)c & 3u);
         return (atomicAdd(&cnt[c >> 2], 1u << sh) >> sh) & 0xffu;
@@ -1075,9 +1069,15 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
         const int t = t0 + tid;
         if (t < tasks) {
             const int c = t / 9, r9 = t - 9 * c;
-            frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, perm_c, perm_p, L.rec[c], r9, rc,
-                                        [&](int j, const uint4 &) {
-                const unsigned h = atomicAdd(&nhits, 1u);
+            frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, L.rec[c], r9, rc, [&](bool nbr, int j) {
+                // one LDS atomic per wave and trip, not one per pair (they would all hit the same word)
+                const unsigned long long m = __ballot(nbr);
+                if (!m) return;
+                const int leader = __ffsll((long long)m) - 1;
+                unsigned h = 0;
+                if (lane == leader) h = atomicAdd(&nhits, (unsigned)__popcll(m));
+                h = __shfl(h, leader, 64) + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                if (!nbr) return;
                 if (h < (unsigned)NBRW_HITS) hits[h] = ((uint32_t)c << 13) | (uint32_t)j;
                 else a.flags[1] = 1;        // (absurdly many pairs per task: the exact kernels take the call)
             });
@@ -1090,15 +1090,16 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
         const unsigned nh = min(nhits, (unsigned)NBRW_HITS);
         for (unsigned h = tid; h < nh; h += NBRW_THREADS) {
             const int c = (int)(hits[h] >> 13), j = (int)(hits[h] & 0x1fffu);
-            const uint32_t rank_c = L.rec[c].w, rank_j = L.rec[j].w & ~NBRW_SLOT1;
-            const double *pc = p + (size_t)perm_c[rank_c] * 3, *pj = p + (size_t)perm_p[rank_j] * 3;
+            const uint32_t atom_c = L.rec[c].w, atom_j = L.rec[j].w & ~NBRW_SLOT1;
+            const int rank_c = la.inv_rank[atom_c], rank_j = la.inv_rank[atom_j];      // (loaded beside the positions)
+            const double *pc = p + (size_t)atom_c * 3, *pj = p + (size_t)atom_j * 3;
             double vx, vy, vz, ux = 0.0, uy = 0.0, uz = 0.0;
             pair_base<ORTHO>(geo, pj[0] - pc[0], pj[1] - pc[1], pj[2] - pc[2], vx, vy, vz);
             if (!unit_vec(vx, vy, vz, ux, uy, uz)) a.flags[0] = 1;          // (the call fails: results are discarded)
             if (it.reg_ab >= 0) {       // (one species: the pair is found from both ends, each end fills its own row)
                 const unsigned k = claim(c);
                 if (k < (unsigned)NBRL_CAP) {
-                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((base + (size_t)(it.reg_ab + (int)rank_c)) * NBRL_CAP + k) * NBRL_EW);
+                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((base + (size_t)(it.reg_ab + rank_c)) * NBRL_CAP + k) * NBRL_EW);
                     e[0] = make_double2(ux, uy); e[1] = make_double2(uz, 0.0);
                 } else {
                     a.flags[1] = 1;
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
             if (it.reg_ba >= 0 && nB > 0) {
                 const unsigned k = claim(j);
                 if (k < (unsigned)NBRL_CAP) {
-                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((base + (size_t)(it.reg_ba + (int)rank_j)) * NBRL_CAP + k) * NBRL_EW);
+                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((base + (size_t)(it.reg_ba + rank_j)) * NBRL_CAP + k) * NBRL_EW);
                     e[0] = make_double2(-ux, -uy); e[1] = make_double2(-uz, 0.0);
                 } else {
                     a.flags[1] = 1;
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
         const int reg = c < nA ? it.reg_ab : it.reg_ba;
         if (reg < 0) continue;
         const uint32_t k = (cnt[c >> 2] >> (8u * ((unsigned)c & 3u))) & 0xffu;
-        la.count[base + (size_t)(reg + (int)(L.rec[c].w & ~NBRW_SLOT1))] = min(k, (uint32_t)NBRL_CAP);
+        la.count[base + (size_t)(reg + la.inv_rank[L.rec[c].w & ~NBRW_SLOT1])] = min(k, (uint32_t)NBRL_CAP);
     }
 }
 
@@ -1862,10 +1863,14 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 if (nw.ok) nw.items.push_back(it);
             }
         if (nw.ok && !awork.empty() && R > 0 && R < (1ll << 30) && t->n_frames > 0) {
-            // one small table: angle work | region_of[S*S]; the items beside it
-            std::vector<int32_t> tab(4 * awork.size() + (size_t)S * S);
+            // one small table: angle work | region_of[S*S] | inv_rank[N]; the items beside it
+            std::vector<int32_t> tab(4 * awork.size() + (size_t)S * S + (size_t)t->n_atoms);
             memcpy(tab.data(), awork.data(), awork.size() * sizeof(int4));
             memcpy(&tab[4 * awork.size()], region_of.data(), region_of.size() * sizeof(int32_t));
+            for (int64_t x = 0; x < t->n_atoms; x++) {
+                const int32_t atom = st.tiles.perm[(size_t)x];
+                tab[4 * awork.size() + (size_t)S * S + (size_t)atom] = (int32_t)(x - nw.sp_first[(size_t)t->species[atom]]);
+            }
             void *d_lists;
             const int i_tab = nw.pk.add(tab.data(), tab.size() * sizeof(int32_t));
             AMOF_TRY(nbr_frame_commit(ctx, nw));
@@ -1879,6 +1884,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             NbrListArgs la;
             const int4 *d_aw = (const int4 *)d_tab;
             la.region_of = (const int32_t *)d_tab + 4 * awork.size();
+            la.inv_rank = la.region_of + (size_t)S * S;
             la.rows = (double *)d_lists;                                   // (doubles first: 8-byte aligned)
             la.count = (uint32_t *)(la.rows + (size_t)FB * R * NBRL_CAP * NBRL_EW);
             la.R = (int32_t)R;
