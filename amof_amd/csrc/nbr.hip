@@ -1023,7 +1023,9 @@ struct NbrListArgs {
     const int32_t *region_of;  // [S][S] first row of the ordered pair (centre species, partner species); -1: not kept
     const int32_t *inv_rank;   // [N] rank of an atom inside its species
     uint32_t *count;           // [frames of the batch][R]
-    double *rows;              // [frames of the batch][R][NBRL_CAP][NBRL_EW] unit vectors centre -> neighbour
+    double *rows;              // [NBRL_CAP][frames of the batch * R][NBRL_EW] unit vectors centre -> neighbour, slot-major: the
+                               // k-th neighbours of consecutive centres are neighbours in memory (dense writes, coalesced reads)
+    size_t plane;              // frames of the batch * R
     int32_t R;
 };
 
@@ -1099,7 +1101,7 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
             if (it.reg_ab >= 0) {       // (one species: the pair is found from both ends, each end fills its own row)
                 const unsigned k = claim(c);
                 if (k < (unsigned)NBRL_CAP) {
-                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((base + (size_t)(it.reg_ab + rank_c)) * NBRL_CAP + k) * NBRL_EW);
+                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((size_t)k * la.plane + base + (size_t)(it.reg_ab + rank_c)) * NBRL_EW);
                     e[0] = make_double2(ux, uy); e[1] = make_double2(uz, 0.0);
                 } else {
                     a.flags[1] = 1;
@@ -1108,7 +1110,7 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
             if (it.reg_ba >= 0 && nB > 0) {
                 const unsigned k = claim(j);
                 if (k < (unsigned)NBRL_CAP) {
-                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((base + (size_t)(it.reg_ba + rank_j)) * NBRL_CAP + k) * NBRL_EW);
+                    double2 *e = reinterpret_cast<double2 *>(la.rows + ((size_t)k * la.plane + base + (size_t)(it.reg_ba + rank_j)) * NBRL_EW);
                     e[0] = make_double2(-ux, -uy); e[1] = make_double2(-uz, 0.0);
                 } else {
                     a.flags[1] = 1;
@@ -1185,16 +1187,16 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_rows_kernel(NbrArgs a, NbrListA
         if (n > NBRL_CAP) { a.flags[1] = 1; return; }        // (as bad_fast_kernel: more than 16 in all -> the exact kernels)
         // entry e of the centre = the e-th unit vector over its rows in species order
         auto entry = [&](int e) -> const double * {
-            if (e < ce.c0) return la.rows + ((ce.cbase + reg0) * NBRL_CAP + e) * NBRL_EW;
+            if (e < ce.c0) return la.rows + ((size_t)e * la.plane + ce.cbase + reg0) * NBRL_EW;
             e -= ce.c0;
-            if (e < ce.c1) return la.rows + ((ce.cbase + reg1) * NBRL_CAP + e) * NBRL_EW;
+            if (e < ce.c1) return la.rows + ((size_t)e * la.plane + ce.cbase + reg1) * NBRL_EW;
             e -= ce.c1;
-            if (e < ce.c2) return la.rows + ((ce.cbase + reg2) * NBRL_CAP + e) * NBRL_EW;
+            if (e < ce.c2) return la.rows + ((size_t)e * la.plane + ce.cbase + reg2) * NBRL_EW;
             e -= ce.c2;
             for (int q = 3; q < n_reg; q++) {
                 const int reg = la.region_of[sa * a.S + reg_sb(q)];
                 const int c = (int)la.count[ce.cbase + reg];
-                if (e < c) return la.rows + ((ce.cbase + reg) * NBRL_CAP + e) * NBRL_EW;
+                if (e < c) return la.rows + ((size_t)e * la.plane + ce.cbase + reg) * NBRL_EW;
                 e -= c;
             }
             return la.rows;     // (not reached: e < n)
@@ -1888,6 +1890,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             la.rows = (double *)d_lists;                                   // (doubles first: 8-byte aligned)
             la.count = (uint32_t *)(la.rows + (size_t)FB * R * NBRL_CAP * NBRL_EW);
             la.R = (int32_t)R;
+            la.plane = (size_t)FB * (size_t)R;
             const size_t lds_rows = lds_bins * sizeof(unsigned);
             int64_t launches = 0;
             for (int64_t fb = 0, cur = FB0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
