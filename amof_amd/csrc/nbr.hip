@@ -1202,25 +1202,57 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_rows_kernel(NbrArgs a, NbrListA
             return la.rows;     // (not reached: e < n)
         };
         const size_t hslot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
+        auto bin_angle = [&](double ax, double ay, double az, double bx, double by, double bz) {
+            double dot = ax * bx + ay * by + az * bz;
+            if (dot > 1.0) dot = 1.0;
+            if (dot < -1.0) dot = -1.0;
+            const double ang = (180.0 / M_PI) * acos(dot);
+            const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
+            if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
+                atomicAdd(&a.n_angles[hslot], 1ull);
+                if (k >= 0) atomicAdd(&a.hist[hslot * nb + k], 1ull);
+            } else {
+                nang++;
+                if (k >= 0) atomicAdd(&hist[k], 1u);
+            }
+        };
+        if (n_reg == 1) {
+            // one partner species (every triple but X-A-X): the centre's k-th vector is one plane further
+            const double2 *__restrict__ e0 = reinterpret_cast<const double2 *>(la.rows + (ce.cbase + reg0) * NBRL_EW);
+            const size_t step = la.plane * (NBRL_EW / 2);
+            if (n <= 4) {
+                // the common case (4 N around a Zn, 2 - 3 around a C): vectors in registers, pairs unrolled
+                const double2 v0a = e0[0], v0b = e0[1], v1a = e0[step], v1b = e0[step + 1];
+                bin_angle(v0a.x, v0a.y, v0b.x, v1a.x, v1a.y, v1b.x);
+                if (n > 2) {
+                    const double2 v2a = e0[2 * step], v2b = e0[2 * step + 1];
+                    bin_angle(v0a.x, v0a.y, v0b.x, v2a.x, v2a.y, v2b.x);
+                    bin_angle(v1a.x, v1a.y, v1b.x, v2a.x, v2a.y, v2b.x);
+                    if (n > 3) {
+                        const double2 v3a = e0[3 * step], v3b = e0[3 * step + 1];
+                        bin_angle(v0a.x, v0a.y, v0b.x, v3a.x, v3a.y, v3b.x);
+                        bin_angle(v1a.x, v1a.y, v1b.x, v3a.x, v3a.y, v3b.x);
+                        bin_angle(v2a.x, v2a.y, v2b.x, v3a.x, v3a.y, v3b.x);
+                    }
+                }
+                return;
+            }
+            for (int u = 0; u + 1 < n; u++) {
+                const double2 a01 = e0[u * step], a2 = e0[u * step + 1];
+                for (int v = u + 1; v < n; v++) {
+                    const double2 b01 = e0[v * step], b2 = e0[v * step + 1];
+                    bin_angle(a01.x, a01.y, a2.x, b01.x, b01.y, b2.x);
+                }
+            }
+            return;
+        }
         for (int u = 0; u + 1 < n; u++) {
             const double2 *eu = reinterpret_cast<const double2 *>(entry(u));
             const double2 a01 = eu[0], a2 = eu[1];
-            const double ax = a01.x, ay = a01.y, az = a2.x;
             for (int v = u + 1; v < n; v++) {
                 const double2 *ev = reinterpret_cast<const double2 *>(entry(v));
                 const double2 b01 = ev[0], b2 = ev[1];
-                double dot = ax * b01.x + ay * b01.y + az * b2.x;
-                if (dot > 1.0) dot = 1.0;
-                if (dot < -1.0) dot = -1.0;
-                const double ang = (180.0 / M_PI) * acos(dot);
-                const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
-                if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
-                    atomicAdd(&a.n_angles[hslot], 1ull);
-                    if (k >= 0) atomicAdd(&a.hist[hslot * nb + k], 1ull);
-                } else {
-                    nang++;
-                    if (k >= 0) atomicAdd(&hist[k], 1u);
-                }
+                bin_angle(a01.x, a01.y, a2.x, b01.x, b01.y, b2.x);
             }
         }
     };
