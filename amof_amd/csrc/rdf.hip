@@ -931,6 +931,7 @@ struct RdfCellArgs {
     int32_t nx, ny, nz, npk;
     int32_t frames_grid;      // frames in the grid (rounded up to a multiple of 8 with the XCD mapping)
     int32_t cpt;              // centre atoms per thread (the workgroup covers 256 * cpt consecutive atoms)
+    int32_t trim;             // 1: rows trimmed per lane to the cells within reach (AMOF_RDF_NOTRIM=1: the full 5-cell runs)
 };
 
 constexpr int CELL_THREADS = 512;
@@ -984,6 +985,18 @@ __global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs c
         const uint32_t ida = own.idx & CELL_IDX_MASK;
         const int cx = (int)__umulhi(own.ux, (unsigned)nx), cy = (int)__umulhi(own.uy, (unsigned)ny),
                   cz = (int)__umulhi(own.uz, (unsigned)nz);
+        // Per-lane trimming of the rows (round 3).  The f32 scales are the lower-triangular factor of the cell's metric, so
+        // the Cartesian z of a difference depends on its fractional z only and y on (y, z): from the atom's own place
+        // inside its cell, the least |z| and |y| any partner of row (dz, dy) can have leave rho^2 = R^2 - z^2 - y^2 for x,
+        // and only the cells of the row within that reach are walked (none if rho^2 < 0).  Bounds are conservative
+        // (cell edges widened by 1e-5 of a cell + 1024 units, R by 1e-4 + 2 bins): no pair within rmax is skipped; the
+        // visited volume drops from the 5 x 5 x 2.5 cells block to a shell about one cell thick around the half sphere.
+        const float uxf = (float)own.ux, uyf = (float)own.uy, uzf = (float)own.uz;
+        const float wx = 4294967296.f / (float)nx, wy = 4294967296.f / (float)ny, wz = 4294967296.f / (float)nz;
+        const float ex = wx * 1e-5f + 1024.f, ey = wy * 1e-5f + 1024.f, ez = wz * 1e-5f + 1024.f;
+        const float Rq = nb_hi * 1.0001f + 2.f;
+        const float s_xx = sc[0], s_yx = ORTHO ? 0.f : sc[3], s_yy = ORTHO ? sc[1] : sc[4], s_zx = ORTHO ? 0.f : sc[6],
+                    s_zy = ORTHO ? 0.f : sc[7], s_zz = ORTHO ? sc[2] : sc[8];
 #pragma unroll 1
         for (int row = 0; row < 13; row++) {
             // rows of the positive half shell
@@ -994,15 +1007,36 @@ __global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs c
             if (cy2 >= ny) cy2 -= ny;
             if (cy2 < 0) cy2 += ny;
             const int rowbase = (cz2 * ny + cy2) * nx;
-            const int xlo = row == 0 ? cx : cx - 2, xhi = cx + 2;
+            int xlo = row == 0 ? cx : cx - 2, xhi = cx + 2;
+            if (ca.trim) {
+                const float zl = (float)(cz + dz) * wz - uzf - ez, zh = zl + wz + 2.f * ez;     // fractional z of the row's partners - mine
+                const float yl = (float)(cy + dy) * wy - uyf - ey, yh = yl + wy + 2.f * ey;
+                const float dzmin = (zl > 0.f ? zl : (zh < 0.f ? -zh : 0.f)) * s_zz;
+                const float yc_lo = yl * s_yy + fminf(zl * s_zy, zh * s_zy), yc_hi = yh * s_yy + fmaxf(zl * s_zy, zh * s_zy);
+                const float dymin = yc_lo > 0.f ? yc_lo : (yc_hi < 0.f ? -yc_hi : 0.f);
+                const float rem = Rq * Rq - dzmin * dzmin - dymin * dymin;
+                if (rem < 0.f) {
+                    xhi = xlo - 1;      // nothing of this row is within reach of this atom
+                } else {
+                    const float rho = __builtin_amdgcn_sqrtf(rem) * 1.0001f + 1.f;
+                    const float e_lo = fminf(yl * s_yx, yh * s_yx) + fminf(zl * s_zx, zh * s_zx);
+                    const float e_hi = fmaxf(yl * s_yx, yh * s_yx) + fmaxf(zl * s_zx, zh * s_zx);
+                    const float fx_lo = (-rho - e_hi) / s_xx, fx_hi = (rho - e_lo) / s_xx;
+                    const float inv_wx = (float)nx * (1.f / 4294967296.f);
+                    xlo = max(xlo, (int)floorf((uxf + fx_lo - ex) * inv_wx - 1e-3f));
+                    xhi = min(xhi, (int)floorf((uxf + fx_hi + ex) * inv_wx + 1e-3f));
+                }
+            }
             // cells [xlo, xhi] with periodic wrap: at most two runs
             int xa0, xb0, xa1 = 0, xb1 = -1;
-            if (xlo < 0) { xa0 = xlo + nx; xb0 = nx - 1; xa1 = 0; xb1 = xhi; }
+            if (xhi < 0) { xa0 = xlo + nx; xb0 = xhi + nx; }                  // (trimmed runs may lie wholly beyond an edge)
+            else if (xlo >= nx) { xa0 = xlo - nx; xb0 = xhi - nx; }
+            else if (xlo < 0) { xa0 = xlo + nx; xb0 = nx - 1; xa1 = 0; xb1 = xhi; }
             else if (xhi >= nx) { xa0 = xlo; xb0 = nx - 1; xa1 = 0; xb1 = xhi - nx; }
             else { xa0 = xlo; xb0 = xhi; }
             // both runs are looked up before either is walked (dependent global loads)
             int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0;
-            if (active) {
+            if (active && xlo <= xhi) {
                 ja0 = (int)st[(size_t)(rowbase + xa0) * S];
                 ja1 = (int)st[(size_t)(rowbase + xb0 + 1) * S];
                 if (row == 0) ja0 = i + 1;                    // own cell: the partners after me
@@ -1403,6 +1437,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     ca.nx = nk[0]; ca.ny = nk[1]; ca.nz = nk[2];
                     ca.npk = npk;
                     ca.cpt = 1;
+                    ca.trim = getenv("AMOF_RDF_NOTRIM") ? 0 : 1;
                     const unsigned gx = (unsigned)((t->n_atoms + (int64_t)CELL_THREADS * ca.cpt - 1) / ((int64_t)CELL_THREADS * ca.cpt));
                     int64_t launches = 0;
                     for (int64_t fb = 0; fb < t->n_frames; fb += FB3) {

@@ -604,7 +604,7 @@ def main():
                 "kernel_seconds_per_step": {"rdf_all": mean3["rdf_all"], "msd_all": mean3["msd_all"],
                                             "bad_all": mean3["bad_all"]},
                 "bad_wall_s": mean3["bad_wall"],
-                "roofline_bad": {"kernel": "bad pipeline (quantize + bad_fast)", "bound": "hbm",
+                "roofline_bad": {"kernel": "bad pipeline (lists_frame_kernel + bad_rows_kernel: whole frame in LDS)", "bound": "hbm",
                                  "achieved": alg_bytes / mean3["bad_all"] / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": alg_bytes / mean3["bad_all"] / 1e9 / HBM_PEAK_GBPS,
                                  "algorithmic_bytes": alg_bytes},
