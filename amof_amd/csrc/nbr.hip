@@ -1910,11 +1910,19 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             AMOF_TRY(nbr_frame_commit(ctx, nw));
             const int32_t *d_tab = nw.pk.ptr<int32_t>(i_tab);
             const size_t per_frame = (size_t)R * (sizeof(uint32_t) + (size_t)NBRL_CAP * NBRL_EW * sizeof(double));
-            int64_t FB = std::max<int64_t>(1, (int64_t)((size_t)4 << 30) / (int64_t)per_frame);                 // <= 4 GiB of rows
+            size_t rows_budget = (size_t)4 << 30;                          // <= 4 GiB of rows
+            if (const char *mb = getenv("AMOF_BAD_ROWS_MB")) rows_budget = (size_t)std::max(1, atoi(mb)) << 20;     // tests: many batches
+            int64_t FB = std::max<int64_t>(1, (int64_t)rows_budget / (int64_t)per_frame);
             FB = std::min<int64_t>(FB, std::max<int64_t>(1, 0x7fffff00ll / std::max<int64_t>(1, t->n_atoms)));    // flat (frame, centre) index
             FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), t->n_frames);
+            // (a device short of memory gets smaller batches, not an error)
+            for (;;) {
+                const int rc_rows = ensure(ctx, SLOT_AUX9, (size_t)FB * per_frame, &d_lists);
+                if (rc_rows == AMOF_OK) break;
+                if (rc_rows != AMOF_ENOMEM || FB == 1) return rc_rows;
+                FB = std::max<int64_t>(1, FB / 4);
+            }
             const int64_t FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
-            AMOF_TRY(ensure(ctx, SLOT_AUX9, (size_t)FB * per_frame, &d_lists));
             NbrListArgs la;
             const int4 *d_aw = (const int4 *)d_tab;
             la.region_of = (const int32_t *)d_tab + 4 * awork.size();
