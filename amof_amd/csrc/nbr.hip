@@ -1272,6 +1272,137 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_rows_kernel(NbrArgs a, NbrListA
     if ((tid & 63) == 0 && nang) atomicAdd(&a.n_angles[trip], nang);
 }
 
+// All triples of one centre species in ONE pass over its rows (histograms in LDS, no BadByCn keys).  The reference asks
+// for every ordered species pair plus 'X' (amof/bad.py:126-131): B-A-B, X-A-X and X-X-X count the same angles again and
+// again -- X-A-X is every unordered neighbour pair of an A centre, B-A-B those of them with both neighbours B, X-X-X the
+// sum of X-A-X over A (X-B-X, centre any species, the sum of B-A-B over A).  Here every angle is computed once and added to
+// the histogram of its partner species (if both neighbours share it) and to the all-pairs histogram; at the end the
+// workgroup adds each LDS histogram to every triple it belongs to.  17 triples of three cutoffs: 14 passes and 37k angles
+// a frame before, 4 passes and 14.8k angles now.
+struct MergedItem {
+    int32_t sa, n_reg;
+    int32_t reg[3];            // first row of region (sa, b_q), q < n_reg (partner species in species order)
+    int32_t tb[3][2];          // triples that take the pairs inside region q: (sa, b_q), (X, b_q); -1: not asked for
+    int32_t tx[2];             // triples that take every pair: (sa, X), (X, X)
+    int32_t _pad[3];
+};
+constexpr int NBRM_THREADS = 512;
+
+template <bool ORTHO>
+__global__ __launch_bounds__(NBRM_THREADS) void bad_rows_merged_kernel(NbrArgs a, NbrListArgs la, const MergedItem *__restrict__ items,
+                                                                       const int64_t *__restrict__ sp_first, int nf)
+{
+    extern __shared__ unsigned hist[];          // [n_reg (+ 1 when there are several partner species)][nb]
+    const int tid = threadIdx.x;
+    const MergedItem it = items[blockIdx.y];
+    const uint32_t nA = (uint32_t)(sp_first[it.sa + 1] - sp_first[it.sa]);
+    const uint32_t total = (uint32_t)nf * nA;                             // (< 2^31: the host sizes the frame batch)
+    const uint32_t tiles = (total + NBRM_THREADS - 1) / NBRM_THREADS;
+    const int nb = a.nb, n_reg = it.n_reg;
+    const bool all_pairs = n_reg > 1 && (it.tx[0] >= 0 || it.tx[1] >= 0);       // (one partner species: its histogram IS the all-pairs one)
+    const int n_hist = n_reg + (n_reg > 1 ? 1 : 0);
+    unsigned *hist_x = hist + (size_t)n_reg * nb;
+    const double hb_e0 = a.edges[0], hb_en = a.edges[nb], hb_inv_w = (double)nb / (hb_en - hb_e0);
+    for (int k = tid; k < n_hist * nb; k += NBRM_THREADS) hist[k] = 0u;
+    __syncthreads();
+    unsigned long long nang0 = 0, nang1 = 0, nang2 = 0, nangx = 0;
+    const int reg0 = it.reg[0], reg1 = it.reg[1], reg2 = it.reg[2];
+    const bool w0 = it.tb[0][0] >= 0 || it.tb[0][1] >= 0 || n_reg == 1, w1 = n_reg > 1 && (it.tb[1][0] >= 0 || it.tb[1][1] >= 0),
+               w2 = n_reg > 2 && (it.tb[2][0] >= 0 || it.tb[2][1] >= 0);
+    struct Centre {
+        size_t cbase;
+        int c0, c1, c2;
+    };
+    auto load_centre = [&](uint32_t tile) -> Centre {
+        Centre ce{0, 0, 0, 0};
+        const uint32_t flat = tile * (uint32_t)NBRM_THREADS + tid;
+        if (tile >= tiles || flat >= total) return ce;
+        const uint32_t fl = flat / nA, r = flat - fl * nA;
+        ce.cbase = (size_t)fl * la.R + r;
+        ce.c0 = (int)la.count[ce.cbase + reg0];
+        if (n_reg > 1) ce.c1 = (int)la.count[ce.cbase + reg1];
+        if (n_reg > 2) ce.c2 = (int)la.count[ce.cbase + reg2];
+        return ce;
+    };
+    auto bin_of = [&](const double2 &a01, const double2 &a2, const double2 &b01, const double2 &b2) -> int {
+        double dot = a01.x * b01.x + a01.y * b01.y + a2.x * b2.x;
+        if (dot > 1.0) dot = 1.0;
+        if (dot < -1.0) dot = -1.0;
+        return hist_bin(a.edges, nb, (180.0 / M_PI) * acos(dot), hb_e0, hb_en, hb_inv_w, a.edge_step);
+    };
+    auto angles_of = [&](const Centre &ce) {
+        const int n = ce.c0 + ce.c1 + ce.c2;
+        if (n < 2) return;
+        const int o1 = ce.c0, o2 = ce.c0 + ce.c1;
+        auto entry = [&](int e) -> const double2 * {     // the e-th unit vector of the centre over its rows in species order
+            const int q = e < o1 ? 0 : (e < o2 ? 1 : 2);
+            const int i = e - (q == 0 ? 0 : (q == 1 ? o1 : o2)), reg = q == 0 ? reg0 : (q == 1 ? reg1 : reg2);
+            return reinterpret_cast<const double2 *>(la.rows + ((size_t)i * la.plane + ce.cbase + reg) * NBRL_EW);
+        };
+        if (all_pairs) {
+            if (n > NBRL_CAP) { a.flags[1] = 1; return; }       // (as bad_fast_kernel: more than 16 in all -> the exact kernels)
+            for (int u = 0; u + 1 < n; u++) {
+                const double2 *eu = entry(u);
+                const double2 a01 = eu[0], a2 = eu[1];
+                const int qu = u < o1 ? 0 : (u < o2 ? 1 : 2);
+                for (int v = u + 1; v < n; v++) {
+                    const double2 *ev = entry(v);
+                    const int k = bin_of(a01, a2, ev[0], ev[1]);
+                    const int qv = v < o1 ? 0 : (v < o2 ? 1 : 2);
+                    nangx++;
+                    if (k >= 0) atomicAdd(&hist_x[k], 1u);
+                    if (qu == qv && (qu == 0 ? w0 : (qu == 1 ? w1 : w2))) {
+                        if (qu == 0) nang0++; else if (qu == 1) nang1++; else nang2++;
+                        if (k >= 0) atomicAdd(&hist[(size_t)qu * nb + k], 1u);
+                    }
+                }
+            }
+            return;
+        }
+        // only the pairs inside a partner species are asked for
+        for (int q = 0; q < n_reg; q++) {
+            const int c = q == 0 ? ce.c0 : (q == 1 ? ce.c1 : ce.c2);
+            if (c < 2 || !(q == 0 ? w0 : (q == 1 ? w1 : w2))) continue;
+            const int off = q == 0 ? 0 : (q == 1 ? o1 : o2);
+            for (int u = 0; u + 1 < c; u++) {
+                const double2 *eu = entry(off + u);
+                const double2 a01 = eu[0], a2 = eu[1];
+                for (int v = u + 1; v < c; v++) {
+                    const double2 *ev = entry(off + v);
+                    const int k = bin_of(a01, a2, ev[0], ev[1]);
+                    if (q == 0) nang0++; else if (q == 1) nang1++; else nang2++;
+                    if (k >= 0) atomicAdd(&hist[(size_t)q * nb + k], 1u);
+                }
+            }
+        }
+    };
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += 2 * gridDim.x) {
+        const Centre c_a = load_centre(tile), c_b = load_centre(tile + gridDim.x);
+        angles_of(c_a);
+        angles_of(c_b);
+    }
+    __syncthreads();
+    // every LDS histogram to every triple it belongs to
+    auto flush = [&](const unsigned *h, unsigned long long nang, int t0, int t1) {
+        for (int off = 32; off > 0; off >>= 1) nang += __shfl_down(nang, off, 64);
+        for (int w = 0; w < 2; w++) {
+            const int trip = w == 0 ? t0 : t1;
+            if (trip < 0) continue;
+            unsigned long long *H = a.hist + (size_t)trip * nb;
+            for (int k = tid; k < nb; k += NBRM_THREADS) {
+                const unsigned v = h[k];
+                if (v) atomicAdd(&H[k], (unsigned long long)v);
+            }
+            if ((tid & 63) == 0 && nang) atomicAdd(&a.n_angles[trip], nang);
+        }
+    };
+    flush(hist, nang0, it.tb[0][0], it.tb[0][1]);
+    if (n_reg > 1) flush(hist + nb, nang1, it.tb[1][0], it.tb[1][1]);
+    if (n_reg > 2) flush(hist + 2 * (size_t)nb, nang2, it.tb[2][0], it.tb[2][1]);
+    if (n_reg == 1) flush(hist, nang0, it.tx[0], it.tx[1]);
+    else flush(hist_x, nangx, it.tx[0], it.tx[1]);
+}
+
 // ------------------------------------------------------------ host side ----
 struct NbrSetup {
     HostGeom geom;
@@ -1897,6 +2028,44 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 if (nw.ok) nw.items.push_back(it);
             }
         if (nw.ok && !awork.empty() && R > 0 && R < (1ll << 30) && t->n_frames > 0) {
+            // merged angle passes: one per centre species, every angle computed once (histograms in LDS; BadByCn keys, more
+            // bins than LDS holds, a centre species with more than three partner species or a triple named twice keep
+            // the pass per triple)
+            std::vector<MergedItem> merged;
+            size_t lds_merged = 0;
+            if (cn_max == 0 && !a.global_hist && !getenv("AMOF_BAD_NOMERGE")) {
+                auto find_triple = [&](int A, int B, bool &twice) {
+                    int found = -1;
+                    for (int k = 0; k < T; k++)
+                        if (triples[2 * k] == A && triples[2 * k + 1] == B) { if (found >= 0) twice = true; else found = k; }
+                    return found;
+                };
+                bool usable = true, twice = false;
+                for (int sa = 0; sa < S && usable; sa++) {
+                    MergedItem mi{};
+                    mi.sa = sa;
+                    for (int q = 0; q < 3; q++) { mi.reg[q] = 0; mi.tb[q][0] = mi.tb[q][1] = -1; }
+                    for (int sb = 0; sb < S && usable; sb++) {
+                        if (region_of[(size_t)sa * S + sb] < 0) continue;
+                        if (mi.n_reg == 3) { usable = false; break; }
+                        mi.reg[mi.n_reg] = region_of[(size_t)sa * S + sb];
+                        mi.tb[mi.n_reg][0] = find_triple(sa, sb, twice);
+                        mi.tb[mi.n_reg][1] = find_triple(-1, sb, twice);
+                        mi.n_reg++;
+                    }
+                    mi.tx[0] = find_triple(sa, -1, twice);
+                    mi.tx[1] = find_triple(-1, -1, twice);
+                    if (mi.n_reg == 0) continue;
+                    bool any = mi.tx[0] >= 0 || mi.tx[1] >= 0;
+                    for (int q = 0; q < mi.n_reg; q++) any = any || mi.tb[q][0] >= 0 || mi.tb[q][1] >= 0;
+                    if (!any) continue;
+                    lds_merged = std::max(lds_merged, (size_t)(mi.n_reg + (mi.n_reg > 1 ? 1 : 0)) * lds_bins * sizeof(unsigned));
+                    merged.push_back(mi);
+                }
+                // (worth it when it saves passes: two triples over one species pair are two passes either way, and the pass
+                //  per triple keeps a centre's vectors in registers)
+                if (!usable || twice || lds_merged > 60 * 1024 || merged.size() >= awork.size()) merged.clear();
+            }
             // one small table: angle work | region_of[S*S] | inv_rank[N]; the items beside it
             std::vector<int32_t> tab(4 * awork.size() + (size_t)S * S + (size_t)t->n_atoms);
             memcpy(tab.data(), awork.data(), awork.size() * sizeof(int4));
@@ -1907,6 +2076,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             }
             void *d_lists;
             const int i_tab = nw.pk.add(tab.data(), tab.size() * sizeof(int32_t));
+            const int i_merged = nw.pk.add(merged.data(), merged.size() * sizeof(MergedItem));
             AMOF_TRY(nbr_frame_commit(ctx, nw));
             const int32_t *d_tab = nw.pk.ptr<int32_t>(i_tab);
             const size_t per_frame = (size_t)R * (sizeof(uint32_t) + (size_t)NBRL_CAP * NBRL_EW * sizeof(double));
@@ -1950,6 +2120,28 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 else e = nw.ortho ? launch(lists_frame_kernel<true, 8>) : launch(lists_frame_kernel<false, 8>);
                 AMOF_HIP_TRY(ctx, e);
                 AMOF_HIP_TRY(ctx, hipGetLastError());
+                if (!merged.empty()) {
+                    // one pass per centre species: about 1024 workgroups of 512 lanes in all
+                    int64_t widest_m = 0;
+                    for (const MergedItem &mi : merged)
+                        widest_m = std::max<int64_t>(widest_m, (nfr * st.tiles.nsp[(size_t)mi.sa] + NBRM_THREADS - 1) / NBRM_THREADS);
+                    const int64_t gm = std::max<int64_t>(1, std::min<int64_t>(widest_m, (1024 + (int64_t)merged.size() - 1) / (int64_t)merged.size()));
+                    const dim3 mgrid((unsigned)gm, (unsigned)merged.size());
+                    const MergedItem *d_merged = nw.pk.ptr<MergedItem>(i_merged);
+                    if (nw.ortho) {
+                        e = allow_max_lds((const void *)bad_rows_merged_kernel<true>);
+                        if (e == hipSuccess) hipLaunchKernelGGL(bad_rows_merged_kernel<true>, mgrid, dim3(NBRM_THREADS), lds_merged, ctx->stream, a, la,
+                                                                d_merged, nw.d_spfirst, (int)nfr);
+                    } else {
+                        e = allow_max_lds((const void *)bad_rows_merged_kernel<false>);
+                        if (e == hipSuccess) hipLaunchKernelGGL(bad_rows_merged_kernel<false>, mgrid, dim3(NBRM_THREADS), lds_merged, ctx->stream, a, la,
+                                                                d_merged, nw.d_spfirst, (int)nfr);
+                    }
+                    AMOF_HIP_TRY(ctx, e);
+                    AMOF_HIP_TRY(ctx, hipGetLastError());
+                    launches++;
+                    continue;
+                }
                 // angle kernel: about eight workgroups per CU in all work items together, each striding over the tiles of its own
                 int64_t widest = 0;
                 for (const int4 &w : awork) widest = std::max<int64_t>(widest, (nfr * st.tiles.nsp[(size_t)w.y] + NBRF_TILE - 1) / NBRF_TILE);

@@ -139,6 +139,9 @@ def test_cn_bad_fast_equals_exact_equals_oracle(hip_ctx, kind):
         h_fb, a_fb = hip_ctx.bad_hist(packed, rcm, triples, edges)
         assert hip_ctx.last_path() == "bad_frame"
     assert np.array_equal(a_fb, a_frame) and np.array_equal(h_fb, h_frame)
+    with _env(AMOF_BAD_NOMERGE="1"):                                 # one angle pass per triple instead of one per centre species
+        h_nm, a_nm = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert np.array_equal(a_nm, a_frame) and np.array_equal(h_nm, h_frame)
     with _env(AMOF_BAD_EDGE_TABLE="1"):                              # bin edges read from the table instead of recomputed as k * step
         h_et, a_et = hip_ctx.bad_hist(packed, rcm, triples, edges)
     assert np.array_equal(a_et, a_frame) and np.array_equal(h_et, h_frame)
