@@ -1701,8 +1701,8 @@ static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slot
     return true;
 }
 
-// shared constants of the tier (after the items are known); ok stays false when the tier cannot take the call
-static int nbr_frame_prepare(amof_ctx *ctx, const amof_traj *t, const double *cutoff, NbrSetup &st, NbrFrame &nw, double hmin[3])
+// host-side constants of the tier (nothing is uploaded before nbr_frame_commit); ok stays false when the tier cannot take the call
+static int nbr_frame_prepare(const amof_traj *t, const double *cutoff, NbrSetup &st, NbrFrame &nw, double hmin[3])
 {
     const int S = t->n_species;
     const int64_t nc = t->n_cells;
@@ -1810,7 +1810,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         // gather kernels: its centres still want their zeros)
         NbrFrame nw;
         double hmin[3];
-        AMOF_TRY(nbr_frame_prepare(ctx, t, cutoff, st, nw, hmin));
+        AMOF_TRY(nbr_frame_prepare(t, cutoff, st, nw, hmin));
         for (int s2 = 0; s2 < n_sets && nw.ok; s2++) {
             const int A = sets[2 * s2], B = sets[2 * s2 + 1];
             const int64_t nA = st.tiles.nsp[A], nB = st.tiles.nsp[B];
@@ -1990,7 +1990,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         const int S = t->n_species;
         NbrFrame nw;
         double hmin[3];
-        AMOF_TRY(nbr_frame_prepare(ctx, t, cutoff, st, nw, hmin));
+        AMOF_TRY(nbr_frame_prepare(t, cutoff, st, nw, hmin));
         if (getenv("AMOF_BAD_NOTRANSPOSE")) nw.ok = false;      // (names the two-search gather kernels)
         auto live_pair = [&](int x, int y) { return cutoff[x * S + y] > 0.0 && st.tiles.nsp[x] > 0 && st.tiles.nsp[y] > 0; };
         std::vector<char> needed((size_t)S * S, 0);
