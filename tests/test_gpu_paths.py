@@ -687,3 +687,31 @@ def test_rdf_zf_cubic_cells_without_culling(hip_ctx):
     packed = PackedTrajectory(np.stack([p, p[:, [2, 0, 1]], p + 100.0]), np.diag([L] * 3), numbers)
     for rmax, nb in [(12.0, 1200), (11.5, 2310), (12.0, 37)]:
         _zf_vs_oracle(hip_ctx, packed, rmax, nb, nocull_too=False)
+
+
+def test_frame_tier_on_a_host_trajectory_staged_in_batches(hip_ctx):
+    """1700 host-resident frames reach the whole-frame kernels in staged batches of 512, 1024, ... frames: same counts as
+    the device-resident copy, the oracle on both ends of the trajectory"""
+    import torch
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (2, 1, 1)), 1700, 0.03, 5, ortho=True)
+    kinds, sp = H.species_of(packed.numbers)
+    S = len(kinds)
+    zn, n, c = kinds.index(30), kinds.index(7), kinds.index(6)
+    rcm = np.zeros((S, S))
+    rcm[zn, n] = rcm[n, zn] = 2.5
+    rcm[c, n] = rcm[n, c] = 1.6
+    sets = [(zn, n), (n, zn), (c, n)]
+    triples = [(zn, n), (n, zn), (n, -1), (-1, -1)]
+    edges = np.arange(182) * 1.0
+    dev = PackedTrajectory(torch.tensor(packed.pos, device="cuda:0"), packed.cell, packed.numbers)
+    s_host = hip_ctx.cn_count(packed, rcm, sets)
+    assert hip_ctx.last_path() == "cn_frame"
+    assert np.array_equal(s_host, hip_ctx.cn_count(dev, rcm, sets))
+    assert np.array_equal(s_host[:40], clib.cn_counts(packed.pos[:40], packed.cell, sp, S, rcm, sets))
+    h_host, a_host = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_frame"
+    h_dev, a_dev = hip_ctx.bad_hist(dev, rcm, triples, edges)
+    assert np.array_equal(h_host, h_dev) and np.array_equal(a_host, a_dev)
+    h_ref, a_ref = clib.bad_hist(packed.pos[1600:], packed.cell, sp, S, rcm, triples, edges)
+    h_end, a_end = hip_ctx.bad_hist(packed, rcm, triples, edges, frame_range=(1600, 1700))
+    assert np.array_equal(h_end, h_ref) and np.array_equal(a_end, a_ref)
