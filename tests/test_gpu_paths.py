@@ -715,3 +715,32 @@ def test_frame_tier_on_a_host_trajectory_staged_in_batches(hip_ctx):
     h_ref, a_ref = clib.bad_hist(packed.pos[1600:], packed.cell, sp, S, rcm, triples, edges)
     h_end, a_end = hip_ctx.bad_hist(packed, rcm, triples, edges, frame_range=(1600, 1700))
     assert np.array_equal(h_end, h_ref) and np.array_equal(a_end, a_ref)
+
+
+@pytest.mark.parametrize("n_pair", [4096, 4097, 8192, 8193])
+def test_frame_tier_atom_count_boundaries(hip_ctx, n_pair):
+    """4096 / 4097 atoms in a pair switch between the 4- and the 8-atoms-per-thread kernels, 8192 / 8193 between the
+    whole-frame tier and the gather kernels: one species alone, and two species sharing the count unevenly"""
+    rng = np.random.default_rng(n_pair)
+    L = (n_pair / 0.06) ** (1 / 3)
+    cell = np.diag([L, 1.1 * L, 0.9 * L])
+    edges = np.arange(182) * 1.0
+    for split in (n_pair, n_pair // 3):
+        numbers = np.where(np.arange(n_pair) < split, 30, 7)
+        pos = rng.uniform(0, 1, (2, n_pair, 3)) @ cell
+        packed = PackedTrajectory(pos, cell, numbers)
+        kinds, sp = H.species_of(packed.numbers)
+        S = len(kinds)
+        rcm = np.full((S, S), 2.2)
+        sets = [(a, b) for a in range(S) for b in range(S)]
+        got = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+        path = hip_ctx.last_path()
+        # (two species: every pair of the call must fit -- the same-species pairs are smaller than the mixed one)
+        assert (path == "cn_frame") == (n_pair <= 8192), (n_pair, split, path)
+        ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (n_pair, split, path)
+        triples = [(0, 0), (0, -1), (-1, -1)] if S == 1 else [(0, 1), (1, 0), (1, -1), (-1, -1)]
+        hg = hip_ctx.bad_hist(packed, rcm, triples, edges)
+        assert (hip_ctx.last_path() == "bad_frame") == (n_pair <= 8192), (n_pair, split, hip_ctx.last_path())
+        hr = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
+        assert np.array_equal(hg[0], hr[0]) and np.array_equal(hg[1], hr[1]), (n_pair, split)
