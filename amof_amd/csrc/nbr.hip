@@ -1017,7 +1017,9 @@ __global__ __launch_bounds__(256) void bad_transposed_kernel(NbrFastArgs fa, con
 // three sorts and three LDS searches.
 constexpr int NBRL_CAP = NBRF_NLIST;      // a fuller centre sends the call to the exact kernels, as in bad_fast_kernel
 constexpr int NBRL_EW = 4;                // doubles per row entry: (ux, uy, uz, -) -- one aligned 32-byte sector per unit vector
-constexpr int NBRW_HITS = 3072;           // pairs lists_frame_kernel buffers in LDS (flushed once half full)
+constexpr int NBRW_HITS = 3072;           // pairs lists_frame_kernel buffers in LDS, flushed once a third full: a round of 1024
+                                          // tasks may then add 2048 (two neighbours per centre and ROW of cells) before the call
+                                          // has to fall back to the exact kernels
 
 struct NbrListArgs {
     const int32_t *region_of;  // [S][S] first row of the ordered pair (centre species, partner species); -1: not kept
@@ -1084,10 +1086,10 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
                 else a.flags[1] = 1;        // (absurdly many pairs per task: the exact kernels take the call)
             });
         }
-        // flush once the buffer is half full, and after the last round (the OR makes the decision uniform: a thread may
+        // flush once the buffer is a third full, and after the last round (the OR makes the decision uniform: a thread may
         // read the counter while slower ones still append)
-        const bool half_full = __syncthreads_or(nhits > (unsigned)NBRW_HITS / 2);
-        if (!half_full && t0 + NBRW_THREADS < tasks) continue;
+        const bool filling = __syncthreads_or(nhits > (unsigned)NBRW_HITS / 3);
+        if (!filling && t0 + NBRW_THREADS < tasks) continue;
         // one lane per pair: the canonical unit vector once, to the centre's row and, negated, to the partner's
         const unsigned nh = min(nhits, (unsigned)NBRW_HITS);
         for (unsigned h = tid; h < nh; h += NBRW_THREADS) {
