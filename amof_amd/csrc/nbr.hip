@@ -557,17 +557,38 @@ struct FrameArgs {
     int32_t *qflag;            // raised for atoms absurdly far from the cell
     int32_t f_base, nf;
     float guard_rel, guard_abs;
+    // COMPACT kernels (pairs too big for two workgroups per CU with 16-byte records): 8-byte records -- 16-bit fixed point,
+    // no atom index -- and, in global scratch, (atom, rank inside its species) of every sorted position
+    float guard_abs16;         // the absolute guard of 16-bit coordinates
+    uint2 *sidx;               // [frames of the batch][items of the launch][sidx_stride]
+    int32_t sidx_stride;
 };
 
 struct FrameLds {
-    uint4 *rec;                // [atoms of the item] sorted records: species slot 0 first (cells x fastest), then slot 1
+    unsigned char *rec;        // [atoms of the item] sorted records (uint4, COMPACT: uint2): species slot 0 first (cells x fastest), then slot 1
     uint32_t *cell_end;        // [slots * ncell] end of every cell (its start = the entry before it; 0 for the first)
+    uint2 *sidx;               // COMPACT: this workgroup's piece of FrameArgs::sidx
 };
+
+// record of sorted position j as (ux, uy, uz, atom | slot flag) -- COMPACT: the 16-bit coordinates in the upper halves, w = 0
+template <bool COMPACT>
+__device__ __forceinline__ uint4 frame_rec(const FrameLds &L, int j)
+{
+    if (!COMPACT) return reinterpret_cast<const uint4 *>(L.rec)[j];
+    const uint2 r = reinterpret_cast<const uint2 *>(L.rec)[j];
+    return make_uint4(r.x << 16, r.x & 0xffff0000u, r.y << 16, 0u);
+}
+
+template <bool COMPACT>
+__device__ __forceinline__ uint32_t frame_atom(const FrameLds &L, int j, const uint4 &q)
+{
+    return COMPACT ? L.sidx[j].x : (q.w & ~NBRW_SLOT1);
+}
 
 // fold, quantise and cell-sort the item's one or two species of frame f into LDS.  PT = atoms per thread (records wait
 // in registers between the counting and the placement pass); the index and position loads of a thread's atoms are
 // issued together -- one round trip each instead of one per atom
-template <int PT>
+template <int PT, bool COMPACT>
 __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr, const FrameItem &it, const FrameLds &L,
                                            int f, int nA, int nB, unsigned *wsum)
 {
@@ -603,6 +624,7 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
             sf = sf - floor(sf);
             const double t = sf * 4294967296.0;
             u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+            if (COMPACT) u[c] &= 0xffff0000u;       // (the cell of an atom follows from the coordinate its record keeps)
         }
         const bool second = k >= nA;
         rec[i] = make_uint4(u[0], u[1], u[2], (uint32_t)atom[i] | (second ? NBRW_SLOT1 : 0u));
@@ -635,7 +657,15 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
 #pragma unroll
     for (int i = 0; i < PT; i++) {
         const int k = tid + i * NBRW_THREADS;
-        if (k < n) L.rec[atomicAdd(&L.cell_end[key[i]], 1u)] = rec[i];
+        if (k < n) {
+            const unsigned slot = atomicAdd(&L.cell_end[key[i]], 1u);
+            if (COMPACT) {
+                reinterpret_cast<uint2 *>(L.rec)[slot] = make_uint2((rec[i].x >> 16) | rec[i].y, rec[i].z >> 16);
+                L.sidx[slot] = make_uint2(rec[i].w & ~NBRW_SLOT1, (uint32_t)(k >= nA ? k - nA : k));
+            } else {
+                reinterpret_cast<uint4 *>(L.rec)[slot] = rec[i];
+            }
+        }
     }
     __syncthreads();
 }
@@ -645,14 +675,16 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
 // wave's trip count is the fullest ROW of its lanes, not the fullest neighbourhood (per-lane loops over all 27 cells ran
 // at a third of the issue rate: 18 us of a 31 us frame).  visit(is a neighbour, sorted position of the partner) is called
 // for EVERY candidate by all lanes still in the loop, so that a caller may aggregate over the wave.
-template <bool ORTHO, typename F>
+// c = the centre's own sorted position; one_species: partners and centres are the same atoms (the zero-shift self pair is skipped).
+template <bool ORTHO, bool COMPACT, typename F>
 __device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const FrameItem &it, const FrameLds &L, int slot,
                                                      const float *sc, const double *__restrict__ geo,
-                                                     const double *__restrict__ p, const uint4 qc, int r9, double rc, F &&visit)
+                                                     const double *__restrict__ p, int c, bool one_species, const uint4 qc, int r9, double rc,
+                                                     F &&visit)
 {
     const int nx = it.nx, ny = it.ny, nz = it.nz;
     const float rcf = (float)rc;
-    const float gd = rcf * fr.guard_rel + fr.guard_abs;
+    const float gd = rcf * fr.guard_rel + (COMPACT ? fr.guard_abs16 : fr.guard_abs);
     const float r_in = rcf - gd, r_out = rcf + gd;
     const int cx = (int)__umulhi(qc.x, (unsigned)nx), cy = (int)__umulhi(qc.y, (unsigned)ny), cz = (int)__umulhi(qc.z, (unsigned)nz);
     const int dz = r9 / 3 - 1, dy = r9 - 3 * (r9 / 3) - 1;
@@ -670,17 +702,18 @@ __device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const 
     const int len0 = hi0 - lo0, total = len0 + hi1 - lo1;
     for (int q = 0; q < total; q++) {
         const int j = q < len0 ? lo0 + q : lo1 + (q - len0);
-        const uint4 qj = L.rec[j];
+        const uint4 qj = frame_rec<COMPACT>(L, j);
         const float d = nbr_fast_dist<ORTHO>(sc, qc.x, qc.y, qc.z, qj);
         bool nbr = d < r_in;
-        if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, qc.w & ~NBRW_SLOT1, qj.w & ~NBRW_SLOT1, rc);
-        visit(nbr && qj.w != qc.w, j);                          // (no zero-shift self pair: same species, same atom)
+        if (!nbr && d < r_out) nbr = nbr_exact<ORTHO>(geo, p, frame_atom<COMPACT>(L, c, qc), frame_atom<COMPACT>(L, j, qj), rc);
+        visit(nbr && !(one_species && j == c), j);              // (no zero-shift self pair)
     }
 }
 
-// PT = 4: up to 4096 atoms per item, two workgroups per CU (64 VGPRs); PT = 8: up to 8192, one
-template <bool ORTHO, int PT>
-__global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void cn_frame_kernel(NbrArgs a, FrameArgs fr)
+// PT = 4: up to 4096 atoms per item, two workgroups per CU (64 VGPRs); PT = 8: up to 8192 -- two per CU with COMPACT records when
+// the pair then fits half a CU's LDS, one otherwise
+template <bool ORTHO, int PT, bool COMPACT>
+__global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void cn_frame_kernel(NbrArgs a, FrameArgs fr)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ unsigned wsum[NBRW_THREADS / 64];
@@ -691,13 +724,14 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void cn_frame_kernel
     const int f = fr.f_base + (int)blockIdx.y;
     const int nA = (int)(fr.sp_first[it.sa + 1] - fr.sp_first[it.sa]);
     const int nB = it.sa == it.sb ? 0 : (int)(fr.sp_first[it.sb + 1] - fr.sp_first[it.sb]);
-    L.rec = reinterpret_cast<uint4 *>(lds_raw);                         // (every item lays LDS out for its own atom count)
-    L.cell_end = reinterpret_cast<uint32_t *>(L.rec + nA + nB);
+    L.rec = lds_raw;                                                    // (every item lays LDS out for its own atom count)
+    L.cell_end = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(nA + nB) * (COMPACT ? sizeof(uint2) : sizeof(uint4)));
+    L.sidx = COMPACT ? fr.sidx + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)fr.sidx_stride : nullptr;
     const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
     int32_t *__restrict__ pa = a.per_atom ? a.per_atom + ((size_t)f * a.n_sets + it.set) * (size_t)a.N : nullptr;
     if (pa)     // every centre starts at zero (the barriers of the sort order these stores before the atomics below)
         for (int c = tid; c < nA; c += NBRW_THREADS) pa[a.perm[fr.sp_first[it.sa] + c]] = 0;
-    frame_sort<PT>(a, fr, it, L, f, nA, nB, wsum);
+    frame_sort<PT, COMPACT>(a, fr, it, L, f, nA, nB, wsum);
     const int gi = a.n_cells == 1 ? 0 : f;
     const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
     float sc[9];
@@ -708,10 +742,11 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void cn_frame_kernel
     const int tasks = nA * 9;
     for (int t = tid; t < tasks; t += NBRW_THREADS) {
         const int c = t / 9, r9 = t - 9 * c;
-        const uint4 qc = L.rec[c];
+        const uint4 qc = frame_rec<COMPACT>(L, c);
         int cnt = 0;
-        frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, qc, r9, rc, [&](bool nbr, int) { cnt += nbr ? 1 : 0; });
-        if (pa && cnt) atomicAdd(&pa[qc.w], cnt);
+        frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, c, nB == 0, qc, r9, rc,
+                                             [&](bool nbr, int) { cnt += nbr ? 1 : 0; });
+        if (pa && cnt) atomicAdd(&pa[frame_atom<COMPACT>(L, c, qc)], cnt);
         sum += (unsigned long long)cnt;
     }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
@@ -1031,8 +1066,8 @@ struct NbrListArgs {
     int32_t R;
 };
 
-template <bool ORTHO, int PT>
-__global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_kernel(NbrArgs a, FrameArgs fr, NbrListArgs la)
+template <bool ORTHO, int PT, bool COMPACT>
+__global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void lists_frame_kernel(NbrArgs a, FrameArgs fr, NbrListArgs la)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ unsigned wsum[NBRW_THREADS / 64];
@@ -1042,8 +1077,9 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
     const int fl = (int)blockIdx.y, f = fr.f_base + fl;
     const int nA = (int)(fr.sp_first[it.sa + 1] - fr.sp_first[it.sa]);
     const int nB = it.sa == it.sb ? 0 : (int)(fr.sp_first[it.sb + 1] - fr.sp_first[it.sb]);
-    L.rec = reinterpret_cast<uint4 *>(lds_raw);
-    L.cell_end = reinterpret_cast<uint32_t *>(L.rec + nA + nB);
+    L.rec = lds_raw;
+    L.cell_end = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(nA + nB) * (COMPACT ? sizeof(uint2) : sizeof(uint4)));
+    L.sidx = COMPACT ? fr.sidx + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)fr.sidx_stride : nullptr;
     const int n = nA + nB, ntab = (nB > 0 ? 2 : 1) * it.nx * it.ny * it.nz;
     // neighbours found so far, one BYTE per atom (sorted position), four to a word: a lane claims a slot with
     // atomicAdd(word, 1 << 8 * (c & 3)) (an atom past 16 fails the call anyway, so a carry into the next byte is harmless)
@@ -1054,7 +1090,7 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
     __shared__ unsigned nhits;
     for (int c = tid; c < (n + 3) / 4; c += NBRW_THREADS) cnt[c] = 0u;
     if (tid == 0) nhits = 0u;
-    frame_sort<PT>(a, fr, it, L, f, nA, nB, wsum);
+    frame_sort<PT, COMPACT>(a, fr, it, L, f, nA, nB, wsum);
     const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
     const int gi = a.n_cells == 1 ? 0 : f;
     const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
@@ -1073,7 +1109,8 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
         const int t = t0 + tid;
         if (t < tasks) {
             const int c = t / 9, r9 = t - 9 * c;
-            frame_row_neighbours<ORTHO>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, L.rec[c], r9, rc, [&](bool nbr, int j) {
+            frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, c, nB == 0, frame_rec<COMPACT>(L, c), r9, rc,
+                                                 [&](bool nbr, int j) {
                 // one LDS atomic per wave and trip, not one per pair (they would all hit the same word)
                 const unsigned long long m = __ballot(nbr);
                 if (!m) return;
@@ -1094,8 +1131,16 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
         const unsigned nh = min(nhits, (unsigned)NBRW_HITS);
         for (unsigned h = tid; h < nh; h += NBRW_THREADS) {
             const int c = (int)(hits[h] >> 13), j = (int)(hits[h] & 0x1fffu);
-            const uint32_t atom_c = L.rec[c].w, atom_j = L.rec[j].w & ~NBRW_SLOT1;
-            const int rank_c = la.inv_rank[atom_c], rank_j = la.inv_rank[atom_j];      // (loaded beside the positions)
+            uint32_t atom_c, atom_j;
+            int rank_c, rank_j;
+            if (COMPACT) {
+                const uint2 ic = L.sidx[c], ij = L.sidx[j];
+                atom_c = ic.x; rank_c = (int)ic.y; atom_j = ij.x; rank_j = (int)ij.y;
+            } else {
+                atom_c = reinterpret_cast<const uint4 *>(L.rec)[c].w;
+                atom_j = reinterpret_cast<const uint4 *>(L.rec)[j].w & ~NBRW_SLOT1;
+                rank_c = la.inv_rank[atom_c]; rank_j = la.inv_rank[atom_j];                // (loaded beside the positions)
+            }
             const double *pc = p + (size_t)atom_c * 3, *pj = p + (size_t)atom_j * 3;
             double vx, vy, vz, ux = 0.0, uy = 0.0, uz = 0.0;
             pair_base<ORTHO>(geo, pj[0] - pc[0], pj[1] - pc[1], pj[2] - pc[2], vx, vy, vz);
@@ -1128,7 +1173,8 @@ __global__ __launch_bounds__(NBRW_THREADS, PT == 4 ? 8 : 4) void lists_frame_ker
         const int reg = c < nA ? it.reg_ab : it.reg_ba;
         if (reg < 0) continue;
         const uint32_t k = (cnt[c >> 2] >> (8u * ((unsigned)c & 3u))) & 0xffu;
-        la.count[base + (size_t)(reg + la.inv_rank[L.rec[c].w & ~NBRW_SLOT1])] = min(k, (uint32_t)NBRL_CAP);
+        const int rank = COMPACT ? (int)L.sidx[c].y : la.inv_rank[reinterpret_cast<const uint4 *>(L.rec)[c].w & ~NBRW_SLOT1];
+        la.count[base + (size_t)(reg + rank)] = min(k, (uint32_t)NBRL_CAP);
     }
 }
 
@@ -1664,6 +1710,7 @@ struct NbrFrame {
     bool ortho = false;
     std::vector<FrameItem> items;
     size_t lds = 0;
+    bool compact = false;   // 8-byte records + (atom, rank) in global scratch: pairs that 16-byte records leave one workgroup per CU
     FrameArgs fr;
     std::vector<NbrCell> cells;
     std::vector<int64_t> sp_first;
@@ -1674,7 +1721,7 @@ struct NbrFrame {
 
 // a grid for one species pair: cells at least rc thick, >= 3 per axis, as fine as the LDS left beside n records allows
 static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slots, int64_t densest, FrameItem &it, size_t &lds,
-                            size_t extra_bytes = 0)
+                            size_t rec_size, size_t extra_bytes = 0)
 {
     if (n > NBRW_MAX_ATOMS || n <= 0) return false;
     int nk[3];
@@ -1682,10 +1729,10 @@ static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slot
         nk[x] = (int)std::min(1024.0, floor(hmin[x] / (rc * (1.0 + 1e-5))));
         if (nk[x] < 3) return false;
     }
-    const size_t rec_bytes = (size_t)n * sizeof(uint4) + extra_bytes;      // (+ whatever else the kernel keeps per atom)
+    const size_t rec_bytes = (size_t)n * rec_size + extra_bytes;           // (+ whatever else the kernel keeps per atom)
     // two workgroups per CU when the records leave room for a useful table, one otherwise
     size_t budget = 76 * 1024;
-    if (rec_bytes + (size_t)slots * 4 * std::min<int64_t>(densest / 2 + 27, 4096) > budget) budget = 152 * 1024;
+    if (rec_bytes + (size_t)slots * 4 * std::min<int64_t>(densest / 4 + 27, 1024) > budget) budget = 152 * 1024;
     if (rec_bytes + (size_t)slots * 4 * 27 > budget) return false;
     const int64_t cells_budget = (int64_t)((budget - rec_bytes) / ((size_t)slots * 4));
     // no point in cells emptier than ~1 atom of the denser species
@@ -1752,6 +1799,9 @@ static int nbr_frame_prepare(const amof_traj *t, const double *cutoff, NbrSetup 
         fr.guard_rel = fg;
     }
     fr.guard_abs = (float)(csum * (1.0 / 2147483648.0));
+    fr.guard_abs16 = (float)(csum * (1.0 / 32768.0));      // (16-bit coordinates: one unit is 2^-16 of a cell vector; x2 margin as above)
+    fr.sidx = nullptr;
+    fr.sidx_stride = 0;
     return AMOF_OK;
 }
 
@@ -1813,14 +1863,24 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         NbrFrame nw;
         double hmin[3];
         AMOF_TRY(nbr_frame_prepare(t, cutoff, st, nw, hmin));
-        for (int s2 = 0; s2 < n_sets && nw.ok; s2++) {
-            const int A = sets[2 * s2], B = sets[2 * s2 + 1];
-            const int64_t nA = st.tiles.nsp[A], nB = st.tiles.nsp[B];
-            if (!(cutoff[A * S + B] > 0.0) || nA == 0 || nB == 0) { nw.ok = !per_atom; continue; }
-            FrameItem it{};
-            it.sa = A; it.sb = B; it.set = s2; it.reg_ab = it.reg_ba = -1;
-            nw.ok = frame_item_grid(hmin, cutoff[A * S + B], A == B ? nA : nA + nB, A == B ? 1 : 2, std::max(nA, nB), it, nw.lds);
-            if (nw.ok) nw.items.push_back(it);
+        const bool tier_ok = nw.ok;
+        for (int pass = 0; pass < 3 && tier_ok; pass++) {
+            // 16-byte records first; if a pair then needs a whole CU's LDS, everything again with the 8-byte ones; if that
+            // does not bring two workgroups per CU either, the 16-byte ones stay
+            nw.ok = true; nw.items.clear(); nw.lds = 0; nw.compact = pass == 1;
+            int64_t biggest = 0;
+            for (int s2 = 0; s2 < n_sets && nw.ok; s2++) {
+                const int A = sets[2 * s2], B = sets[2 * s2 + 1];
+                const int64_t nA = st.tiles.nsp[A], nB = st.tiles.nsp[B];
+                if (!(cutoff[A * S + B] > 0.0) || nA == 0 || nB == 0) { nw.ok = !per_atom; continue; }
+                FrameItem it{};
+                it.sa = A; it.sb = B; it.set = s2; it.reg_ab = it.reg_ba = -1;
+                nw.ok = frame_item_grid(hmin, cutoff[A * S + B], A == B ? nA : nA + nB, A == B ? 1 : 2, std::max(nA, nB), it, nw.lds,
+                                        nw.compact ? sizeof(uint2) : sizeof(uint4));
+                if (nw.ok) nw.items.push_back(it);
+                biggest = std::max(biggest, A == B ? nA : nA + nB);
+            }
+            if ((nw.ok && nw.lds <= 76 * 1024) || pass == 2) break;
         }
         if (nw.ok && !nw.items.empty()) {
             AMOF_TRY(nbr_frame_commit(ctx, nw));
@@ -1828,7 +1888,16 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
             for (const FrameItem &it : nw.items)
                 most = std::max<int64_t>(most, st.tiles.nsp[it.sa] + (it.sa == it.sb ? 0 : st.tiles.nsp[it.sb]));
             int64_t launches = 0;
-            const int64_t FB = std::min<int64_t>(t->n_frames, 32768), FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
+            int64_t FB = std::min<int64_t>(t->n_frames, 32768);
+            if (nw.compact) {       // (atom, rank) of every sorted position: at most 256 MB a batch
+                const size_t per_frame = nw.items.size() * (size_t)most * sizeof(uint2);
+                FB = std::max<int64_t>(1, std::min<int64_t>(FB, (int64_t)(((size_t)256 << 20) / per_frame)));
+                void *d_sidx;
+                AMOF_TRY(ensure(ctx, SLOT_AUX6, (size_t)FB * per_frame, &d_sidx));
+                nw.fr.sidx = (uint2 *)d_sidx;
+                nw.fr.sidx_stride = (int32_t)most;
+            }
+            const int64_t FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
             for (int64_t fb = 0, cur = FB0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
                 const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
                 AMOF_TRY(stager_need(st.stage, fb + nfr));
@@ -1842,8 +1911,10 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
                     return e2;
                 };
                 hipError_t e;
-                if (most <= 4 * NBRW_THREADS) e = nw.ortho ? launch(cn_frame_kernel<true, 4>) : launch(cn_frame_kernel<false, 4>);
-                else e = nw.ortho ? launch(cn_frame_kernel<true, 8>) : launch(cn_frame_kernel<false, 8>);
+                if (most > 4 * NBRW_THREADS && nw.compact) e = nw.ortho ? launch(cn_frame_kernel<true, 8, true>) : launch(cn_frame_kernel<false, 8, true>);
+                else if (most > 4 * NBRW_THREADS) e = nw.ortho ? launch(cn_frame_kernel<true, 8, false>) : launch(cn_frame_kernel<false, 8, false>);
+                else if (nw.compact) e = nw.ortho ? launch(cn_frame_kernel<true, 4, true>) : launch(cn_frame_kernel<false, 4, true>);
+                else e = nw.ortho ? launch(cn_frame_kernel<true, 4, false>) : launch(cn_frame_kernel<false, 4, false>);
                 AMOF_HIP_TRY(ctx, e);
                 AMOF_HIP_TRY(ctx, hipGetLastError());
                 launches++;
@@ -2012,23 +2083,31 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         for (int x = 0; x < S * S && nw.ok; x++)
             if (needed[(size_t)x]) { region_of[(size_t)x] = (int32_t)R; R += st.tiles.nsp[(size_t)(x / S)]; }
         int64_t most = 0;
-        for (int x = 0; x < S && nw.ok; x++)
-            for (int y = x; y < S && nw.ok; y++) {
-                if (!needed[(size_t)x * S + y] && !needed[(size_t)y * S + x]) continue;
-                FrameItem it{};
-                it.sa = st.tiles.nsp[y] < st.tiles.nsp[x] ? y : x;      // the species with fewer atoms searches
-                it.sb = it.sa == x ? y : x;
-                it.set = 0;
-                it.reg_ab = region_of[(size_t)it.sa * S + it.sb];
-                it.reg_ba = x == y ? -1 : region_of[(size_t)it.sb * S + it.sa];
-                const int64_t n = st.tiles.nsp[x] + (x == y ? 0 : st.tiles.nsp[y]);
-                size_t lds_it = 0;
-                nw.ok = frame_item_grid(hmin, cutoff[x * S + y], n, x == y ? 1 : 2, std::max(st.tiles.nsp[x], st.tiles.nsp[y]), it, lds_it,
-                                        (size_t)((n + 3) / 4) * 4 + (size_t)NBRW_HITS * sizeof(uint32_t));
-                nw.lds = std::max(nw.lds, lds_it);
-                most = std::max(most, n);
-                if (nw.ok) nw.items.push_back(it);
-            }
+        const bool tier_ok = nw.ok;
+        for (int pass = 0; pass < 3 && tier_ok; pass++) {
+            // 16-byte records first; if a pair then needs a whole CU's LDS, everything again with the 8-byte ones; if that
+            // does not bring two workgroups per CU either, the 16-byte ones stay
+            nw.ok = true; nw.items.clear(); nw.lds = 0; nw.compact = pass == 1; most = 0;
+            for (int x = 0; x < S && nw.ok; x++)
+                for (int y = x; y < S && nw.ok; y++) {
+                    if (!needed[(size_t)x * S + y] && !needed[(size_t)y * S + x]) continue;
+                    FrameItem it{};
+                    it.sa = st.tiles.nsp[y] < st.tiles.nsp[x] ? y : x;      // the species with fewer atoms searches
+                    it.sb = it.sa == x ? y : x;
+                    it.set = 0;
+                    it.reg_ab = region_of[(size_t)it.sa * S + it.sb];
+                    it.reg_ba = x == y ? -1 : region_of[(size_t)it.sb * S + it.sa];
+                    const int64_t n = st.tiles.nsp[x] + (x == y ? 0 : st.tiles.nsp[y]);
+                    size_t lds_it = 0;
+                    nw.ok = frame_item_grid(hmin, cutoff[x * S + y], n, x == y ? 1 : 2, std::max(st.tiles.nsp[x], st.tiles.nsp[y]), it, lds_it,
+                                            nw.compact ? sizeof(uint2) : sizeof(uint4),
+                                            (size_t)((n + 3) / 4) * 4 + (size_t)NBRW_HITS * sizeof(uint32_t));
+                    nw.lds = std::max(nw.lds, lds_it);
+                    most = std::max(most, n);
+                    if (nw.ok) nw.items.push_back(it);
+                }
+            if ((nw.ok && nw.lds <= 76 * 1024) || pass == 2) break;
+        }
         if (nw.ok && !awork.empty() && R > 0 && R < (1ll << 30) && t->n_frames > 0) {
             // merged angle passes: one per centre species, every angle computed once (histograms in LDS; BadByCn keys, more
             // bins than LDS holds, a centre species with more than three partner species or a triple named twice keep
@@ -2087,6 +2166,11 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             int64_t FB = std::max<int64_t>(1, (int64_t)rows_budget / (int64_t)per_frame);
             FB = std::min<int64_t>(FB, std::max<int64_t>(1, 0x7fffff00ll / std::max<int64_t>(1, t->n_atoms)));    // flat (frame, centre) index
             FB = std::min<int64_t>(std::min<int64_t>(FB, 32768), t->n_frames);
+            size_t sidx_per_frame = 0;
+            if (nw.compact) {       // (atom, rank) of every sorted position: at most 256 MB a batch
+                sidx_per_frame = nw.items.size() * (size_t)most * sizeof(uint2);
+                FB = std::max<int64_t>(1, std::min<int64_t>(FB, (int64_t)(((size_t)256 << 20) / sidx_per_frame)));
+            }
             // (a device short of memory gets smaller batches, not an error)
             for (;;) {
                 const int rc_rows = ensure(ctx, SLOT_AUX9, (size_t)FB * per_frame, &d_lists);
@@ -2095,6 +2179,12 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 FB = std::max<int64_t>(1, FB / 4);
             }
             const int64_t FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
+            if (nw.compact) {
+                void *d_sidx;
+                AMOF_TRY(ensure(ctx, SLOT_AUX6, (size_t)FB * sidx_per_frame, &d_sidx));
+                nw.fr.sidx = (uint2 *)d_sidx;
+                nw.fr.sidx_stride = (int32_t)most;
+            }
             NbrListArgs la;
             const int4 *d_aw = (const int4 *)d_tab;
             la.region_of = (const int32_t *)d_tab + 4 * awork.size();
@@ -2118,8 +2208,10 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                     return e2;
                 };
                 hipError_t e;
-                if (most <= 4 * NBRW_THREADS) e = nw.ortho ? launch(lists_frame_kernel<true, 4>) : launch(lists_frame_kernel<false, 4>);
-                else e = nw.ortho ? launch(lists_frame_kernel<true, 8>) : launch(lists_frame_kernel<false, 8>);
+                if (most > 4 * NBRW_THREADS && nw.compact) e = nw.ortho ? launch(lists_frame_kernel<true, 8, true>) : launch(lists_frame_kernel<false, 8, true>);
+                else if (most > 4 * NBRW_THREADS) e = nw.ortho ? launch(lists_frame_kernel<true, 8, false>) : launch(lists_frame_kernel<false, 8, false>);
+                else if (nw.compact) e = nw.ortho ? launch(lists_frame_kernel<true, 4, true>) : launch(lists_frame_kernel<false, 4, true>);
+                else e = nw.ortho ? launch(lists_frame_kernel<true, 4, false>) : launch(lists_frame_kernel<false, 4, false>);
                 AMOF_HIP_TRY(ctx, e);
                 AMOF_HIP_TRY(ctx, hipGetLastError());
                 if (!merged.empty()) {
