@@ -566,7 +566,7 @@ struct FrameArgs {
 
 struct FrameLds {
     unsigned char *rec;        // [atoms of the item] sorted records (uint4, COMPACT: uint2): species slot 0 first (cells x fastest), then slot 1
-    uint32_t *cell_end;        // [slots * ncell] end of every cell (its start = the entry before it; 0 for the first)
+    uint32_t *cell_end;        // [ncell] end of every cell of the sorted species (its start = the entry before it)
     uint2 *sidx;               // COMPACT: this workgroup's piece of FrameArgs::sidx
 };
 
@@ -594,7 +594,9 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nx = it.nx, ny = it.ny, nz = it.nz, ncell = nx * ny * nz;
-    const int n = nA + nB, ntab = (nB > 0 ? 2 : 1) * ncell;
+    // two species: the centres (slot 0) keep their order in positions [0, nA) -- nobody looks them up by cell -- and only the
+    // partners are counting-sorted behind them, so the whole table budget buys cells for ONE species
+    const int n = nA + nB, ntab = ncell;
     const double *__restrict__ g = a.geom + (size_t)(a.n_cells == 1 ? 0 : f) * GEOM_STRIDE;
     const int64_t segA = fr.sp_first[it.sa], segB = fr.sp_first[it.sb];
     int32_t atom[PT];
@@ -628,10 +630,8 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
         }
         const bool second = k >= nA;
         rec[i] = make_uint4(u[0], u[1], u[2], (uint32_t)atom[i] | (second ? NBRW_SLOT1 : 0u));
-        key[i] = (second ? (uint32_t)ncell : 0u) +
-                 (__umulhi(u[2], (unsigned)nz) * (unsigned)ny + __umulhi(u[1], (unsigned)ny)) * (unsigned)nx +
-                 __umulhi(u[0], (unsigned)nx);
-        if (k < n) atomicAdd(&L.cell_end[key[i]], 1u);
+        key[i] = (__umulhi(u[2], (unsigned)nz) * (unsigned)ny + __umulhi(u[1], (unsigned)ny)) * (unsigned)nx + __umulhi(u[0], (unsigned)nx);
+        if (k < n && (second || nB == 0)) atomicAdd(&L.cell_end[key[i]], 1u);
     }
     __syncthreads();
     // exclusive scan of the counters, in place: one contiguous chunk per thread, chunk totals scanned by waves
@@ -646,7 +646,7 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    unsigned run = incl - sum;
+    unsigned run = incl - sum + (nB > 0 ? (unsigned)nA : 0u);      // (sorted positions start behind the centres)
     for (int q = 0; q < wave; q++) run += wsum[q];
     for (int c = c0; c < c1; c++) {
         const unsigned v = L.cell_end[c];
@@ -658,7 +658,7 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
     for (int i = 0; i < PT; i++) {
         const int k = tid + i * NBRW_THREADS;
         if (k < n) {
-            const unsigned slot = atomicAdd(&L.cell_end[key[i]], 1u);
+            const unsigned slot = (k >= nA || nB == 0) ? atomicAdd(&L.cell_end[key[i]], 1u) : (unsigned)k;
             if (COMPACT) {
                 reinterpret_cast<uint2 *>(L.rec)[slot] = make_uint2((rec[i].x >> 16) | rec[i].y, rec[i].z >> 16);
                 L.sidx[slot] = make_uint2(rec[i].w & ~NBRW_SLOT1, (uint32_t)(k >= nA ? k - nA : k));
@@ -677,7 +677,7 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
 // for EVERY candidate by all lanes still in the loop, so that a caller may aggregate over the wave.
 // c = the centre's own sorted position; one_species: partners and centres are the same atoms (the zero-shift self pair is skipped).
 template <bool ORTHO, bool COMPACT, typename F>
-__device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const FrameItem &it, const FrameLds &L, int slot,
+__device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const FrameItem &it, const FrameLds &L, int first,
                                                      const float *sc, const double *__restrict__ geo,
                                                      const double *__restrict__ p, int c, bool one_species, const uint4 qc, int r9, double rc,
                                                      F &&visit)
@@ -691,14 +691,14 @@ __device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const 
     int cz2 = cz + dz, cy2 = cy + dy;
     cz2 += cz2 < 0 ? nz : 0; cz2 -= cz2 >= nz ? nz : 0;
     cy2 += cy2 < 0 ? ny : 0; cy2 -= cy2 >= ny ? ny : 0;
-    const int row = slot * nx * ny * nz + (cz2 * ny + cy2) * nx;
+    const int row = (cz2 * ny + cy2) * nx;          // (first = sorted position of the first partner: the start of cell 0)
     // cells xa .. xb of the row, plus the wrapped piece (nx >= 3: three distinct cells)
     int xa = cx - 1, xb = cx + 1, wa = 0, wb = -1;
     if (xa < 0) { xa = 0; wa = nx - 1; wb = nx - 1; }
     else if (xb >= nx) { xb = nx - 1; wa = 0; wb = 0; }
-    const int lo0 = row + xa > 0 ? (int)L.cell_end[row + xa - 1] : 0, hi0 = (int)L.cell_end[row + xb];
+    const int lo0 = row + xa > 0 ? (int)L.cell_end[row + xa - 1] : first, hi0 = (int)L.cell_end[row + xb];
     int lo1 = 0, hi1 = 0;
-    if (wa <= wb) { lo1 = row + wa > 0 ? (int)L.cell_end[row + wa - 1] : 0; hi1 = (int)L.cell_end[row + wb]; }
+    if (wa <= wb) { lo1 = row + wa > 0 ? (int)L.cell_end[row + wa - 1] : first; hi1 = (int)L.cell_end[row + wb]; }
     const int len0 = hi0 - lo0, total = len0 + hi1 - lo1;
     for (int q = 0; q < total; q++) {
         const int j = q < len0 ? lo0 + q : lo1 + (q - len0);
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void c
         const int c = t / 9, r9 = t - 9 * c;
         const uint4 qc = frame_rec<COMPACT>(L, c);
         int cnt = 0;
-        frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, c, nB == 0, qc, r9, rc,
+        frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, nB > 0 ? nA : 0, sc, geo, p, c, nB == 0, qc, r9, rc,
                                              [&](bool nbr, int) { cnt += nbr ? 1 : 0; });
         if (pa && cnt) atomicAdd(&pa[frame_atom<COMPACT>(L, c, qc)], cnt);
         sum += (unsigned long long)cnt;
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
     L.rec = lds_raw;
     L.cell_end = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(nA + nB) * (COMPACT ? sizeof(uint2) : sizeof(uint4)));
     L.sidx = COMPACT ? fr.sidx + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)fr.sidx_stride : nullptr;
-    const int n = nA + nB, ntab = (nB > 0 ? 2 : 1) * it.nx * it.ny * it.nz;
+    const int n = nA + nB, ntab = it.nx * it.ny * it.nz;
     // neighbours found so far, one BYTE per atom (sorted position), four to a word: a lane claims a slot with
     // atomicAdd(word, 1 << 8 * (c & 3)) (an atom past 16 fails the call anyway, so a carry into the next byte is harmless)
     uint32_t *cnt = L.cell_end + ntab;
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
         const int t = t0 + tid;
         if (t < tasks) {
             const int c = t / 9, r9 = t - 9 * c;
-            frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, nB > 0 ? 1 : 0, sc, geo, p, c, nB == 0, frame_rec<COMPACT>(L, c), r9, rc,
+            frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, nB > 0 ? nA : 0, sc, geo, p, c, nB == 0, frame_rec<COMPACT>(L, c), r9, rc,
                                                  [&](bool nbr, int j) {
                 // one LDS atomic per wave and trip, not one per pair (they would all hit the same word)
                 const unsigned long long m = __ballot(nbr);
@@ -1875,7 +1875,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
                 if (!(cutoff[A * S + B] > 0.0) || nA == 0 || nB == 0) { nw.ok = !per_atom; continue; }
                 FrameItem it{};
                 it.sa = A; it.sb = B; it.set = s2; it.reg_ab = it.reg_ba = -1;
-                nw.ok = frame_item_grid(hmin, cutoff[A * S + B], A == B ? nA : nA + nB, A == B ? 1 : 2, std::max(nA, nB), it, nw.lds,
+                nw.ok = frame_item_grid(hmin, cutoff[A * S + B], A == B ? nA : nA + nB, 1, nB, it, nw.lds,
                                         nw.compact ? sizeof(uint2) : sizeof(uint4));
                 if (nw.ok) nw.items.push_back(it);
                 biggest = std::max(biggest, A == B ? nA : nA + nB);
@@ -2099,7 +2099,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                     it.reg_ba = x == y ? -1 : region_of[(size_t)it.sb * S + it.sa];
                     const int64_t n = st.tiles.nsp[x] + (x == y ? 0 : st.tiles.nsp[y]);
                     size_t lds_it = 0;
-                    nw.ok = frame_item_grid(hmin, cutoff[x * S + y], n, x == y ? 1 : 2, std::max(st.tiles.nsp[x], st.tiles.nsp[y]), it, lds_it,
+                    nw.ok = frame_item_grid(hmin, cutoff[x * S + y], n, 1, st.tiles.nsp[it.sb], it, lds_it,
                                             nw.compact ? sizeof(uint2) : sizeof(uint4),
                                             (size_t)((n + 3) / 4) * 4 + (size_t)NBRW_HITS * sizeof(uint32_t));
                     nw.lds = std::max(nw.lds, lds_it);
