@@ -1735,8 +1735,9 @@ static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slot
     if (rec_bytes + (size_t)slots * 4 * std::min<int64_t>(densest / 4 + 27, 1024) > budget) budget = 152 * 1024;
     if (rec_bytes + (size_t)slots * 4 * 27 > budget) return false;
     const int64_t cells_budget = (int64_t)((budget - rec_bytes) / ((size_t)slots * 4));
-    // no point in cells emptier than ~1 atom of the denser species
-    const int64_t want = std::max<int64_t>(27, std::min<int64_t>(cells_budget, densest));
+    // as fine as the budget allows (the cutoff bounds it from the other side): a centre walks 27 cells whatever their size,
+    // so emptier cells are fewer candidates, and clearing + scanning 8k counters costs a thousand lanes eight steps
+    const int64_t want = std::max<int64_t>(27, std::min<int64_t>(cells_budget, std::max<int64_t>(4 * densest, 4096)));
     while ((int64_t)nk[0] * nk[1] * nk[2] > want) {
         int big = 0;
         for (int x = 1; x < 3; x++)
