@@ -20,7 +20,7 @@ for _ in range(2):
 F, N = nf.value, na.value
 pos = np.zeros((F, N, 3)); sym = np.zeros((N, 4), np.uint8); lat = np.zeros((F, 9)); has = ctypes.c_int32(0)
 lib.amof_xyz_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
-for th in (1, 1, 2, 4, 8, 16, 16):
+for th in (1, 4, 8, 16, 16, 24, 32, 48, 64, 64, 16):
     t0 = time.perf_counter()
     rc = lib.amof_xyz_read(bp, 0, F, 1, N, pos.ctypes.data, sym.ctypes.data, lat.ctypes.data, ctypes.addressof(has), th)
     t1 = time.perf_counter()
