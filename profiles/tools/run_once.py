@@ -28,7 +28,7 @@ if what == "cfg4":
         ctx.rdf_accumulate(packed, 10.0, 999)
     print(ctx.last_path(), ctx.last_kernel_seconds(True))
     sys.exit(0)
-packed = H.device_walk(dev, (3, 3, 4), F, 0.05, 20261003)
+packed = H.device_walk(dev, (3, 3, 4), F, float(os.environ.get("RUN_ONCE_SIGMA", "0.05")), 20261003)   # 0.002: the framework stays intact
 torch.cuda.synchronize()
 kinds, sp = H.species_of(packed.numbers)
 if what == "msd":
