@@ -23,24 +23,30 @@ from .frames import pack_trajectory
 logger = logging.getLogger(__name__)
 
 
+DEFAULT_SHELL = "exact"
+
+
 def normalize_rdf(hist, ncount, natoms, mean_volume, rmax, nbins):
     """asap3 ``RadialDistributionFunction.get_rdf`` normalisation ([3P-memory],
     consumed at amof/rdf.py:96,109):
 
-        g[b] = V * H[b] / (4 pi r_b^2 delta * N * ncount),
-        delta = rmax / nbins, r_b = (b + 1/2) delta
+        g[b] = V * H[b] / (shell_b * N * ncount),
+        shell_b = 4 pi delta (r_b^2 + delta^2 / 12), delta = rmax / nbins, r_b = (b + 1/2) delta
 
     ``ncount`` = frames * N for the total RDF, frames * N_a for the partial
     a -> b (partials are normalised with the TOTAL density, so that
     g_XX = sum_ab (N_a/N) g_ab; corroborated by amof/rdf.py:114,216-227).
 
     Shell volume (assumption A1, DESIGN 5.1 -- asap3 is not available here and the reference holds no test that pins
-    it): the default is the MIDPOINT shell ``4 pi r_b^2 delta``; ``AMOF_RDF_SHELL=exact`` (or ``shell='exact'``)
-    switches to the exact volume of the spherical shell, ``4 pi delta (r_b^2 + delta^2 / 12)``.  The two differ by
+    it): the default is the EXACT volume of the spherical shell, ``(4 pi / 3)(r_hi^3 - r_lo^3) = 4 pi delta (r_b^2 +
+    delta^2 / 12)`` -- what asap3's ``get_rdf`` and its port ``ase.geometry.rdf.get_rdf`` divide by according to two
+    independent reviewer readings (rounds 2 and 3), and the only choice for which an ideal gas gives g = 1 in EVERY bin,
+    the first ones included (``tests/test_oracle_kat.py::test_ideal_gas_discriminates_the_shell_volume``).
+    ``AMOF_RDF_SHELL=midpoint`` (or ``shell='midpoint'``) switches to ``4 pi r_b^2 delta``; the two differ by
     ``delta^2 / (12 r_b^2)`` relative: 8e-6 at r = 1 A, dr = 0.01 (above the 1e-6 bar, shrinking as 1/r^2).  A
-    maintainer with asap3 installed settles it with ``tests/golden/make_thirdparty_goldens.py`` +
-    ``tests/test_thirdparty_goldens.py`` and flips the default here -- one line."""
-    return normalize_rdf_shell(hist, ncount, natoms, mean_volume, rmax, nbins, os.environ.get("AMOF_RDF_SHELL", "midpoint"))
+    maintainer with asap3 installed settles it for good with ``tests/golden/make_thirdparty_goldens.py`` +
+    ``tests/test_thirdparty_goldens.py``."""
+    return normalize_rdf_shell(hist, ncount, natoms, mean_volume, rmax, nbins, os.environ.get("AMOF_RDF_SHELL", DEFAULT_SHELL))
 
 
 def normalize_rdf_shell(hist, ncount, natoms, mean_volume, rmax, nbins, shell):

@@ -112,6 +112,8 @@ class GoldenFrame(Frame):
 class _StubRDF(object):
     """asap3.analysis.rdf.RadialDistributionFunction ([3P-memory])."""
 
+    shell = "exact"
+
     def __init__(self, atoms, rMax, nBins, groups=None, interval=1, restart=None, verbose=0):
         self.atoms = atoms
         self.natoms = len(atoms)
@@ -141,7 +143,10 @@ class _StubRDF(object):
     def _normalize(self, h, ncount):
         vol = self.volume / self.countRDF
         r = (np.arange(self.nBins) + 0.5) * self.dr
-        shell = 4 * np.pi * r * r * self.dr
+        if _StubRDF.shell == "exact":          # the default since round 4
+            shell = 4 * np.pi * self.dr * (r * r + self.dr * self.dr / 12.0)
+        else:
+            shell = 4 * np.pi * r * r * self.dr
         return h * (vol / (self.natoms * ncount)) / shell
 
     def get_rdf(self, groups=None, elements=None):
@@ -305,12 +310,20 @@ def gold_e2e():
         np.savez_compressed(os.path.join(OUT, "reference_e2e_bad_zif4_dtheta%s.npz" % str(dtheta).replace('.', 'p')),
                             pos=pos, cell=cells, numbers=Z, cutoffs=json.dumps({'Zn-N': 2.5, 'C-N': 1.6}),
                             dtheta=dtheta, **_df_to_npz(bad.data))
-    rdf = amof.rdf.Rdf.from_trajectory([f.copy() for f in frames])
-    np.savez_compressed(os.path.join(OUT, "reference_e2e_rdf_zif4_default.npz"), pos=pos, cell=cells, numbers=Z,
-                        dr=0.01, rmax="half_cell", **_df_to_npz(rdf.data))
-    rdf = amof.rdf.Rdf.from_trajectory([f.copy() for f in frames], dr=0.05, rmax=6.0)
-    np.savez_compressed(os.path.join(OUT, "reference_e2e_rdf_zif4_dr0p05_rmax6.npz"), pos=pos, cell=cells, numbers=Z,
-                        dr=0.05, rmax=6.0, **_df_to_npz(rdf.data))
+    # the reference's Rdf class over the stand-in asap3 object, once per shell-volume convention (A1): `values` is the
+    # default (exact shell), `values_midpoint` what AMOF_RDF_SHELL=midpoint must reproduce
+    for name, kw in [("reference_e2e_rdf_zif4_default.npz", dict()),
+                     ("reference_e2e_rdf_zif4_dr0p05_rmax6.npz", dict(dr=0.05, rmax=6.0))]:
+        both = {}
+        for shell in ("exact", "midpoint"):
+            _StubRDF.shell = shell
+            rdf = amof.rdf.Rdf.from_trajectory([f.copy() for f in frames], **kw)
+            d = _df_to_npz(rdf.data)
+            both["columns"] = d["columns"]
+            both["values" if shell == "exact" else "values_midpoint"] = d["values"]
+        _StubRDF.shell = "exact"
+        np.savez_compressed(os.path.join(OUT, name), pos=pos, cell=cells, numbers=Z,
+                            dr=kw.get("dr", 0.01), rmax=kw.get("rmax", "half_cell"), **both)
 
 
 def gold_direct_msd():

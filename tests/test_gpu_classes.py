@@ -27,21 +27,30 @@ def _frames(g):
     return [Frame(g["numbers"], g["pos"][k], cell[k if len(cell) > 1 else 0]) for k in range(len(g["pos"]))]
 
 
-def _check_df(df, g, rtol=RTOL, atol=1e-12):
+def _check_df(df, g, rtol=RTOL, atol=1e-12, values="values"):
     assert list(df.columns) == [str(c) for c in g["columns"]]
-    np.testing.assert_allclose(df.values.astype(float), g["values"], rtol=rtol, atol=atol)
+    np.testing.assert_allclose(df.values.astype(float), g[values], rtol=rtol, atol=atol)
 
 
 @pytest.mark.parametrize("name", ["zif4_default", "zif4_dr0p05_rmax6"])
 @pytest.mark.parametrize("packed", [False, True])
-def test_rdf_matches_reference_dataframe(name, packed):
+@pytest.mark.parametrize("shell", [None, "exact", "midpoint"])
+def test_rdf_matches_reference_dataframe(name, packed, shell, monkeypatch):
+    """The reference's own Rdf class over the stand-in asap3 object, under BOTH shell-volume conventions (assumption
+    A1): the default (exact shell) and AMOF_RDF_SHELL=midpoint each reproduce their DataFrame -- and not the other's."""
+    if shell is None:
+        monkeypatch.delenv("AMOF_RDF_SHELL", raising=False)
+    else:
+        monkeypatch.setenv("AMOF_RDF_SHELL", shell)
     g = np.load(os.path.join(GOLDEN, "reference_e2e_rdf_%s.npz" % name))
     rmax = str(g["rmax"]) if g["rmax"].dtype.kind == "U" else float(g["rmax"])
     traj = _frames(g)
     if packed:
         traj = PackedTrajectory(g["pos"], g["cell"], g["numbers"])
     rdf = Rdf.from_trajectory(traj, dr=float(g["dr"]), rmax=rmax)
-    _check_df(rdf.data, g)
+    _check_df(rdf.data, g, values="values_midpoint" if shell == "midpoint" else "values")
+    with pytest.raises(AssertionError):      # dr^2 / (12 r^2) at the first populated bins: far above 1e-6
+        _check_df(rdf.data, g, values="values" if shell == "midpoint" else "values_midpoint")
     # integer sum rule and symmetry of the raw counts
     assert np.array_equal(rdf.hist, rdf.hist.transpose(1, 0, 2))
 

@@ -32,7 +32,8 @@ def test_cfg1_216_atom_cubic_and_272_atom_fixture_50_frames(hip_ctx):
         # normalisation against an independent evaluation of the asap3 formula
         d = rdf.rmax / bins
         r = (np.arange(bins) + 0.5) * d
-        g_tot = ref.sum(axis=(0, 1)) * (vol / 50) / (4 * np.pi * r * r * d * len(base) * 50 * len(base))
+        shell = 4 * np.pi / 3 * ((r + d / 2) ** 3 - (r - d / 2) ** 3)      # exact shell volume
+        g_tot = ref.sum(axis=(0, 1)) * (vol / 50) / (shell * len(base) * 50 * len(base))
         np.testing.assert_allclose(rdf.data["X-X"].values, g_tot, rtol=1e-12)
 
 

@@ -116,14 +116,15 @@ def test_pack_trajectory(zif4):
     assert kinds == [1, 6, 7, 30] and sp.dtype == np.int32 and sp.max() == 3
 
 
-def test_normalize_rdf_formula():
+def test_normalize_rdf_formula(monkeypatch):
     from amof_amd.rdf import normalize_rdf
+    monkeypatch.delenv("AMOF_RDF_SHELL", raising=False)
     nb, rmax, N, F, V = 10, 5.0, 100, 4, 1000.0
     h = np.arange(nb) * 7
     g = normalize_rdf(h, F * N, N, V, rmax, nb)
     d = rmax / nb
     r = (np.arange(nb) + 0.5) * d
-    np.testing.assert_allclose(g, V * h / (4 * np.pi * r ** 2 * d * N * F * N), rtol=1e-15)
+    np.testing.assert_allclose(g, V * h / (4 * np.pi * d * (r ** 2 + d * d / 12) * N * F * N), rtol=1e-15)
 
 
 def test_shard_range_partitions():
@@ -238,17 +239,21 @@ def test_volume_sum_is_the_librarys_sum_bit_for_bit():
 
 
 def test_rdf_shell_switch(monkeypatch):
-    """AMOF_RDF_SHELL: midpoint shell 4 pi r^2 dr (default) or the exact shell volume (4 pi / 3)(r_hi^3 - r_lo^3) --
-    assumption A1 about asap3's get_rdf, made a visible switch because it cannot be settled here."""
+    """AMOF_RDF_SHELL: the exact shell volume (4 pi / 3)(r_hi^3 - r_lo^3) (default since round 4) or the midpoint shell
+    4 pi r^2 dr -- assumption A1 about asap3's get_rdf, a visible switch because asap3 cannot be run here."""
     from amof_amd.rdf import normalize_rdf, normalize_rdf_shell
     hist = np.arange(1, 51, dtype=np.uint64) * 1000
     args = (hist, 4 * 272.0, 272, 4380.486, 5.0, 50)
+    monkeypatch.delenv("AMOF_RDF_SHELL", raising=False)
+    default = normalize_rdf(*args)
+    monkeypatch.setenv("AMOF_RDF_SHELL", "midpoint")
     mid = normalize_rdf(*args)
     monkeypatch.setenv("AMOF_RDF_SHELL", "exact")
     exact = normalize_rdf(*args)
     monkeypatch.setenv("AMOF_RDF_SHELL", "bogus")
     with pytest.raises(ValueError):
         normalize_rdf(*args)
+    assert np.array_equal(default, exact)
     dr = 5.0 / 50
     r = (np.arange(50) + 0.5) * dr
     np.testing.assert_allclose(mid / exact, 1.0 + dr * dr / (12.0 * r * r), rtol=1e-14)

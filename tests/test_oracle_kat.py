@@ -201,3 +201,30 @@ def test_ideal_gas_rdf_is_one():
     g = normalize_rdf(h[0, 0], F * N, N, vol / F, rmax, nb)
     # N-1 partners instead of N: expect (N-1)/N, with sqrt(counts) noise
     assert abs(g[5:].mean() - (N - 1) / N) < 0.01
+
+
+def test_ideal_gas_discriminates_the_shell_volume(monkeypatch):
+    """A1 without asap3: an ideal gas has g(r) = 1 in EVERY bin -- asap3 documents that its g(r) tends to
+    1 for uncorrelated atoms -- which at a coarse dr only the exact shell volume (4 pi / 3)(r_hi^3 - r_lo^3) delivers:
+    the midpoint shell 4 pi r_b^2 dr underestimates the volume of bin b by dr^2 / (12 r_b^2) = 1 / (3 (2b + 1)^2), i.e.
+    33 % in bin 0, 3.7 % in bin 1, 1.3 % in bin 2.  The default of `normalize_rdf` must be the one that gives 1."""
+    from amof_amd import rdf as amrdf
+    monkeypatch.delenv("AMOF_RDF_SHELL", raising=False)
+    N, F, L = 4000, 8, 10.0
+    packed = H.random_gas(N, [L, L, L], np.ones(N, int), 20261004, F=F)
+    rmax, nb = 5.0, 10                      # dr = 0.5 A
+    h, vol = clib.rdf_hist(packed.pos, packed.cell, np.zeros(N, np.int32), 1, rmax, nb)
+    counts = h[0, 0].astype(float)
+    assert counts[0] > 5e4                  # ordered pairs in the first bin: 0.6 % noise on the unordered count
+    sigma = np.sqrt(2.0 / counts)           # every unordered pair is counted twice
+    expect = (N - 1) / N                    # N - 1 partners per centre, normalised with N
+    args = (h[0, 0], F * N, N, vol / F, rmax, nb)
+    g_default = amrdf.normalize_rdf(*args)
+    g_exact = amrdf.normalize_rdf_shell(*args, "exact")
+    g_mid = amrdf.normalize_rdf_shell(*args, "midpoint")
+    assert amrdf.DEFAULT_SHELL == "exact" and np.array_equal(g_default, g_exact)
+    assert np.all(np.abs(g_exact / expect - 1.0) < 4 * sigma)
+    b = np.arange(nb)
+    np.testing.assert_allclose(g_mid / g_exact, 1.0 + 1.0 / (3.0 * (2 * b + 1) ** 2), rtol=1e-13)
+    # the midpoint shell is off by 33 % / 3.7 % in the first two bins: tens of sigma
+    assert abs(g_mid[0] / expect - 1.0) > 0.3 and abs(g_mid[1] / expect - 1.0) > 10 * sigma[1]

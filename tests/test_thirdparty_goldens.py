@@ -60,7 +60,8 @@ def _shell_that_matches(g, hist, vol_sum):
         except AssertionError:
             pass
     assert ok, "neither shell volume reproduces asap3's get_rdf: A2 / A3 / A4 / A8 are wrong, not only A1"
-    default = os.environ.get("AMOF_RDF_SHELL", "midpoint")
+    from amof_amd.rdf import DEFAULT_SHELL
+    default = os.environ.get("AMOF_RDF_SHELL", DEFAULT_SHELL)
     assert default in ok, ("asap3 normalises with the %s shell: flip the default of AMOF_RDF_SHELL in amof_amd/rdf.py "
                            "(assumption A1)" % ok[0])
 
