@@ -157,7 +157,11 @@ class _TrajHandle(object):
     """Keeps the numpy buffers behind an ``AmofTraj`` alive."""
 
     def __init__(self, packed, frame_range=None):
-        assert isinstance(packed, PackedTrajectory)
+        if getattr(packed, "is_stream", False):
+            raise TypeError("this analysis does not walk a stream batch by batch: pass stream.read_all() (Rdf, "
+                            "cn.CoordinationNumber and Bad accept the stream itself)")
+        if not isinstance(packed, PackedTrajectory):
+            raise TypeError("expected a PackedTrajectory, got %s" % type(packed).__name__)
         f0, f1 = (0, packed.n_frames) if frame_range is None else frame_range
         self.kinds, self.species = packed_species(packed)
         pos = getattr(packed, "_dev_pos", None)        # (PackedTrajectory.keep_on_device: resident copy of a host array)

@@ -159,6 +159,24 @@ class Bad(CoreBad):
         self.data = pd.read_feather(path_to_data)
 
 
+def _largest_neighbour_count(ctx, packed, rcm, frame_range, batch_bytes=256 << 20):
+    """largest number of neighbours (over every species with a cutoff to the centre's) of any atom in any frame of the
+    range: the per-atom output of the CN kernels, in frame batches of bounded size.  An upper bound of the coordination
+    number any B-A-B / X-A-X triple can see, exact for the X triples."""
+    S = rcm.shape[0]
+    sets = [(a, b) for a in range(S) for b in range(S) if rcm[a, b] > 0]
+    if not sets:
+        return 0
+    f0, f1 = frame_range
+    step = max(1, int(batch_bytes // max(1, 4 * len(sets) * packed.n_atoms)))
+    largest = 0
+    for k in range(f0, f1, step):
+        _, pa = ctx.cn_count(packed, rcm, sets, frame_range=(k, min(k + step, f1)), per_atom=True)
+        # an atom's row is -1 in the sets whose centre species is not its own: count those as zero
+        largest = max(largest, int(np.maximum(pa, 0).sum(axis=1).max()))
+    return largest
+
+
 class BadByCn(CoreBad):
     """
     Bond-angle distributions split by coordination number (mirror of reference
@@ -184,6 +202,8 @@ class BadByCn(CoreBad):
                     device=None, distributed=None):
         """compute bond-angle distributions by cn (reference amof/bad.py:240-301)"""
         packed = pack_trajectory(trajectory)
+        if getattr(packed, "is_stream", False):
+            packed = packed.read_all()      # (this analysis does not add up batch by batch)
         atomic_numbers_unique = packed.unique_numbers()
         cutoff_dict = amatom.format_cutoff(nb_set_and_cutoff)
         elements_present_unique = list(set([_data.atomic_numbers[i] for nb_set in nb_set_and_cutoff.keys()
@@ -213,21 +233,30 @@ class BadByCn(CoreBad):
         frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
         dev = device if device is not None else getattr(packed, "device_index", None)
         ctx = _hip.get_context(dev)
-        # the last slot (cn_max) also collects every larger neighbour count: when it is populated, count again with
-        # more slots -- the reference has no limit on the coordination number (amof/bad.py:190-224)
+        # the last slot (cn_max) also collects every larger neighbour count -- the reference has no limit on the
+        # coordination number (amof/bad.py:190-224).  When it is populated the slots are sized ONCE from a count pass (the
+        # CN kernels' per-atom output: the largest number of neighbours any centre has in any frame) and the histogram is
+        # taken a second and last time; rounds 2 - 3 grew the slots x4 per retry, each a whole pass and an all-reduce.
         cn_max = self.CN_MAX
+        self.passes = 0
         while True:
             if triples:
                 hist, nang = ctx.bad_hist_by_cn(packed, rcm, triples, theta_bins, cn_max=cn_max, frame_range=frame_range)
             else:
                 hist = np.zeros((0, cn_max + 1, bins + 1), dtype=np.uint64)
                 nang = np.zeros((0, cn_max + 1), dtype=np.uint64)
+            self.passes += 1
             full = float(nang[:, cn_max].any()) if nang.size else 0.0
             if merge:
                 full = _dist.all_reduce_sum(np.array([full]), device=ctx.device)[0]     # every rank must take the same decision
             if not full:
                 break
-            cn_max *= 4
+            if self.passes > 1:
+                raise RuntimeError("BadByCn: a centre has more neighbours than the count pass found (%d)" % (cn_max - 1))
+            largest = _largest_neighbour_count(ctx, packed, rcm, frame_range)
+            if merge:
+                largest = -int(_dist.all_reduce_min(-float(largest), device=ctx.device))
+            cn_max = max(cn_max + 1, int(largest) + 1)          # slot cn_max stays empty: it is the overflow slot
         if merge:
             hist = _dist.all_reduce_sum(hist, device=ctx.device)
             nang = _dist.all_reduce_sum(nang, device=ctx.device)

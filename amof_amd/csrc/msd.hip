@@ -1138,22 +1138,20 @@ extern "C" int amof_msd_com_dev(amof_ctx *ctx, const amof_traj *t, int64_t frame
     for (int64_t i = 0; i < N; i++) total_mass += t->masses[i];
     AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
     timing_begin(ctx);
-    const double *pos_dev = nullptr;
+    const double *range_dev = nullptr;      // first frame OF THE RANGE on the device
     if (t->pos_on_device) {
-        pos_dev = t->pos;
+        range_dev = t->pos + (size_t)frame_begin * (size_t)N * 3;
     } else {        // host input: only the frames of the range travel
         amof_traj sub = *t;
         sub.pos = t->pos + (size_t)frame_begin * (size_t)N * 3;
         sub.n_frames = frame_end - frame_begin;
-        AMOF_TRY(stage_positions(ctx, &sub, &pos_dev));
-        pos_dev -= (size_t)frame_begin * (size_t)N * 3;
+        AMOF_TRY(stage_positions(ctx, &sub, &range_dev));
     }
     void *d_mass;
     AMOF_TRY(upload(ctx, SLOT_AUX1, t->masses, (size_t)N * sizeof(double), &d_mass));
     timing_dom_begin(ctx, "msd_com");
     hipLaunchKernelGGL(com_kernel, dim3((unsigned)(frame_end - frame_begin)), dim3(MSD_THREADS), 0, ctx->stream,
-                       pos_dev + (size_t)frame_begin * (size_t)N * 3, (const double *)d_mass, N, total_mass,
-                       com_dev + 3 * frame_begin);
+                       range_dev, (const double *)d_mass, N, total_mass, com_dev + 3 * frame_begin);
     timing_dom_end(ctx, 1);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_end(ctx);

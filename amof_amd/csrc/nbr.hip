@@ -1747,8 +1747,13 @@ static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slot
 {
     if (n > NBRW_MAX_ATOMS || n <= 0) return false;
     int nk[3];
+    // A centre only looks at the 27 cells around its own, so a cell must be at least rc thick IN THE COORDINATES THE CELL KEYS
+    // ARE TAKEN FROM.  16-byte records key the 32-bit fixed point (2^-32 of a cell vector: inside the 1e-5 margin); COMPACT
+    // 8-byte records key the coordinate TRUNCATED to 16 bits, which moves a centre against its partner by up to 2^-16 of the
+    // cell vector -- far more than 1e-5 * rc / h -- so their cells are 2^-15 (twice that, in fractions of the axis) thicker.
+    const double trunc = rec_size < sizeof(uint4) ? 1.0 / 32768.0 : 0.0;
     for (int x = 0; x < 3; x++) {
-        nk[x] = (int)std::min(1024.0, floor(hmin[x] / (rc * (1.0 + 1e-5))));
+        nk[x] = (int)std::min(1024.0, floor(1.0 / (rc * (1.0 + 1e-5) / hmin[x] + trunc)));
         if (nk[x] < 3) return false;
     }
     const size_t rec_bytes = (size_t)n * rec_size + extra_bytes;           // (+ whatever else the kernel keeps per atom)
@@ -1771,6 +1776,22 @@ static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slot
     it.nx = nk[0]; it.ny = nk[1]; it.nz = nk[2];
     lds = std::max(lds, rec_bytes + (size_t)slots * 4 * (size_t)nk[0] * nk[1] * nk[2]);
     return true;
+}
+
+// Record size of the tier, three passes: 0 = 16-byte records, 1 = COMPACT 8-byte ones, 2 = 16-byte again.  AMOF_NBR_COMPACT=1
+// starts at (and keeps) the compact pass -- tests of the 16-bit cell keys; =0 never leaves pass 0.
+static int frame_first_pass()
+{
+    const char *e = getenv("AMOF_NBR_COMPACT");
+    return e && e[0] == '1' ? 1 : 0;
+}
+static bool frame_pass_done(int pass, bool ok, size_t lds, bool ok16)
+{
+    const char *e = getenv("AMOF_NBR_COMPACT");
+    if (e && (e[0] == '1' || e[0] == '0')) return true;     // forced: whatever this pass gave
+    if (ok && lds <= 76 * 1024) return true;                // two workgroups per CU: nothing to gain
+    if (pass == 1 && ok && !ok16) return true;              // only the compact records fit at all: keep them (pass 2 would fail again)
+    return pass == 2;
 }
 
 // host-side constants of the tier (nothing is uploaded before nbr_frame_commit); ok stays false when the tier cannot take the call
@@ -1887,9 +1908,10 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         double hmin[3];
         AMOF_TRY(nbr_frame_prepare(t, cutoff, st, nw, hmin));
         const bool tier_ok = nw.ok;
-        for (int pass = 0; pass < 3 && tier_ok; pass++) {
+        bool ok16 = false;
+        for (int pass = frame_first_pass(); pass < 3 && tier_ok; pass++) {
             // 16-byte records first; if a pair then needs a whole CU's LDS, everything again with the 8-byte ones; if that
-            // does not bring two workgroups per CU either, the 16-byte ones stay
+            // does not bring two workgroups per CU either, the 16-byte ones stay -- unless they did not fit at all
             nw.ok = true; nw.items.clear(); nw.lds = 0; nw.compact = pass == 1;
             int64_t biggest = 0;
             for (int s2 = 0; s2 < n_sets && nw.ok; s2++) {
@@ -1903,7 +1925,8 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
                 if (nw.ok) nw.items.push_back(it);
                 biggest = std::max(biggest, A == B ? nA : nA + nB);
             }
-            if ((nw.ok && nw.lds <= 76 * 1024) || pass == 2) break;
+            if (pass == 0) ok16 = nw.ok;
+            if (frame_pass_done(pass, nw.ok, nw.lds, ok16)) break;
         }
         if (nw.ok && !nw.items.empty()) {
             AMOF_TRY(nbr_frame_commit(ctx, nw));
@@ -2107,9 +2130,10 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             if (needed[(size_t)x]) { region_of[(size_t)x] = (int32_t)R; R += st.tiles.nsp[(size_t)(x / S)]; }
         int64_t most = 0;
         const bool tier_ok = nw.ok;
-        for (int pass = 0; pass < 3 && tier_ok; pass++) {
+        bool ok16 = false;
+        for (int pass = frame_first_pass(); pass < 3 && tier_ok; pass++) {
             // 16-byte records first; if a pair then needs a whole CU's LDS, everything again with the 8-byte ones; if that
-            // does not bring two workgroups per CU either, the 16-byte ones stay
+            // does not bring two workgroups per CU either, the 16-byte ones stay -- unless they did not fit at all
             nw.ok = true; nw.items.clear(); nw.lds = 0; nw.compact = pass == 1; most = 0;
             for (int x = 0; x < S && nw.ok; x++)
                 for (int y = x; y < S && nw.ok; y++) {
@@ -2129,7 +2153,8 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                     most = std::max(most, n);
                     if (nw.ok) nw.items.push_back(it);
                 }
-            if ((nw.ok && nw.lds <= 76 * 1024) || pass == 2) break;
+            if (pass == 0) ok16 = nw.ok;
+            if (frame_pass_done(pass, nw.ok, nw.lds, ok16)) break;
         }
         if (nw.ok && !awork.empty() && R > 0 && R < (1ll << 30) && t->n_frames > 0) {
             // merged angle passes: one per centre species, every angle computed once (histograms in LDS; BadByCn keys, more

@@ -248,17 +248,32 @@ class PackedTrajectory(object):
         the copy exists the host array is read-only (numpy raises on ``packed.pos[...] = ...``); ``release_device()``
         drops the copy and makes the array writable again.  (A view taken BEFORE this call can still be written
         through -- do not keep one.)"""
-        if self.on_device or getattr(self, "_dev_pos", None) is not None:
+        kept = getattr(self, "_dev_pos", None)
+        if self.on_device or kept is not None:
+            have = self.pos.device.index if self.on_device else kept.device.index
+            if have != int(device):
+                raise ValueError("the trajectory already has a copy on cuda:%d; release_device() first to move it to "
+                                 "cuda:%d" % (have, int(device)))
             return self
         import torch
-        self._dev_pos = torch.from_numpy(self.pos).to(torch.device("cuda", device))
+        was_writeable = bool(self.pos.flags.writeable)
+        src = self.pos
+        if not was_writeable:           # (torch.from_numpy warns on read-only arrays; the upload only reads)
+            src = self.pos.view()
+            try:
+                src.flags.writeable = True
+            except ValueError:          # a truly read-only base (np.memmap mode='r', np.frombuffer): stage through a copy
+                src = np.array(self.pos)
+        self._dev_pos = torch.from_numpy(src).to(torch.device("cuda", int(device)))
+        self._was_writeable = was_writeable
         self.pos.flags.writeable = False
         return self
 
     def release_device(self):
         if getattr(self, "_dev_pos", None) is not None:
             self._dev_pos = None
-            self.pos.flags.writeable = True
+            if getattr(self, "_was_writeable", True):      # (an array that was read-only before stays read-only)
+                self.pos.flags.writeable = True
         return self
 
     def to_device(self, device=0):

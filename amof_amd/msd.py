@@ -81,6 +81,8 @@ class DirectMsd(Msd):
 
     def compute_msd(self, trajectory, step, parallel=False, device=None):
         packed = pack_trajectory(trajectory)
+        if getattr(packed, "is_stream", False):
+            packed = packed.read_all()      # (this analysis does not add up batch by batch)
         logger.info("Start computing msd for %s frames", len(packed))
         elements = packed.unique_numbers()
         dev = device if device is not None else getattr(packed, "device_index", None)

@@ -312,6 +312,8 @@ class CoordinationNumber(object):
 
     def compute_cn(self, trajectory, nb_set_and_cutoff, step, dr, parallel=False, device=None):
         packed = pack_trajectory(trajectory)
+        if getattr(packed, "is_stream", False):
+            packed = packed.read_all()      # (this analysis does not add up batch by batch)
         rmax = float(np.max(list(nb_set_and_cutoff.values())))
         logger.info("Start computing coordination number for %s frames with dr = %s and rmax = %s", len(packed), dr, rmax)
         bins = int(rmax // dr)

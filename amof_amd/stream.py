@@ -33,7 +33,10 @@ class XyzStream(object):
             the extended-XYZ ``Lattice`` of every frame (read ahead of the frames; a plain XYZ file without cells
             raises when a cell is first needed)
         batch_frames: frames per batch (default: about 256 MiB of positions)
-        index: slice or 'first:last:step' selecting frames, like ``ase.io.read``
+        index: slice or 'first:last:step' selecting frames, in ``ase.io.read``'s slice syntax.  NOTE the default:
+            None means ALL frames here (a stream exists to walk a trajectory), whereas ``ase.io.read`` and
+            ``amof_amd.trajectory.read_xyz`` return the LAST frame for index=None.  A selection without frames (an empty
+            file, '5:5') raises ValueError.
         n_threads: parser threads (0 = the CPUs this process may use)
         pinned: parse into page-locked memory (needs torch; falls back to ordinary memory without a GPU)
     """
@@ -62,6 +65,9 @@ class XyzStream(object):
             raise ValueError("frames must be read forwards")
         self.n_frames = len(range(self._first, stop, self._step))
         self.n_atoms = na.value
+        if self.n_frames == 0:
+            self.close()
+            raise ValueError("empty selection: %s holds %d frames, index %r selects none" % (self.path, nf.value, index))
         if int(n_threads) <= 0:
             n_threads = default_parser_threads()
         self.n_threads = int(max(1, min(int(n_threads), 64)))

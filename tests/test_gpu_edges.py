@@ -97,6 +97,16 @@ def test_undefined_angle_raises_like_ase(hip_ctx):
         hip_ctx.bad_hist(packed, rcm, [(1, 0)], np.arange(181.0))
 
 
+def by_triples(by, kinds):
+    """(centre, partner) species indices of a BadByCn result's columns 'B-A-B'"""
+    from amof_amd import data as D
+    out = []
+    for name in by.columns:
+        b, a, _ = name.split("-")
+        out.append(tuple(-1 if x == "X" else kinds.index(D.atomic_numbers[x]) for x in (a, b)))
+    return out
+
+
 def test_more_neighbours_than_the_lds_lists_hold(hip_ctx):
     """The reference has no limit on the neighbours of a centre (amof/bad.py:87-100).  A dense gas with ~100
     neighbours per atom exceeds the 32-entry LDS lists of the BAD kernels: the call goes through the big-list pass
@@ -130,6 +140,13 @@ def test_more_neighbours_than_the_lds_lists_hold(hip_ctx):
     frames = [Frame(packed.numbers, packed.pos[k], packed.cell_of(k)) for k in range(2)]
     by = BadByCn.from_trajectory(frames, {'H-O': 2.9}, dtheta=1.0)
     assert max(by.bad["O-H-O"]) > 16              # ~47 O within 2.9 A of an H in this gas
+    # ... ONCE: the slots of the second pass come from a count pass (largest neighbour count of any centre), not from x4 steps
+    rc2 = np.array([[0.0, 2.9], [2.9, 0.0]])
+    largest = clib.cn_counts(packed.pos[:2], packed.cell, sp, 2, rc2, [(0, 1), (1, 0)], per_atom=True)[1].max()
+    assert by.passes == 2 and by.hist.shape[1] - 1 == largest + 1 and not by.n_angles[:, -1].any()
+    hb_ref, ab_ref = clib.bad_hist_by_cn(packed.pos[:2], packed.cell, sp, 2, rc2,
+                                         by_triples(by, kinds), np.arange(182) * 1.0, by.hist.shape[1] - 1)
+    assert np.array_equal(by.hist, hb_ref) and np.array_equal(by.n_angles, ab_ref)
 
 
 def test_more_angle_bins_than_lds_holds(hip_ctx):

@@ -141,3 +141,36 @@ def test_host_trajectory_keeps_its_device_copy(hip_ctx):
     packed.release_device()
     packed.pos[0, 0, 0] += 0.0
     assert Rdf.from_trajectory(packed).data.equals(ref_r)
+    # an array that was read-only BEFORE keep_on_device stays read-only after release_device (advisor, round 3)
+    ro = H.random_walk(H.zif4_frame(), 30, 0.05, 12)
+    ro.pos.flags.writeable = False
+    ro.keep_on_device(0)
+    with pytest.raises(ValueError):
+        ro.keep_on_device(1)                  # (a copy on another GPU is refused, not silently ignored)
+    assert Rdf.from_trajectory(ro).data.equals(ref_r)
+    ro.release_device()
+    assert not ro.pos.flags.writeable
+
+
+def test_streams_in_classes_that_do_not_walk_batches(tmp_path, hip_ctx):
+    """BadByCn, DirectMsd and the RDF-integration CoordinationNumber read a stream whole (advisor, round 3: they died on a
+    bare assert); an empty selection raises a ValueError that says so"""
+    from amof_amd.stream import XyzStream
+    from amof_amd.msd import DirectMsd
+    from amof_amd.bad import BadByCn
+    from amof_amd.rdf import CoordinationNumber as RdfCn
+    from amof_amd import trajectory as T
+    packed = H.random_walk(H.zif4_frame(), 6, 0.05, 3, ortho=True)
+    path = str(tmp_path / "s.xyz")
+    T.write_xyz(path, packed, comment_lattice=True, fmt="%.17g")
+    whole = XyzStream(path, pinned=False).read_all()
+    assert DirectMsd.from_trajectory(XyzStream(path, batch_frames=4)).data.equals(DirectMsd.from_trajectory(whole).data)
+    a = RdfCn.from_trajectory(XyzStream(path, batch_frames=4), {'Zn-N': 2.5}, dr=0.01).data
+    assert a.equals(RdfCn.from_trajectory(whole, {'Zn-N': 2.5}, dr=0.01).data)
+    b1 = BadByCn.from_trajectory(XyzStream(path, batch_frames=4), {'Zn-N': 2.5}, dtheta=1.0)
+    b2 = BadByCn.from_trajectory(whole, {'Zn-N': 2.5}, dtheta=1.0)
+    assert np.array_equal(b1.hist, b2.hist) and b1.columns == b2.columns and b1.passes == 1
+    with pytest.raises(ValueError, match="empty selection"):
+        XyzStream(path, index="5:5")
+    with pytest.raises(TypeError):
+        hip_ctx.rdf_accumulate(XyzStream(path), 3.0, 30)

@@ -491,6 +491,11 @@ def test_msd_device_side_merge_entry_points(hip_ctx):
         assert hip_ctx.last_path() == "msd_com"
     m = packed.masses
     np.testing.assert_allclose(com.cpu().numpy(), (packed.pos * m[None, :, None]).sum(axis=1) / m.sum(), rtol=1e-13)
+    # a HOST trajectory with frame_begin > 0 (advisor, round 3: only the frames of the range are staged)
+    com_h = torch.zeros((F, 3), dtype=torch.float64, device="cuda:0")
+    for r in ((311, F), (5, 311), (0, 5)):
+        hip_ctx.msd_com(packed, r, com_h)
+    assert torch.equal(com_h, com)
     out = torch.zeros((len(kinds), len(window)), dtype=torch.float64, device="cuda:0")
     for r in ((0, 100), (100, N)):
         hip_ctx.msd_window(dev, window, atom_range=r, com=com, out=out)
@@ -744,3 +749,44 @@ def test_frame_tier_atom_count_boundaries(hip_ctx, n_pair):
         assert (hip_ctx.last_path() == "bad_frame") == (n_pair <= 8192), (n_pair, split, hip_ctx.last_path())
         hr = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
         assert np.array_equal(hg[0], hr[0]) and np.array_equal(hg[1], hr[1]), (n_pair, split)
+
+
+@pytest.mark.parametrize("records", ["1", "0"])
+def test_frame_tier_compact_records_grid_as_fine_as_the_cutoff_allows(hip_ctx, monkeypatch, records):
+    """Advisor (round 3, medium): COMPACT 8-byte records take the cell of an atom from its coordinate TRUNCATED to 16 bits,
+    which moves a centre against its partner by up to 2^-16 of the cell vector; with cells only 1e-5 thicker than the
+    cutoff a partner just inside rc could land two cells from its centre and be missed.  Constructed case: a cubic cell
+    with hmin = 7 rc (1 + 1.2e-5), axis-aligned pairs at rc (1 - 1e-7) whose centre sits 0 .. 2 units of 2^-16 above every
+    cell edge of the 7-cell grid, along each axis, compact records forced (and, as a control, forbidden)."""
+    monkeypatch.setenv("AMOF_NBR_COMPACT", records)
+    L, nk = 21.0, 7
+    rc = L / (nk * (1.0 + 1.2e-5))
+    u = 2.0 ** -16
+    rng = np.random.default_rng(77)
+    nfill = 20
+    numbers = np.array([30] + [7] + [30] * nfill + [7] * nfill)
+    frames = []
+    for axis in range(3):
+        for c in range(nk):
+            for e in range(64):
+                s = np.full((2, 3), 0.37)
+                s[0, axis] = c / nk + (e + 0.5) / 32.0 * u
+                s[1, axis] = s[0, axis] + (rc / L) * (1.0 - 1e-7)
+                fill = rng.uniform(0, 1, (2 * nfill, 3))
+                frames.append(np.concatenate([s, fill]) % 1.0 * L)
+    packed = PackedTrajectory(np.array(frames), np.diag([L, L, L]), numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    rcm = np.array([[0.0, rc], [rc, 0.0]])
+    sets = [(0, 1), (1, 0)]
+    got = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+    assert hip_ctx.last_path() == "cn_frame"
+    ref = clib.cn_counts(packed.pos, packed.cell, sp, 2, rcm, sets, per_atom=True)
+    a30 = int(np.nonzero(packed.numbers == 30)[0][0])
+    assert ref[1][:, sets.index((kinds.index(30), kinds.index(7))), a30].min() >= 1      # (the constructed partner is in range)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    edges = np.arange(182) * 1.0
+    triples = [(0, 1), (1, 0), (-1, -1)]
+    hg = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_frame"
+    hr = clib.bad_hist(packed.pos, packed.cell, sp, 2, rcm, triples, edges)
+    assert np.array_equal(hg[0], hr[0]) and np.array_equal(hg[1], hr[1])
