@@ -350,6 +350,80 @@ def supplementary(device, local_rank, ctx, do_verify=True):
     return out
 
 
+def realistic_cells(device, local_rank, ctx, head, do_verify=True, frames=400):
+    """Cells the reference's users actually have (amof/rdf.py:74-79 takes half the shortest cell LENGTH over all frames:
+    written for changing, non-rectangular cells), timed by the same process and tied to the oracle like every other leg:
+
+    * fixture: the TRUE lattice of examples/files/ZIF-4.xyz (off-diagonals -1.9e-4 .. -5.8e-4 A) replicated 3x3x4 -- the
+      headline system without the bench's exactly-diagonal cell;
+    * npt: a near-cubic 4x4x3 supercell (13 056 atoms) sheared by 2 %, a different (breathing) cell every frame;
+    * hexagonal: the 3x3x4 system mapped affinely into a hexagonal cell (a = b, gamma = 120 degrees) of the same volume.
+
+    Every leg runs Rdf.from_trajectory with the reference's defaults (dr = 0.01, rmax = half the shortest length).  `head`
+    = (kernel seconds, frames, atoms, visited fraction) of the headline launch: `vs_headline_per_visited_pair` is this leg's
+    kernel time per VISITED pair evaluation over the headline's (both kernels cull by slabs along the longest axis: the
+    visited share is the geometric one, min(1, 2 rmax / L_slab + 3/256))."""
+    import torch
+    from amof_amd.rdf import Rdf
+    from amof_amd.frames import Frame
+    from tests import helpers as H
+    t_head, f_head, n_head, vis_head = head
+    head_cost = t_head / (f_head * n_head * (n_head - 1) / 2.0 * vis_head)
+    out = {}
+    zif = H.zif4_frame()
+    legs = []
+    base = H.replicate(zif, (3, 3, 4))
+    legs.append(("fixture", "true ZIF-4.xyz lattice (off-diagonals kept) x 3x3x4, constant cell", base, base.cell, 20261004))
+    cub = H.replicate(zif, (4, 4, 3))
+    cub = Frame(cub.numbers, cub.positions, np.diag(np.diag(cub.cell)))
+    shear = np.eye(3) + np.array([[0, 0.02, 0.01], [0, 0, 0.02], [0, 0, 0]])
+    rng = np.random.default_rng(9)
+    npt_cells = np.array([(cub.cell @ shear) * (1.0 + 0.005 * rng.normal()) for _ in range(frames)])
+    legs.append(("npt", "near-cubic 4x4x3 (13 056 atoms), 2 % shear, a breathing cell per frame (sigma 0.5 %)",
+                 Frame(cub.numbers, cub.positions @ shear, cub.cell @ shear), npt_cells, 20261005))
+    d3 = np.diag(np.diag(base.cell))
+    a_hex = float(np.sqrt(d3[0, 0] * d3[1, 1] / (np.sqrt(3.0) / 2.0)))          # same volume, same c
+    hexc = np.array([[a_hex, 0.0, 0.0], [-0.5 * a_hex, np.sqrt(3.0) / 2.0 * a_hex, 0.0], [0.0, 0.0, d3[2, 2]]])
+    frac = np.linalg.solve(np.asarray(base.cell).T, base.positions.T).T
+    legs.append(("hexagonal", "3x3x4 system mapped into a hexagonal cell (a = b = %.3f A, gamma = 120), constant cell" % a_hex,
+                 Frame(base.numbers, frac @ hexc, hexc), hexc, 20261006))
+    for key, what, frame0, cells, seed in legs:
+        try:
+            tr = H.device_walk_cell(device, frame0, cells, frames, 0.05, seed)
+            torch.cuda.synchronize()
+            best, path = None, None
+            for rep in range(3):
+                t0 = time.perf_counter()
+                r = Rdf.from_trajectory(tr, device=local_rank, distributed=False)
+                wall = time.perf_counter() - t0
+                k = ctx.last_kernel_seconds(dominant=True)
+                if best is None or k < best:
+                    best, k_all, path, wall_best = k, ctx.last_kernel_seconds(dominant=False), ctx.last_path(), wall
+            N = tr.n_atoms
+            lengths = tr.cell_lengths()
+            rmax = r.rmax
+            lz = float(np.max(lengths))
+            visited = min(1.0, 2.0 * rmax / lz + 3.0 / 256.0) if 2.0 * rmax * 1.05 < lz else 1.0
+            pairs = frames * N * (N - 1) / 2.0
+            leg = {"workload": "%s; %d atoms x %d frames, Rdf(dr=0.01, rmax=half shortest length = %.4f A -> %d bins)"
+                               % (what, N, frames, rmax, len(r.data)),
+                   "path": path, "kernel_ms_per_frame": 1e3 * best / frames, "wall_ms_per_frame": 1e3 * wall_best / frames,
+                   "frames_per_s": frames / wall_best, "kernel_s_all": k_all,
+                   "pair_evals_per_s": pairs / best, "visited_fraction_geometric": visited,
+                   "vs_headline_per_pair": (best / pairs) / (head_cost * vis_head),
+                   "vs_headline_per_visited_pair": (best / (pairs * visited)) / head_cost}
+            if do_verify:
+                fr = [0, frames - 1]
+                leg["verified"] = bool(verify_rdf_timed(ctx, tr, rmax, len(r.data), r.hist, fr))
+                leg["verification"] = {"rdf_frames": fr}
+            out[key] = leg
+            del tr, r
+        except Exception as exc:
+            out[key] = {"error": repr(exc)}
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,7 +436,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rdf-frames", type=int, default=24)
     ap.add_argument("--no-bad", action="store_true", help="skip the configs[3] leg (RDF+BAD+MSD steps after the timed ones)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the supplementary configs[1] / configs[4] legs (N = 1)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the realistic-cell and the supplementary configs[1] / configs[4] legs (N = 1)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle spot checks of the timed results")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rehearsals")
     ap.add_argument("--all-on-device", type=int, default=None, help="rehearsal: put every rank on this GPU")
@@ -648,6 +723,11 @@ def main():
         if world == 1 and not args.no_extra:
             del packed
             torch.cuda.empty_cache()
+            try:
+                out["realistic_cells"] = realistic_cells(device, local_rank, ctx, (t_rdf, f_loc, N, visited),
+                                                         do_verify=not args.no_verify)
+            except Exception as exc:
+                out["realistic_cells"] = {"error": repr(exc)}
             try:
                 out["supplementary"] = supplementary(device, local_rank, ctx, do_verify=not args.no_verify)
             except Exception as exc:

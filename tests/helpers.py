@@ -128,6 +128,38 @@ def device_walk(device, reps, n_frames, sigma, seed, base=None):
     return PackedTrajectory(traj, cell, rep.numbers)
 
 
+def device_walk_cell(device, base, cells, n_frames, sigma, seed):
+    """Like device_walk, for ANY cell: a Gaussian random walk in Cartesian space from the (replicated) Frame `base`,
+    wrapped each frame into `cells` -- one [3][3] cell or a per-frame [F][3][3] series (NPT) -- in fractional
+    coordinates.  Atoms keep their fractional coordinates when the cell breathes.  Generated in HBM (torch, float64)."""
+    import torch
+    cells = np.asarray(cells, dtype=np.float64)
+    per_frame = cells.ndim == 3 and cells.shape[0] > 1
+    if cells.ndim == 2:
+        cells = cells.reshape(1, 3, 3)
+    assert cells.shape[0] in (1, n_frames)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = len(base.numbers)
+    C = torch.tensor(cells, dtype=torch.float64, device=device)
+    Cinv = torch.linalg.inv(C)
+    traj = torch.empty((n_frames, n, 3), dtype=torch.float64, device=device)
+    # the walk lives in the fractional coordinates of the first cell (steps of sigma Angstrom there)
+    cur = torch.tensor(np.linalg.solve(np.asarray(base.cell).T, base.positions.T).T, dtype=torch.float64, device=device)
+    chunk = 250
+    for f0 in range(0, n_frames, chunk):
+        f1 = min(f0 + chunk, n_frames)
+        steps = torch.randn((f1 - f0, n, 3), dtype=torch.float64, device=device, generator=g) * sigma
+        if f0 == 0:
+            steps[0] = 0.0
+        walk = cur + torch.cumsum(steps @ Cinv[0], dim=0)
+        cur = walk[-1].clone()
+        s = walk - torch.floor(walk)
+        traj[f0:f1] = torch.matmul(s, C[f0:f1] if per_frame else C[0])
+        del steps, walk, s
+    return PackedTrajectory(traj, cells if per_frame else cells[0], base.numbers)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # A second, stricter stand-in for ase.Atoms (ASE itself is not installed here).  Unlike amof_amd.frames.Frame --
 # written by the same hand as the code that consumes it -- this one copies the SHAPES of ASE 3.20's objects: the
