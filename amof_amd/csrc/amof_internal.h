@@ -264,9 +264,20 @@ __device__ __forceinline__ QAtom quantize_atom(const double *__restrict__ pos, c
     return q;
 }
 
+// "Triangular" tile kernel (rdf.hip, TRI): the first two stored coordinates carry the slab coordinate's share of the
+// shear, x'' = x + kx z, y' = y + ky z (mod 1; fold = {kx, ky} of the frame's cell), so that the u32 differences of a pair
+// are the components of its vector along the orthogonalised lattice directions (see RdfTri in rdf.hip).
+__device__ __forceinline__ void fold_atom(QAtom &q, const double *__restrict__ fold)
+{
+    const double z = (double)q.uz;
+    q.ux += (uint32_t)(long long)rint(z * fold[0]);
+    q.uy += (uint32_t)(long long)rint(z * fold[1]);
+}
+
+// ax0, ax1: the stored order of the two axes that are not the slab axis; d_fold (optional, device [n_cells][2]): fold_atom
 int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                     const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis, QAtom *d_Q,
-                    uint32_t *d_slab_start, int32_t *d_flag);
+                    uint32_t *d_slab_start, int32_t *d_flag, int ax0 = -1, int ax1 = -1, const double *d_fold = nullptr);
 
 int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                      const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis_z, int axis_y, int nz,

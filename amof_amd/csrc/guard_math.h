@@ -63,4 +63,19 @@ inline double fast_guard_zf(int nbins, double hb, double gfrac)
     return 1.1 * u * qmax * (3.5 + extra + 1.56);
 }
 
+// TRI form of the tile kernel (general cells, rdf.hip tri_q): the pair vector in the orthogonalised lattice frame,
+//   X = L00 (ix + c10 iy), Y = L11 iy, Z from f32 slab coordinates as in the ZF form (or L22 iz on the integer path),
+// ix, iy the u32 differences of the FOLDED coordinates.  The x term: two conversions, the constant c10 and the fma leave
+// |X~ - X| <= u (2 |X| + 3 a), a = |L10| / 2 in bins (the largest |L10 iy|); squared, scaled, summed: 9u X^2 + 6u a |X|;
+// y term 7u Y^2, z term as in fast_guard_zf.  With zeta = Z^2 / T:
+//   |q~ - q| <= u q (4.5 - 3 zeta + 1.56) + A sqrt(zeta) + 3 u a  <=  u qmax (6.06 + a_z^2 / 12 + 3 a / qmax)
+// (a_z = A / (u qmax) <= 6; else 3.06 + a_z).  10 % margin.  Returns the bound in bins (without the grid term g_m).
+inline double fast_guard_tri(int nbins, double hb, double gfrac, double l10_bins)
+{
+    const double u = 1.0 / 16777216.0, qmax = (double)nbins + 1.0;
+    const double az = hb * (gfrac + 1.0 / 16 + 1.0 / 128) / qmax;
+    const double extra = az <= 6.0 ? az * az / 12.0 : az - 3.0;
+    return 1.1 * u * qmax * (4.5 + extra + 1.56 + 1.5 * fabs(l10_bins) / qmax);
+}
+
 }  // namespace amof

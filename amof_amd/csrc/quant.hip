@@ -19,7 +19,8 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_kernel(const double *_
                                                        const int32_t *__restrict__ perm,
                                                        const int64_t *__restrict__ sp_first, int S, int64_t N,
                                                        int f0, int axis, QAtom *__restrict__ Q,
-                                                       uint32_t *__restrict__ slab_start, int32_t *flag, int cache_cap)
+                                                       uint32_t *__restrict__ slab_start, int32_t *flag, int cache_cap,
+                                                       int ax0, int ax1, const double *__restrict__ fold)
 {
     // species segments of up to cache_cap atoms keep their quantised records in LDS between the
     // counting pass and the placement pass, so the positions are read from HBM once
@@ -29,14 +30,16 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_kernel(const double *_
     __shared__ unsigned wsum[4];
     const int sp = blockIdx.x, fl = blockIdx.y, tid = threadIdx.x;
     const int f = f0 + fl;
-    const int ax0 = (axis + 1) % 3, ax1 = (axis + 2) % 3;   // stored order: (ax0, ax1, axis)
+    // stored order: (ax0, ax1, axis)
     const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const double *__restrict__ fo = fold ? fold + (size_t)(n_cells == 1 ? 0 : f) * 2 : nullptr;
     const int64_t k0 = sp_first[sp], k1 = sp_first[sp + 1];
     const bool cached = k1 - k0 <= (int64_t)cache_cap;
     if (tid < QSLABS) cnt[tid] = 0u;
     __syncthreads();
     for (int64_t k = k0 + tid; k < k1; k += QUANT_THREADS) {
-        const QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        QAtom q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        if (fo) fold_atom(q, fo);
         if (cached) cache[k - k0] = q;
         atomicAdd(&cnt[q.uz >> 24], 1u);
     }
@@ -65,7 +68,13 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_kernel(const double *_
     __syncthreads();
     QAtom *__restrict__ Qf = Q + (size_t)fl * N + k0;
     for (int64_t k = k0 + tid; k < k1; k += QUANT_THREADS) {
-        const QAtom q = cached ? cache[k - k0] : quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+        QAtom q;
+        if (cached) {
+            q = cache[k - k0];
+        } else {
+            q = quantize_atom(pos, g, N, f, perm[k], ax0, ax1, axis, flag);
+            if (fo) fold_atom(q, fo);
+        }
         const unsigned slot = atomicAdd(&cnt[q.uz >> 24], 1u);
         Qf[slot] = q;
     }
@@ -349,8 +358,9 @@ int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_
 
 int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                     const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis, QAtom *d_Q,
-                    uint32_t *d_slab_start, int32_t *d_flag)
+                    uint32_t *d_slab_start, int32_t *d_flag, int ax0, int ax1, const double *d_fold)
 {
+    if (ax0 < 0 || ax1 < 0) { ax0 = (axis + 1) % 3; ax1 = (axis + 2) % 3; }
     if (nf <= 0 || S <= 0) return AMOF_OK;
     if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
     dim3 qgrid((unsigned)S, (unsigned)nf);
@@ -360,7 +370,7 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
     const size_t lds = (size_t)cache_cap * sizeof(QAtom);
     AMOF_HIP_TRY(ctx, allow_max_lds((const void *)quantize_kernel));
     hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(QUANT_THREADS), lds, ctx->stream, pos_dev, d_geom, n_cells, d_perm, d_spfirst,
-                       S, N, f0, axis, d_Q, d_slab_start, d_flag, cache_cap);
+                       S, N, f0, axis, d_Q, d_slab_start, d_flag, cache_cap, ax0, ax1, d_fold);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     return AMOF_OK;
 }

@@ -215,6 +215,12 @@ struct FrameScale {
     uint32_t near_t[3]; // IMG variant: a pair with |i_k| > near_t[k] (stored axis order) is evaluated canonically
     uint32_t _pad;
     double sc64[9];     // the same factors in f64 (level-2 refinement)
+    // TRI variant (see RdfTri below): sc[3..5] = L00^2, L11^2, L22^2, sc[8] = L22 (units: bins per 2^-32 of the axis)
+    uint32_t tri_kx, tri_ky;    // round(kx 2^32), round(ky 2^32) mod 2^32: what one cell of slab wrap adds to the folded x'', y'
+    float tri_c10;              // L10 / L00
+    float tri_near_y;           // a pair with |fl(iy)| > tri_near_y may have a second image in range (+inf: never)
+    float tri_near_z;           // likewise |dz| (bins) > tri_near_z
+    float tri_near_x;           // likewise |fl(ix + c10 iy)| (slow path only: the variant is refused when the fast path would need it)
 };
 
 struct RdfFastArgs {
@@ -466,6 +472,185 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
     }
 }
 
+// --------------------------------------------------------------------------
+// TRI: general (triclinic) cells in the orthogonalised lattice frame.
+//
+// With the cell vectors in stored order A, B, C (C the slab axis) and L the lower-triangular factor of their metric,
+// an image of a pair has the components  Z = L22 fz,  Y = L11 (fy + r21 fz),  X = L00 (fx + c10 fy + r20 fz)
+// (c10 = L10/L00, r20 = L20/L00, r21 = L21/L11).  quantize_kernel stores FOLDED coordinates x'' = x + kx z, y' = y + ky z
+// (kx = r20 - c10 r21, ky = r21), so the wrapped u32 differences of a pair are  iy = fy + r21 fz  and
+// ix = fx + r20 fz - c10 r21 fz, i.e.  Y = L11 iy,  X = L00 (ix + c10 iy)  -- one fma more than a diagonal cell -- of the
+// image whose |Y| and |ix| are smallest (the slab difference is the minimum image by the culling window, or wrapped).
+// The fold uses every atom's own z in [0, 1): a pair whose slab difference wraps m cells (m = -1, 0, 1) is corrected
+// by m (Kx, Ky) -- per piece of the partner window on the centre's side where the slab difference comes from f32
+// coordinates (ZF quads), per pair from the sign and the borrow of the slab subtraction otherwise (tri_int).
+// Which pairs are decided here: an image with |d| < R has |Z|, |Y|, |X| < R.  The host admits the variant when
+//   L22 >= 2R or near_z is flagged,  L11 >= 2R or near_y is flagged,  R / L00 + |c10| / 2 < 1/2
+// (R = rmax with the guards): then the image above is the ONLY one that can be in range unless |Y| > L11 - R or
+// |Z| > L22 - R ("near": flagged by one compare each, taken back and evaluated canonically with every listed image),
+// and the x wrap -- decided on ix without the c10 iy term -- can only go wrong where both candidates are out of range.
+// Levels: f32 candidate (always-add), f64 T of the same integers, canonical evaluation (parked, drained densely).
+__device__ __forceinline__ void tri_int(const uint4 qj, uint32_t ux, uint32_t uy, uint32_t uz, uint32_t kx, uint32_t ky,
+                                        int &ix, int &iy, int &iz)
+{
+    iz = (int)(qj.z - uz);
+    // unwrapped slab difference = wrapped + m: m = (wrapped < 0) - (borrow)
+    const uint32_t sgn = (uint32_t)(iz >> 31);           // all ones when the wrapped difference is negative
+    const bool borrow = qj.z < uz;
+    ix = (int)(qj.x - ux - (sgn & kx) + (borrow ? kx : 0u));
+    iy = (int)(qj.y - uy - (sgn & ky) + (borrow ? ky : 0u));
+}
+
+// XW: the x wrap is decided WITH the c10 iy term (cells whose x axis has no slack, e.g. two equal in-plane lengths):
+// the term joins the integer difference before it wraps (truncated product: the candidate moves by < 1 + 256 |c10| grid
+// units, part of the guards; level 2 repeats the decision bit for bit and is exact for the image it picks)
+template <bool XW>
+__device__ __forceinline__ int tri_xwrap(float c10, int ix, float fy)
+{
+    return XW ? (int)((uint32_t)ix + (uint32_t)(int)(fy * c10)) : ix;
+}
+
+template <bool XW>
+__device__ __forceinline__ float tri_q(const float *sc, float c10, int ix, float fy, float dz)
+{
+    const float dxf = XW ? (float)tri_xwrap<true>(c10, ix, fy) : fmaf(fy, c10, (float)ix);
+    const float x2 = dxf * dxf, y2 = fy * fy;
+    return __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(y2, sc[4], x2 * sc[3])));
+}
+
+struct TriConst {
+    float c10, near_y, near_z, near_x;
+    uint32_t kx, ky;
+};
+
+// one pair on the TRI fast path (always-add histogram, see fast_bin<AA>); returns "needs the slow path".
+// ZF: (ux, uy) are the centre's folded coordinates already corrected for the piece's slab wrap, zif its f32 slab
+// coordinate; else the raw folded ones (per-pair correction).  NEAR: 0 no second image possible anywhere; 1 only for pairs
+// inside the guard band of the last bin edge, which are flagged anyway: the slow path tests, the fast path does not; 2 the
+// fast path tests y, 3 y and z (the slow path always both: every instruction of its body costs, so NEAR = 0 has none).
+template <bool ZF, int NEAR, bool XW>
+__device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, const TriConst &tc, bool live, float half_m_guard,
+                                             uint32_t ux, uint32_t uy, uint32_t uz, uint4 qj, float &q, float zif,
+                                             float clampv, bool live_all)
+{
+    int ix, iy;
+    float dz;
+    if (ZF) {
+        ix = (int)(qj.x - ux); iy = (int)(qj.y - uy);
+        dz = __uint_as_float(qj.w) - zif;
+    } else {
+        int iz;
+        tri_int(qj, ux, uy, uz, tc.kx, tc.ky, ix, iy, iz);
+        dz = (float)iz * sc[8];
+    }
+    const float fy = (float)iy;
+    q = tri_q<XW>(sc, tc.c10, ix, fy, dz);
+    if (!live_all) q = live ? q : __builtin_inff();
+    q = __builtin_fminf(q, clampv);
+    bool flag = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
+    if (NEAR == 2) flag |= live && (fabsf(fy) > tc.near_y);
+    if (NEAR == 3) flag |= live && ((fabsf(fy) > tc.near_y) | (fabsf(dz) > tc.near_z));
+    atomicAdd(&hist[(int)q], 1u);
+    return flag;
+}
+
+// slow path of a flagged TRI pair: the provisional count of candidate bin (int)q stands, moves, or is taken back and the
+// pair parked for the canonical evaluation (near pairs: a second image may count; level 3: within g_m of a bin edge)
+// (ZF quads: (ux, uy) carry the piece's slab wrap -- for a partner inside the window that is the pair's own; one outside it is
+//  out of range by its slab distance alone, whatever the other two components come out as)
+template <bool ZF, int NEAR, bool XW, typename Park>
+__device__ __forceinline__ void rdf_pair_refine_tri(unsigned *hist, const RdfFastArgs &fa, const float *sc, const TriConst &tc,
+                                                    const double *sc64, float q, uint32_t ux, uint32_t uy, uint32_t uz,
+                                                    uint4 qj, Park &&park)
+{
+    int ix, iy, iz;
+    if (ZF) { ix = (int)(qj.x - ux); iy = (int)(qj.y - uy); iz = (int)(qj.z - uz); }
+    else tri_int(qj, ux, uy, uz, tc.kx, tc.ky, ix, iy, iz);
+    const int cand = (int)q;
+    // (+inf on an axis without second image; x: only pairs inside the guard band of the last bin edge can matter)
+    if (NEAR > 0 && ((fabsf((float)iy) > tc.near_y) | (fabsf((float)iz * sc[8]) > tc.near_z) |
+                     (fabsf(XW ? (float)tri_xwrap<true>(tc.c10, ix, (float)iy) : fmaf((float)iy, tc.c10, (float)ix)) > tc.near_x))) {
+        atomicAdd(&hist[cand], 0xffffffffu);
+        park();
+        return;
+    }
+    double fx = (double)ix;
+    const double fy = (double)iy, fz = (double)iz;
+    if (XW) {   // the image the fast path picked: the same f32 product decides the wrap, the shift is a whole cell
+        const double it = (double)(int)((float)iy * tc.c10);
+        fx += (double)tri_xwrap<true>(tc.c10, ix, (float)iy) - (fx + it);      // (-2^32, 0 or 2^32: exact)
+    }
+    const double dx = fma(fy, sc64[3], fx * sc64[0]), dy = fy * sc64[4], dz = fz * sc64[8];
+    const double T = fma(dz, dz, fma(dy, dy, dx * dx));
+    const float ef = rintf(q);
+    const double e = (double)ef;
+    const double D = fma(-e, e, T), band = fma(e, fa.guard64_2, fa.guard64_sq);
+    const int ei = (int)ef;
+    int b = -1;
+    if (D >= band) b = ei;
+    else if (D < -band && ei > 0) b = ei - 1;
+    if (b == cand) return;
+    atomicAdd(&hist[cand], 0xffffffffu);
+    if (b >= 0) {
+        if (b < fa.a.nbins) atomicAdd(&hist[b], 1u);
+        return;
+    }
+    park();
+}
+
+// the atom index of partner j of the tile (wave-uniform address): a SCALAR load, so that the slow path holds no vector-memory
+// operation that the compiler could make the quad loops wait for
+__device__ __forceinline__ uint32_t scalar_idx(const QAtom *q)
+{
+    const unsigned long long a = (unsigned long long)q;
+    const unsigned long long au = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0xc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(au) : "memory");
+    return v;
+}
+
+template <bool DIAG, bool TAIL, bool ZF, int NEAR, bool XW>
+__device__ __forceinline__ void fast_quad_tri(unsigned *hist, const RdfFastArgs &fa, const double *sc64, const float *sc,
+                                              const TriConst &tc, const uint4 *tq, int j0, int cntj, bool has_a, bool has_b,
+                                              int ia, int ib, float half_m_guard,
+                                              uint32_t uax, uint32_t uay, uint32_t uaz, uint32_t ida,
+                                              uint32_t ubx, uint32_t uby, uint32_t ubz, uint32_t idb,
+                                              uint2 *nq, unsigned *nq_count, unsigned nq_cap,
+                                              const double *__restrict__ g, const double *__restrict__ p, int gi,
+                                              float zaf, float zbf, const QAtom *__restrict__ qseg, float clampv)
+{
+    uint4 qj[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) qj[u] = tq[j0 + u];
+    float qa[4], qb[4];
+    bool na[4], nb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int j = j0 + u;
+        const bool la = has_a && (!TAIL || j < cntj) && (!DIAG || j > ia);
+        const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
+        na[u] = fast_bin_tri<ZF, NEAR, XW>(hist, sc, tc, la, half_m_guard, uax, uay, uaz, qj[u], qa[u], zaf, clampv, ZF && !DIAG && !TAIL);
+        nb[u] = fast_bin_tri<ZF, NEAR, XW>(hist, sc, tc, lb, half_m_guard, ubx, uby, ubz, qj[u], qb[u], zbf, clampv, ZF && !DIAG && !TAIL);
+    }
+    if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            auto park = [&](uint32_t idc) {
+                const uint32_t idj = scalar_idx(qseg + (j0 + u));
+                const unsigned slot = atomicAdd(nq_count, 1u);
+                if (slot < nq_cap) {
+                    nq[slot] = make_uint2(idc, idj);
+                } else {        // queue full (perfect lattices: every pair on a bin edge): in place
+                    rdf_pair_images<false>(hist, fa, g, p, idc, idj, gi);
+                }
+            };
+            if (na[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qa[u], uax, uay, uaz, qj[u], [&]() { park(ida); });
+            if (nb[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qb[u], ubx, uby, ubz, qj[u], [&]() { park(idb); });
+        }
+    }
+}
+
 // Work item = (tile I, 128-atom sub-tile of I, tile J) x a chunk of frames.  All four
 // waves of the workgroup hold the SAME 128 centre atoms (two adjacent ones per lane) and
 // share the quads of tile J round-robin, so the slab culling -- which depends only on the
@@ -479,13 +664,18 @@ __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
     dma16(src_lane, dst_wave);
 }
 
-template <bool ORTHO, bool CULL, bool IMG = false, bool ZFK = false>
+template <bool ORTHO, bool CULL, bool IMG = false, bool ZFK = false, int TRI = -1>
 __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
-    static_assert(!ZFK || (ORTHO && !IMG), "f32 slab coordinates: diagonal cells, no image queue");
+    // TRI >= 0: general cells in the orthogonalised lattice frame (fast_quad_tri; TRI % 4: near tests, TRI / 4: x wrap with the y term)
+    static_assert(!ZFK || (ORTHO && !IMG) || TRI >= 0, "f32 slab coordinates: diagonal cells (no image queue) or TRI");
+    static_assert(TRI < 0 || (!ORTHO && !IMG && ZFK), "TRI: general cells, f32 slab coordinates, its own queue");
     // always-add histogram scheme (fast_bin<AA>): measured per variant (profiles/r02/tile_variants.txt) -- the plain
     // general-cell variant spills under it (nine scales, 96 VGPRs) and keeps the masked form
     constexpr bool AA = ORTHO || IMG;
+    constexpr bool QUEUE = IMG || TRI >= 0;     // parked pairs, drained densely by the canonical arithmetic
+    constexpr int NEAR = TRI >= 0 ? TRI % 4 : 0;
+    constexpr bool XW = TRI >= 4;
     const RdfArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // double-buffered tiles: J (512 entries) and the centre sub-tile (128 entries)
@@ -558,7 +748,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     };
 
     const int nsteps = (f1 - f0) * nsub;
-    if (IMG && tid < 3) nq_count[tid] = 0u;
+    if (QUEUE && tid < 3) nq_count[tid] = 0u;
     const double *p_prev = nullptr, *g_prev = nullptr;
     int gi_prev = 0;
     if (nsteps > 0) { stage_j(f0, 0); stage_c(f0, 0, 0); }
@@ -579,12 +769,25 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
             sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
         // the f64 scales of the level-2 refinement: diagonal cells keep their three in scalar registers (a vector load
         // at the head of every refinement visit costs a memory latency each time)
-        double sc64r[3] = {0.0, 0.0, 0.0};
+        double sc64r[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (ORTHO) {
 #pragma unroll
             for (int k = 0; k < 3; k++) sc64r[k] = uniform_f64(fs->sc64[k]);
         }
-        const double *sc64 = ORTHO ? sc64r : fs->sc64;
+        if (TRI >= 0) {     // L00, L10, L11, L22 of the level-2 form (rdf_pair_refine_tri): a load at the head of every visit would cost its latency
+            sc64r[0] = uniform_f64(fs->sc64[0]); sc64r[3] = uniform_f64(fs->sc64[3]);
+            sc64r[4] = uniform_f64(fs->sc64[4]); sc64r[8] = uniform_f64(fs->sc64[8]);
+        }
+        const double *sc64 = (ORTHO || TRI >= 0) ? sc64r : fs->sc64;
+        TriConst trc = {0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u};
+        if (TRI >= 0) {
+            trc.c10 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_c10)));
+            trc.near_y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_y)));
+            trc.near_z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_z)));
+            trc.near_x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_x)));
+            trc.kx = __builtin_amdgcn_readfirstlane(fs->tri_kx);
+            trc.ky = __builtin_amdgcn_readfirstlane(fs->tri_ky);
+        }
         float near_f[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
         if (IMG) {
 #pragma unroll
@@ -595,7 +798,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for this step has landed
         __syncthreads();                                    // everyone's has; the previous step is fully consumed
-        if (IMG) {
+        if (QUEUE) {
             // what the previous step parked is complete (barrier above): dense canonical pass, one pair per lane,
             // while this step parks into the other buffer; the counter of step + 1 was last read a step ago
             if (tid == 0) nq_count[(step + 1) % 3] = 0u;
@@ -626,6 +829,9 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         int rb0 = diag ? (sub * FAST_SUB) : 0, re0 = cntj, rb1 = 0, re1 = 0;
         bool zf = false;          // this step has quads that run on f32 slab coordinates (ZF kernels)
         uint32_t z0 = 0u;         // their origin: the middle of the centre sub-tile's slab range
+        int mz[2] = {0, 0};       // TRI: cells of slab wrap between the centres and the ZF partners of piece 0 / 1
+        bool touch = false;       // TRI: the two pieces of a wrapped reach touch; [sa, sb) = the quads that straddle them
+        int sa = 0, sb = 0;
         // quad ranges [b, e) of this step, quads dealt round-robin to the four waves: zq on f32 slab coordinates,
         // iq on the integer slab differences
         int zqb[2] = {0, 0}, zqe[2] = {0, 0}, iqb[2] = {0, 0}, iqe[2] = {0, 0};
@@ -659,6 +865,20 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                     } else if (b_ < a_) {      // wrapped reach: keys <= khi or >= klo
                         re0 = b_;
                         rb1 = max(rb0, a_); re1 = cntj;
+                        // (piece 0 = the keys <= khi: a cell below the centres when whi + G ran over; piece 1 = the keys
+                        //  >= klo: a cell above them when wlo - G ran under)
+                        if (khi < whi) mz[0] = -1;
+                        if (wlo < G) mz[1] = 1;
+                    } else if (TRI >= 0) {
+                        // the two pieces touch (no partner in the gap, or the tile lies inside one of them).  TRI needs the
+                        // slab wrap of a piece: quads before a_ hold keys <= khi only (or the gap), quads from b_ on keys >=
+                        // klo only; the quads in between (b_ >= a_) straddle both and take the integer path
+                        touch = true;
+                        re0 = a_;
+                        rb1 = max(rb0, b_); re1 = cntj;
+                        sa = max(rb0, a_); sb = b_;
+                        if (khi < whi) mz[0] = -1;
+                        if (wlo < G) mz[1] = 1;
                     }                          // else the two pieces touch: whole tile
                     if (ZFK) {
                         // f32 slab coordinates are valid when no slab difference of a partner inside the reach window and
@@ -679,6 +899,14 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                     if (r == 1) qbr[r] = max(qbr[r], (max(re0, rb0) + 3) & ~3);   // never visit a quad twice
                     (zf ? zqb : iqb)[r] = qbr[r];
                     (zf ? zqe : iqe)[r] = qer[r];
+                }
+                if (TRI >= 0 && touch) {
+                    if (zf) {               // (the integer ranges are free in a ZF step)
+                        iqb[0] = sa & ~3; iqe[0] = sb <= sa ? 0 : (sb + 3) & ~3;
+                    } else {                // everything on the integer path: one range
+                        iqb[0] = rb0 & ~3; iqe[0] = (cntj + 3) & ~3;
+                        iqb[1] = 0; iqe[1] = 0;
+                    }
                 }
             } else {
                 // No culling (the cutoff reaches across the slab axis: cubic cells at the default cutoff): every quad is
@@ -707,6 +935,8 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                         zqb[0] = start; zqe[0] = up4(b2);
                         zqb[1] = max(start, a2); zqe[1] = endq;
                         iqb[0] = max(start, up4(b2)); iqe[0] = min(max(start, a2), endq);
+                        if (khi < whi) mz[0] = -1;
+                        if (wlo < G2) mz[1] = 1;
                     }
                 }
             }
@@ -719,7 +949,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
             // each wave converts the slab coordinate of the partners it is about to meet on the ZF path (its own quads
             // of both pieces) into bins relative to z0, one rounding (f64 product -> f32), and parks it in the LDS
             // copy's .w; centre atoms likewise, in registers.  Wave-local: LDS operations of a wave execute in order.
-            const double cz = sc64[2];
+            const double cz = TRI >= 0 ? sc64[8] : sc64[2];
             uint4 *tqw = tqb + jb * FAST_TILE;
 #pragma unroll 1
             for (int r = 0; r < 2; r++) {
@@ -738,6 +968,29 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                 const int qb = qbr[r], qe = qer[r];
                 if (qe <= qb) continue;
                 const int qe_full = min(qe, full);
+                if (TRI >= 0) {
+                    // ZF quads: the piece's slab wrap goes onto the centres' folded coordinates; integer quads correct per pair
+                    const uint32_t kxm = ZF ? (uint32_t)mz[r] * trc.kx : 0u, kym = ZF ? (uint32_t)mz[r] * trc.ky : 0u;
+                    const uint32_t cax = uax + kxm, cay = uay + kym, cbx = ubx + kxm, cby = uby + kym;
+                    unsigned *nqc = &nq_count[step % 3];
+                    if (diag) {
+                        for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
+                            fast_quad_tri<true, true, ZF, NEAR, XW>(hist, fa, sc64, sc, trc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                                                                cax, cay, uaz, ida, cbx, cby, ubz, idb,
+                                                                nq, nqc, nq_cap, g, p, gi, zaf, zbf, qseg, clampv);
+                    } else {
+                        int j0 = qb + 4 * wave;
+                        for (; j0 < qe_full; j0 += 16)
+                            fast_quad_tri<false, false, ZF, NEAR, XW>(hist, fa, sc64, sc, trc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                                                                  cax, cay, uaz, ida, cbx, cby, ubz, idb,
+                                                                  nq, nqc, nq_cap, g, p, gi, zaf, zbf, qseg, clampv);
+                        if (j0 == full && j0 < qe && full < cntj)
+                            fast_quad_tri<false, true, ZF, NEAR, XW>(hist, fa, sc64, sc, trc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard,
+                                                                 cax, cay, uaz, ida, cbx, cby, ubz, idb,
+                                                                 nq, nqc, nq_cap, g, p, gi, zaf, zbf, qseg, clampv);
+                    }
+                    continue;
+                }
                 if (diag) {
                     for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
                         fast_quad<ORTHO, true, true, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
@@ -761,7 +1014,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         };
         if (ZFK && zf) run(std::true_type{}, zqb, zqe);
         run(std::false_type{}, iqb, iqe);
-        if (IMG && !fa.img_defer) {
+        if (QUEUE && !fa.img_defer) {
             // large shares: dense canonical pass over this step's parked pairs right away (one more barrier per step)
             __syncthreads();
             const int npark = (int)min(nq_count[step % 3], nq_cap);
@@ -772,7 +1025,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         }
         if (++sub == nsub) { sub = 0; fl++; }
     }
-    if (IMG && fa.img_defer && nsteps > 0) {   // the last step's parked pairs
+    if (QUEUE && fa.img_defer && nsteps > 0) {   // the last step's parked pairs
         __syncthreads();
         const uint2 *nqp = nq_base + (size_t)((nsteps - 1) & 1) * nq_cap;
         const int npark = (int)min(nq_count[(nsteps - 1) % 3], nq_cap);
@@ -1254,7 +1507,100 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             fast_img = true;
             near_thr.assign((size_t)nc * 3, 0x7fffffffu);
         }
+        // ---- TRI: general cells in the orthogonalised lattice frame (see fast_quad_tri) ----
+        // Stored order (x, y, z = slab axis): of the two orders of the other axes the one that leaves the x wrap the
+        // larger slack.  Conditions per cell, with R = rmax (1 + guards) and the lower factor L in Angstrom:
+        //   X: R / L00 + |L10| / (2 L00) < 1/2 - 1e-6     (the x wrap, decided without the c10 iy term, cannot lose an in-range image)
+        //   Y: tau_y = R / L11 - 1/2 <= 0: unique; else pairs with |iy| > 1/2 - tau_y are flagged near (<= 1.5 % of them)
+        //   Z: likewise with L22 (= the slab axis's perpendicular height)
+        bool tri = false;
+        int tri_code = 0, tri_ax0 = -1, tri_ax1 = -1, tri_axis = 0;       // code: near tests (0 none, 1 slow path only, 2 fast path y, 3 y + z) + 4 x (x wrap with the y term)
+        double tri_share = 0.0, tri_l10_bins = 0.0, tri_c10 = 0.0;
+        std::vector<double> tri_fold;       // [nc][2] kx, ky
+        std::vector<double> tri_rec;        // [nc][9] L00 L10 L11 L22 (bins per 2^-32), thr_y (units), thr_z (bins), kx, ky, thr_x (units)
+        const double two32_ = 1.0 / 4294967296.0;
+        if (!ortho && max_img <= 124 && t->pbc[0] && t->pbc[1] && t->pbc[2] && nbins <= AMOF_MAX_LDS_BINS - 5120 &&
+            guard_f < 0.25 && !(force && strcmp(force, "v1") == 0) && !getenv("AMOF_RDF_NOTRI") && !getenv("AMOF_RDF_FORCE_IMG")) {
+            double hmin3[3] = {1e300, 1e300, 1e300};
+            for (int64_t k = 0; k < nc; k++)
+                for (int x = 0; x < 3; x++) hmin3[x] = std::min(hmin3[x], geom.rec[(size_t)k * GEOM_STRIDE + 18 + x]);
+            tri_axis = 0;
+            for (int x = 1; x < 3; x++)
+                if (hmin3[x] > hmin3[tri_axis]) tri_axis = x;
+            const double R = rmax * (1.0 + 4.0 * guard_f / (double)nbins + 1e-6);
+            double best_cost = 1e300;
+            for (int sw = 0; sw < 2; sw++) {
+                const int a0 = sw ? (tri_axis + 2) % 3 : (tri_axis + 1) % 3, a1 = sw ? (tri_axis + 1) % 3 : (tri_axis + 2) % 3;
+                const int ordt[3] = {a0, a1, tri_axis};
+                bool ok = true;
+                double slack = 1e300, share = 0.0, l10b = 0.0, c10max = 0.0;
+                int near = 0;
+                std::vector<double> fold((size_t)nc * 2), rec((size_t)nc * 9);
+                for (int64_t k = 0; k < nc && ok; k++) {
+                    const double *c = t->cell + 9 * k;
+                    double rows[9], L[9];
+                    for (int q = 0; q < 3; q++)
+                        for (int x = 0; x < 3; x++) rows[3 * q + x] = c[3 * ordt[q] + x];
+                    lower_factor(rows, L);
+                    if (!(L[0] > 0.0 && L[4] > 0.0 && L[8] > 0.0)) { ok = false; break; }
+                    // (no slack: the x wrap takes the c10 iy term along, XW -- two instructions more per pair)
+                    slack = std::min(slack, 0.5 - 1e-6 - (R / L[0] + 0.5 * fabs(L[3]) / L[0]));
+                    c10max = std::max(c10max, fabs(L[3]) / L[0]);
+                    double tau_y = R / L[4] - 0.5 + 1e-9, tau_z = R / L[8] - 0.5 + 1e-9;
+                    if (tau_y > 0.0075 || tau_z > 0.0075) { ok = false; break; }
+                    // A second image along y (z) can only be in range when L11 / 2 < R0 (canonical rmax with rounding slack);
+                    // then its in-plane components are below rho = sqrt(R0^2 - (L/2)^2), the evaluated image's differ from them
+                    // by at most the lattice offsets, so it lies between L - R0 and sqrt(D2max) from the origin.  When that
+                    // whole interval is within g_m / 2 of the cutoff the pair is flagged by the guard band of the last bin
+                    // edge anyway: no compare in the fast path (the slow path tests, and parks it).
+                    const double R0 = rmax * (1.0 + 1e-12), gband = 0.5 * (2.0 * quant / dr + (double)nbins * 1e-12);
+                    auto covered = [&](double Lk, double off_a, double off_b) {
+                        const double rho = sqrt(std::max(0.0, R0 * R0 - 0.25 * Lk * Lk));
+                        const double d2max = 0.25 * Lk * Lk + (rho + off_a) * (rho + off_a) + (rho + off_b) * (rho + off_b);
+                        return (Lk - R0) / dr >= (double)nbins - gband && sqrt(d2max) / dr <= (double)nbins + gband;
+                    };
+                    if (0.5 * L[4] >= R0) tau_y = -1.0;       // no second image along y at all
+                    else near = std::max(near, covered(L[4], fabs(L[3]), 0.0) ? 1 : 2);
+                    if (0.5 * L[8] >= R0) tau_z = -1.0;
+                    else near = std::max(near, covered(L[8], fabs(L[7]), fabs(L[6]) + fabs(L[3])) ? 1 : 3);
+                    // x: |A| >= 2 rmax whenever rmax is the reference's half shortest length; a larger rmax (the C ABI
+                    // takes any) would need a near test on x in the fast path: not this variant
+                    double tau_x = R / L[0] - 0.5 + 1e-9;
+                    if (0.5 * L[0] >= R0) tau_x = -1.0;
+                    else if (covered(L[0], 0.0, 0.0)) near = std::max(near, 1);
+                    else { ok = false; break; }
+                    share = std::max(share, 2.0 * std::max(tau_y, 0.0) + 2.0 * std::max(tau_z, 0.0));
+                    l10b = std::max(l10b, fabs(L[3]) / dr);
+                    const double c10 = L[3] / L[0], r20 = L[6] / L[0], r21 = L[7] / L[4];
+                    fold[(size_t)k * 2] = r20 - c10 * r21;
+                    fold[(size_t)k * 2 + 1] = r21;
+                    double *r = &rec[(size_t)k * 9];
+                    r[0] = L[0] * two32_ / dr; r[1] = L[3] * two32_ / dr; r[2] = L[4] * two32_ / dr; r[3] = L[8] * two32_ / dr;
+                    // thresholds with room for the f32 conversions / coordinates of the fast path (flag a few more, never fewer)
+                    r[4] = tau_y > 0.0 ? (0.5 - tau_y) * 4294967296.0 * (1.0 - 1e-6) - 8.0 : INFINITY;
+                    r[5] = tau_z > 0.0 ? (L[8] - R) / dr * (1.0 - 1e-6) - 0.02 : INFINITY;
+                    r[6] = fold[(size_t)k * 2]; r[7] = fold[(size_t)k * 2 + 1];
+                    r[8] = tau_x > 0.0 ? (0.5 - tau_x) * 4294967296.0 * (1.0 - 1e-6) - 1024.0 : INFINITY;     // (f32 sum: 2^-23 of 2^31)
+                }
+                // cheaper order first: a near test costs a compare per pair, the x wrap two instructions in the chain
+                // (measured: + 8 % per compare, + 24 % for the wrap, profiles/r04/tri_experiments.txt)
+                const int code = near + (slack > 0.0 ? 0 : 4);
+                const double cost = (near == 0 ? 0.0 : near == 1 ? 0.5 : (double)(near - 1) * 1.5) + (slack > 0.0 ? 0.0 : 2.5);
+                if (ok && (!tri || cost < best_cost)) {
+                    best_cost = cost;
+                    tri = true; tri_code = code; tri_ax0 = a0; tri_ax1 = a1; tri_share = share; tri_l10_bins = l10b; tri_c10 = c10max;
+                    tri_fold.swap(fold); tri_rec.swap(rec);
+                }
+            }
+        }
+        if (tri) {      // (the guard of its candidate at the widest reach must leave room between the bin edges)
+            double hb = 0.0;
+            for (int64_t k = 0; k < nc; k++) hb = std::max(hb, geom.rec[(size_t)k * GEOM_STRIDE + 18 + tri_axis] / dr);
+            if (!(fast_guard_tri(nbins, hb, 0.5, tri_l10_bins) + (3.0 + 128.0 * tri_c10) * quant / dr + (double)nbins * 1e-12 < 0.25)) tri = false;
+        }
         bool done = false;
+        const bool fast_plain = fast;      // the cell-list / range kernels below rest on the plain criterion (cutoff clear of every half height)
+        if (tri) { fast = true; fast_img = false; }
         if (fast || fast_img) {
             HostTiles ftiles;
             build_tiles(t, FAST_TILE, ftiles, FAST_SUB);
@@ -1355,7 +1701,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             bool cell_taken = false;
             {
                 int nk[3];
-                bool cell_ok = fast && S <= 16 && t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && t->n_atoms >= 64 &&
+                bool cell_ok = fast_plain && S <= 16 && t->n_atoms < (1ll << CELL_SPECIES_SHIFT) && t->n_atoms >= 64 &&
                                !getenv("AMOF_RDF_NOCELL");
                 for (int x = 0; x < 3; x++) {
                     nk[x] = (int)std::min(1024.0, floor(hmin[x] / (0.5 * rmax * (1.0 + 1e-5))));
@@ -1474,7 +1820,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             if (hmin[(axis + 2) % 3] > hmin[axis_y]) axis_y = (axis + 2) % 3;
             const int nz2 = (int)std::min(64.0, floor(hmin[axis] / (rmax * (1.0 + 1e-5))));
             bool use_range = false;
-            if (fast && nz2 >= 3 && t->n_cells == 1 && !cell_taken && !(getenv("AMOF_RDF_NORANGE"))) {
+            if (fast_plain && nz2 >= 3 && t->n_cells == 1 && !cell_taken && !(getenv("AMOF_RDF_NORANGE"))) {
                 // visited share of the partners: 1-D slab list vs (3 slabs) x (y strip + 2 rmax)
                 int64_t nmax = 0;
                 for (int x = 0; x < S; x++) nmax = std::max<int64_t>(nmax, ftiles.nsp[x]);
@@ -1583,6 +1929,61 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)(nbins + FAST_TRASH) * sizeof(unsigned);
             fa.img_queue = 0;
             fa.img_defer = 0;
+            const double *d_fold = nullptr;
+            RdfFastArgs ft = fa;        // TRI: its own per-cell records, guards and queue
+            if (tri) {
+                std::vector<FrameScale> fst((size_t)nc);
+                double hb = 0.0, gfrac = 0.0;
+                for (int64_t k = 0; k < nc; k++) {
+                    FrameScale &r = fst[(size_t)k];
+                    memset(&r, 0, sizeof r);
+                    const double *tr = &tri_rec[(size_t)k * 9];
+                    r.sc64[0] = tr[0]; r.sc64[3] = tr[1]; r.sc64[4] = tr[2]; r.sc64[8] = tr[3];
+                    r.sc[3] = (float)(tr[0] * tr[0]); r.sc[4] = (float)(tr[2] * tr[2]); r.sc[5] = (float)(tr[3] * tr[3]);
+                    r.sc[8] = (float)tr[3];
+                    r.tri_c10 = (float)(tr[1] / tr[0]);
+                    auto down = [](double v) {      // largest float <= v
+                        if (!(v < INFINITY)) return (float)INFINITY;
+                        float f = (float)v;
+                        if ((double)f > v) f = nextafterf(f, -INFINITY);
+                        return f;
+                    };
+                    r.tri_near_y = down(tr[4]);
+                    r.tri_near_z = down(tr[5]);
+                    r.tri_near_x = down(tr[8]);
+                    r.tri_kx = (uint32_t)(long long)rint(tr[6] * 4294967296.0);
+                    r.tri_ky = (uint32_t)(long long)rint(tr[7] * 4294967296.0);
+                    r.cull_gap = fsv[(size_t)k].cull_gap;           // (same slab axis, same height)
+                    for (int q = 0; q < 3; q++) r.near_t[q] = 0x7fffffffu;
+                    hb = std::max(hb, geom.rec[(size_t)k * GEOM_STRIDE + 18 + axis] / dr);
+                    gfrac = std::max(gfrac, cull ? (double)r.cull_gap / 4294967296.0 : 0.5);
+                }
+                void *d_fst, *d_foldv;
+                AMOF_TRY(upload(ctx, SLOT_AUX5, fst.data(), fst.size() * sizeof(FrameScale), &d_fst));
+                AMOF_TRY(upload(ctx, SLOT_AUX6, tri_fold.data(), tri_fold.size() * sizeof(double), &d_foldv));
+                d_fold = (const double *)d_foldv;
+                ft.fs = (const FrameScale *)d_fst;
+                // folded coordinates: two fold roundings and the wrap constant on top of the truncation (2.5 grid units per
+                // axis instead of 1): twice the grid term; XW: the truncated f32 product c10 iy moves the x wrap and the
+                // candidate by < 1 + 256 |c10| units more (quant = 2 units of csum)
+                const double guard_m_tri = (tri_code >= 4 ? 3.0 + 128.0 * tri_c10 : 2.0) * quant / dr + (double)nbins * 1e-12;
+                const double guard_tri = fast_guard_tri(nbins, hb, gfrac, tri_l10_bins) + guard_m_tri;
+                if (!(guard_tri < 0.25)) return fail(ctx, AMOF_ECAPACITY, "TRI guard out of range");      // (checked at selection)
+                const double half = 0.5 - guard_tri;
+                float fhalf = (float)half;
+                if ((double)fhalf > half) fhalf = nextafterf(fhalf, -INFINITY);
+                ft.half_m_guard = fhalf;
+                ft.guard64 = guard_m_tri;
+                ft.guard64_2 = 2.0 * guard_m_tri * (1.0 + 1e-9);
+                ft.guard64_sq = guard_m_tri * guard_m_tri * (1.0 + 1e-9);
+                // queue: the near pairs (share of all pairs) and the level-3 pairs of a step
+                const double expect = tri_share * (double)FAST_SUB * FAST_TILE;
+                const double want = std::max(96.0, ceil(4.0 * expect / 32.0) * 32.0);
+                ft.img_defer = want <= 256.0 ? 1 : 0;
+                ft.img_queue = ft.img_defer ? (int32_t)want : IMG_QUEUE_MAX;
+                lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 1) & ~1) * sizeof(unsigned) +
+                      (ft.img_defer ? 2 : 1) * (size_t)ft.img_queue * sizeof(uint2);
+            }
             if (fast_img) {
                 // expected number of parked pairs per step (a step is 128 x 512 pairs).  Slightly sheared cells: two
                 // buffers of >= 96 entries, evaluated a step later -- small enough for five workgroups per CU and no
@@ -1600,7 +2001,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 AMOF_TRY(stager_need(stage, fb + nf));
                 AMOF_TRY(launch_quantize(ctx, pos_dev, (const double *)d_geom, (int)t->n_cells, (const int32_t *)d_perm,
                                          (const int64_t *)d_spfirst, S, t->n_atoms, (int)fb, (int)nf, axis, (QAtom *)d_Q,
-                                         nullptr, (int32_t *)d_flag));
+                                         nullptr, (int32_t *)d_flag, tri ? tri_ax0 : -1, tri ? tri_ax1 : -1, d_fold));
                 fa.f_base = (int32_t)fb;
                 fa.nf = (int32_t)nf;
                 // frames per workgroup chunk: ~80k workgroups per launch (1280 run at a time: > 60 rounds, so that
@@ -1619,7 +2020,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.a.frames_per_chunk = (int32_t)fpc;
                 fa.n_chunks = (int32_t)chunks;
                 dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
-                if (launches == 0) timing_dom_begin(ctx, fast_img ? "rdf_tile_img" : use_zf ? "rdf_tile_zf" : "rdf_tile");
+                if (launches == 0) timing_dom_begin(ctx, tri ? "rdf_tile_tri" : fast_img ? "rdf_tile_img" : use_zf ? "rdf_tile_zf" : "rdf_tile");
                 auto launch = [&](auto kern) -> hipError_t {
                     hipError_t e2 = allow_max_lds((const void *)kern);
                     if (e2 != hipSuccess) return e2;
@@ -1627,7 +2028,30 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     return hipSuccess;
                 };
                 hipError_t e;
-                if (fast_img) {
+                if (tri) {
+                    ft.Q = fa.Q; ft.f_base = fa.f_base; ft.nf = fa.nf; ft.xcd_map = fa.xcd_map; ft.n_chunks = fa.n_chunks;
+                    ft.a.frames_per_chunk = fa.a.frames_per_chunk;
+                    auto launch_tri = [&](auto kern) -> hipError_t {
+                        hipError_t e2 = allow_max_lds((const void *)kern);
+                        if (e2 != hipSuccess) return e2;
+                        hipLaunchKernelGGL(kern, grid, dim3(FAST_THREADS), lds, ctx->stream, ft);
+                        return hipSuccess;
+                    };
+                    // (one instantiation per code: near tests x x wrap)
+#define AMOF_TRI(C) (cull ? launch_tri(rdf_tile_kernel_fast<false, true, false, true, C>) : launch_tri(rdf_tile_kernel_fast<false, false, false, true, C>))
+                    switch (tri_code) {
+                    case 0: e = AMOF_TRI(0); break;
+                    case 1: e = AMOF_TRI(1); break;
+                    case 2: e = AMOF_TRI(2); break;
+                    case 3: e = AMOF_TRI(3); break;
+                    case 4: e = AMOF_TRI(4); break;
+                    case 5: e = AMOF_TRI(5); break;
+                    case 6: e = AMOF_TRI(6); break;
+                    default: e = AMOF_TRI(7); break;
+                    }
+#undef AMOF_TRI
+                }
+                else if (fast_img) {
                     if (ortho && cull) e = launch(rdf_tile_kernel_fast<true, true, true>);
                     else if (ortho) e = launch(rdf_tile_kernel_fast<true, false, true>);
                     else if (cull) e = launch(rdf_tile_kernel_fast<false, true, true>);

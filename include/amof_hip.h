@@ -100,8 +100,9 @@ double amof_last_kernel_seconds(const amof_ctx *ctx, int which);
 /* number of launches of the dominant kernel in the last call */
 int64_t amof_last_kernel_launches(const amof_ctx *ctx);
 /* kernel family that produced the result of the last call (diagnostics and tests; "" before the first call):
- *   RDF  "rdf_tile_zf" (diagonal cells, f32 slab coordinates), "rdf_tile" (general fast tile kernel),
- *        "rdf_tile_img" (cutoffs beyond half a cell height), "rdf_cell" (3-D cell list), "rdf_range" (2-level list),
+ *   RDF  "rdf_tile_zf" (diagonal cells, f32 slab coordinates), "rdf_tile_tri" (general cells in the orthogonalised
+ *        lattice frame, f32 slab coordinates), "rdf_tile" (plain general tile kernel), "rdf_tile_img" (cutoffs beyond
+ *        half a cell height where "rdf_tile_tri" does not apply), "rdf_cell" (3-D cell list), "rdf_range" (2-level list),
  *        "rdf_exact" (canonical float64 arithmetic per pair)
  *   CN   "cn_frame" (whole frame in LDS), "cn_cell", "cn_fast", "cn_exact"
  *   BAD  "bad_frame" (whole frame in LDS), "bad_cell", "bad_fast", "bad_exact", "bad_exact_biglist"

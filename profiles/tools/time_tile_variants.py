@@ -38,11 +38,15 @@ def run(name, frame, rmax, env=None):
 half = float(np.min(np.sqrt((base.cell ** 2).sum(axis=1))) / 2)
 run("diagonal, slab culling (headline)", base, half)
 run("diagonal, culling off", base, half, {"AMOF_RDF_NOCULL": "1"})
+if os.environ.get("AMOF_TILE_DEBUG"):
+    run("  diagonal, rmax = 0.9 half (as the sheared rows)", base, 0.9 * half)
 for eps in (0.02, 0.10):
     shear = np.eye(3) + np.array([[0, eps, 0.5 * eps], [0, 0, eps], [0, 0, 0]])
     fr = Frame(base.numbers, base.positions @ shear, base.cell @ shear)
     hmin = 1.0 / np.linalg.norm(np.linalg.inv(fr.cell), axis=0).max()
     run("sheared %2.0f %%, rmax = 0.45 min height" % (100 * eps), fr, 0.9 * hmin / 2)
+    if os.environ.get("AMOF_TILE_DEBUG"):
+        run("  same, old plain general variant", fr, 0.9 * hmin / 2, {"AMOF_RDF_NOTRI": "1"})
     run("sheared %2.0f %%, default rmax (images)" % (100 * eps), fr, float(np.min(np.sqrt((fr.cell ** 2).sum(axis=1))) / 2))
 # the typical aMOF input: a near-cubic NPT cell, slightly sheared, a different cell every frame, default cutoff
 cub = H.replicate(H.zif4_frame(), (4, 4, 3))                       # 13 056 atoms, 61.6 x 61.2 x 55.3 A

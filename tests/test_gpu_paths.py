@@ -46,18 +46,18 @@ def test_rdf_fast_equals_exact_equals_oracle(hip_ctx, kind):
     packed, rmax, nb = _traj(kind)
     with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
         fast, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-        # diagonal cells: the variant with f32 slab coordinates and the always-add histogram
+        # diagonal cells: the variant with f32 slab coordinates and the always-add histogram; general cells: the same in
+        # the orthogonalised lattice frame (round 4); AMOF_RDF_NOZF / AMOF_RDF_NOTRI name the plain tile kernel
         diagonal = bool(np.all(packed.cell == packed.cell * np.eye(3)))
-        assert hip_ctx.last_path() == ("rdf_tile_zf" if diagonal else "rdf_tile")
-        if diagonal:
-            with _env(AMOF_RDF_NOZF="1"):
-                nozf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-                assert hip_ctx.last_path() == "rdf_tile"
-            assert np.array_equal(fast, nozf)
+        assert hip_ctx.last_path() == ("rdf_tile_zf" if diagonal else "rdf_tile_tri")
+        with _env(AMOF_RDF_NOZF="1", AMOF_RDF_NOTRI="1"):
+            nozf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_tile"
+        assert np.array_equal(fast, nozf)
         with _env(AMOF_RDF_NOCULL="1"):
             nocull, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() == ("rdf_tile_zf" if diagonal else "rdf_tile")
-            with _env(AMOF_RDF_NOZF="1"):
+            assert hip_ctx.last_path() == ("rdf_tile_zf" if diagonal else "rdf_tile_tri")
+            with _env(AMOF_RDF_NOZF="1", AMOF_RDF_NOTRI="1"):
                 nocull_nozf, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
                 assert hip_ctx.last_path() == "rdf_tile"
             assert np.array_equal(nocull, nocull_nozf)
@@ -398,7 +398,7 @@ def test_rdf_range_kernel_two_level_cell_list(hip_ctx, tri):
             assert hip_ctx.last_path() == "rdf_range"
         with _env(AMOF_RDF_NORANGE="1", AMOF_RDF_NOCELL="1"):
             slab, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() in ("rdf_tile", "rdf_tile_zf")
+            assert hip_ctx.last_path() in ("rdf_tile_tri", "rdf_tile_zf")
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
         assert np.array_equal(got, ref) and np.array_equal(slab, ref)
     # exactly three slabs (nz = 3): the forward-slab rule must not double count across the wrap
@@ -560,7 +560,7 @@ def test_rdf_cell_kernel_three_level_cell_list(hip_ctx, kind):
             assert hip_ctx.last_path() == "rdf_cell"
         with _env(AMOF_RDF_NOCELL="1"):
             other, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() in ("rdf_tile", "rdf_tile_zf", "rdf_range")
+            assert hip_ctx.last_path() in ("rdf_tile_tri", "rdf_tile_zf", "rdf_range")
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
         assert np.array_equal(got, ref), (kind, rmax, nb, int(got.sum()), int(ref.sum()))
         assert np.array_equal(other, ref)
@@ -596,14 +596,18 @@ def test_rdf_sheared_cell_default_cutoff_counts_images(hip_ctx, eps, jitter):
     kinds, sp = H.species_of(packed.numbers)
     rmax = float(np.min(packed.cell_lengths()) / 2)
     for nb in (257, 1540):
-        got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-        assert hip_ctx.last_path() == "rdf_tile_img"
-        with _env(AMOF_RDF_NOIMG="1"):
-            exact, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() == "rdf_exact"
+        tri, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+        assert hip_ctx.last_path() == "rdf_tile_tri"          # (round 4: the orthogonalised-frame kernel takes these cells)
+        with _env(AMOF_RDF_NOTRI="1"):
+            got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_tile_img"
+            with _env(AMOF_RDF_NOIMG="1"):
+                exact, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+                assert hip_ctx.last_path() == "rdf_exact"
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
         assert np.array_equal(exact, ref)
         assert np.array_equal(got, ref), (eps, nb, int(got.sum()), int(ref.sum()))
+        assert np.array_equal(tri, ref), (eps, nb, int(tri.sum()), int(ref.sum()))
 
 
 def test_rdf_image_aware_variant_on_a_plain_case(hip_ctx):
@@ -790,3 +794,74 @@ def test_frame_tier_compact_records_grid_as_fine_as_the_cutoff_allows(hip_ctx, m
     assert hip_ctx.last_path() == "bad_frame"
     hr = clib.bad_hist(packed.pos, packed.cell, sp, 2, rcm, triples, edges)
     assert np.array_equal(hg[0], hr[0]) and np.array_equal(hg[1], hr[1])
+
+
+def _tri_cell(kind):
+    """general cells for the orthogonalised-frame tile kernel ("rdf_tile_tri"), by what its selection has to do"""
+    from amof_amd.frames import Frame
+    z = H.zif4_frame()
+    if kind == "fixture":           # the reference's own lattice (off-diagonals ~1e-5): second images only inside the guard band
+        return H.replicate(z, (2, 2, 3))
+    if kind == "equal_ab":          # two equal in-plane lengths, sheared: the x wrap takes the y term along
+        base = H.replicate(z, (2, 2, 2))
+        shear = np.eye(3) + np.array([[0, 0.02, 0.01], [0, 0, 0.02], [0, 0, 0]])
+        return Frame(base.numbers, base.positions @ shear, base.cell @ shear)
+    if kind == "short_c":           # a clearly shortest axis that is sheared against the others: near test on y
+        base = H.replicate(z, (2, 2, 1))
+        base = Frame(base.numbers, base.positions, np.diag(np.diag(base.cell)))
+        shear = np.eye(3) + np.array([[0, 0.02, 0.01], [0, 0, 0.02], [0, 0, 0]])
+        return Frame(base.numbers, base.positions @ shear, base.cell @ shear)
+    if kind == "cubic":             # cubic, sheared: no culling, the slab axis needs the near test too
+        cub = H.replicate(Frame(z.numbers, z.positions, np.diag([15.4, 15.4, 15.4])), (2, 2, 2))
+        shear = np.eye(3) + np.array([[0, 0, 0], [0.03, 0, 0], [-0.015, 0.03, 0]])
+        return Frame(cub.numbers, cub.positions @ shear, cub.cell @ shear)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["fixture", "equal_ab", "short_c", "cubic"])
+@pytest.mark.parametrize("jitter", [0.0, 0.004])
+def test_rdf_triangular_frame_kernel(hip_ctx, kind, jitter):
+    """General cells at the reference's default cutoff (half the shortest cell LENGTH, amof/rdf.py:74): the tile kernel in
+    the orthogonalised lattice frame against the oracle, with the image-aware / exact kernels it replaces beside it; a
+    cutoff beyond half the x axis (only the C ABI allows it) is refused by the variant"""
+    packed = H.random_walk(_tri_cell(kind), 3, 0.08, 41, cell_jitter=jitter)
+    kinds, sp = H.species_of(packed.numbers)
+    rmax = float(np.min(packed.cell_lengths()) / 2)
+    for rm, nb in ((rmax, 1540), (rmax, 257), (0.8 * rmax, 500)):
+        with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
+            got, _, _ = hip_ctx.rdf_accumulate(packed, rm, nb)
+            assert hip_ctx.last_path() == "rdf_tile_tri", (kind, rm)
+            with _env(AMOF_RDF_NOCULL="1"):
+                nocull, _, _ = hip_ctx.rdf_accumulate(packed, rm, nb)
+                assert hip_ctx.last_path() == "rdf_tile_tri"
+            with _env(AMOF_RDF_NOTRI="1"):
+                old, _, _ = hip_ctx.rdf_accumulate(packed, rm, nb)
+                assert hip_ctx.last_path() in ("rdf_tile", "rdf_tile_img", "rdf_exact")
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rm, nb, cell_list=True)
+        assert np.array_equal(got, ref), (kind, rm, nb, int(np.abs(got.astype(np.int64) - ref).sum()))
+        assert np.array_equal(nocull, ref) and np.array_equal(old, ref)
+    # a cutoff beyond half the shortest length (only the C ABI allows it): second images along that axis -- as y or z it
+    # gets the near test, as x (both in-plane axes too short) the variant is refused
+    big, _, _ = hip_ctx.rdf_accumulate(packed, 1.01 * rmax, 800)
+    if kind in ("equal_ab", "cubic"):
+        assert hip_ctx.last_path() != "rdf_tile_tri"
+    ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), 1.01 * rmax, 800, cell_list=True)
+    assert np.array_equal(big, ref)
+
+
+def test_rdf_triangular_frame_lattice_on_faces_and_edges(hip_ctx):
+    """an integer lattice in integer sheared cells: every distance on a bin edge, pairs exactly on cell faces (both images
+    at the same distance) -- every in-range pair goes through the queue of the canonical pass, which overflows into the
+    in-place evaluation"""
+    g12 = np.arange(12) * 1.0
+    for cell in (np.array([[12.0, 0, 0], [1.0, 12.0, 0], [0.0, 1.0, 24.0]]), np.array([[12.0, 0, 0], [0.0, 12.0, 0], [1.0, -1.0, 12.0]])):
+        pts = np.array([[x, y, zz] for x in g12 for y in g12 for zz in np.arange(int(cell[2, 2])) * 1.0])
+        numbers = np.where((pts.sum(axis=1) % 2) == 0, 11, 17)
+        packed = PackedTrajectory(np.stack([pts, pts + 0.5]), cell, numbers)
+        kinds, sp = H.species_of(packed.numbers)
+        for rm, nb in ((6.0, 60), (6.0, 600), (5.0, 50)):
+            with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1"):
+                got, _, _ = hip_ctx.rdf_accumulate(packed, rm, nb)
+                assert hip_ctx.last_path() == "rdf_tile_tri"
+            ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rm, nb, cell_list=True)
+            assert np.array_equal(got, ref), (cell[2].tolist(), rm, nb)
