@@ -16,6 +16,17 @@
 //       position u) and every window m reduces sum_k (u[k+m]-u[k])^2 from LDS.
 //   partial --msd_reduce_kernel--> sumsq[S][W]  (fixed order: deterministic)
 // HBM traffic: pos read twice (com + delta), D_T written once and read once.
+//
+// Round 4, diagonal cells (the 2-pass form): the centre of mass is folded into the transposition.  wrap() is a shift by
+// whole cell vectors, so  wrap((p_k - c_k) - (p_k-1 - c_k-1)) = wrap(wrap(p_k - p_k-1) - (c_k - c_k-1)):  pass 1 reads pos
+// ONCE, writes the wrapped RAW differences to D_T and the mass-weighted coordinate sums of its 64-atom tile per frame
+// (cpart, 1.5 % of the traffic; summed in fixed order by com_finish_kernel into dc[3][Fp] = c_k - c_k-1); the window
+// kernels finish the columns.  Wrapping again changes an entry only when the raw difference lies within |dc| of half the
+// cell (an atom that moves half a box in one frame): for every other column  sum_j wrap(raw_j - dc_j) = U_raw[k] - C[k],
+// C[k] = c_k (up to a constant that cancels in every window) -- the kernels scan the RAW column and subtract C[k] where an entry enters the registers (no extra
+// pass); the scan's first loop checks |raw| against  L/2 - max|dc|,  and a column with such an entry is loaded again,
+// corrected entry by entry with the wrap arithmetic (dcom_column) and scanned once more (C replaced by zeros).
+// pos read once, D_T written once and read once.
 #include <math.h>
 
 #include <algorithm>
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(MSD_THREADS) void com_kernel(const double *__restri
                                                           const double *__restrict__ masses, int64_t N,
                                                           double total_mass, double *__restrict__ com)
 {
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const int f = blockIdx.x;
     const double *__restrict__ p = pos + (size_t)f * (size_t)N * 3;
     double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -120,13 +131,75 @@ __device__ __forceinline__ void wrap_delta_t(const double *__restrict__ g, doubl
     oz = fr[2] * g[8];
 }
 
+// Sum of a double over the 64 lanes of a wave, valid in lane 63; fixed order.  Rows of 16 lanes by DPP moves (row_shr
+// 1, 2, 4, 8 with zero fill: vector-ALU instructions -- __shfl_down goes through the LDS crossbar twice per double and
+// cost the transposition 0.12 ms), the four row totals by readlane.
+__device__ __forceinline__ double wave_sum_dpp(double x)
+{
+#define AMOF_DPP_STEP(CTRL)                                                                                     \
+    {                                                                                                           \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);                  \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);                  \
+        x += __hiloint2double(hi, lo);                                                                           \
+    }
+    AMOF_DPP_STEP(0x111)    // row_shr:1
+    AMOF_DPP_STEP(0x112)    // row_shr:2
+    AMOF_DPP_STEP(0x114)    // row_shr:4
+    AMOF_DPP_STEP(0x118)    // row_shr:8
+#undef AMOF_DPP_STEP
+    auto lane = [&](int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+    };
+    return ((lane(15) + lane(31)) + lane(47)) + x;      // (lane 63 holds the last row's total)
+}
+
+// 2-pass form: what a window kernel needs to finish a column of raw wrapped differences (dcT == nullptr: nothing to do)
+struct Dcom {
+    const double *dcT;      // [3][Fp] centre-of-mass step c_k - c_k-1 per coordinate (entry 0 = 0)
+    const double *CT;       // [4][Fp] C[k] = c_k per coordinate (only its differences matter); row 3 = zeros (columns corrected entry by entry)
+    const unsigned long long *dcmax;   // [3] bits of max_k |dc_k| per coordinate
+    const double *geom;     // [n_cells][MSD_GEOM]
+    double lhalf[3];        // smallest L_c (0.5 - 1e-6) over the frames: an entry beyond lhalf - max|dc| may wrap again
+    int64_t Fp;
+    int32_t n_cells;
+    int32_t _pad;
+};
+
+// threshold of the raw entries of coordinate comp (see above); +inf without the 2-pass form
+__device__ __forceinline__ double dcom_thr(const Dcom &dc, int comp)
+{
+    return dc.dcT ? dc.lhalf[comp] - __longlong_as_double((long long)dc.dcmax[comp]) : __builtin_inf();
+}
+
+// entry k of coordinate `comp`: wrap(x - dc_k) with the cell of frame k - 1, the arithmetic of wrap_delta_t<true>
+__device__ __forceinline__ double dcom_fix(const Dcom &dc, int comp, int k, double x)
+{
+    const double *__restrict__ g = dc.geom + (size_t)(dc.n_cells == 1 || k == 0 ? 0 : k - 1) * MSD_GEOM;
+    double v = x - dc.dcT[(size_t)comp * dc.Fp + k];
+    if (g[18 + comp] != 0.0) {
+        const double shift = 0.0 - 0.5 - 1e-7;
+        double t = v * g[9 + 4 * comp] - shift;
+        t = t - floor(t);
+        v = (t + shift) * g[4 * comp];
+    }
+    return v;
+}
+
+// a column that arrived in LDS by DMA: one coalesced pass (the caller's barrier follows)
+template <int T>
+__device__ __forceinline__ void dcom_column(const Dcom &dc, int comp, double *u, int F)
+{
+    for (int k = threadIdx.x; k < F; k += T) u[k] = dcom_fix(dc, comp, k, u[k]);
+}
+
 template <int TF, int TA, int THREADS, bool ORTHO>
 __global__ __launch_bounds__(THREADS) void delta_transpose_kernel(const double *__restrict__ pos,
                                                                   const double *__restrict__ com,
                                                                   const double *__restrict__ geom,
                                                                   int n_cells, int64_t N, int F, int64_t Fp,
                                                                   int64_t a_begin, int64_t a_end,
-                                                                  double *__restrict__ DT)
+                                                                  double *__restrict__ DT,
+                                                                  const double *__restrict__ masses, double *__restrict__ cpart)
 {
     constexpr int KG = THREADS / TA;      // frame groups of the workgroup
     constexpr int FPT = TF / KG;          // consecutive frames per thread
@@ -158,6 +231,21 @@ __global__ __launch_bounds__(THREADS) void delta_transpose_kernel(const double *
             }
         }
     }
+    if (cpart) {
+        // 2-pass form: the tile's share of sum_a m_a p_a for this thread's own frames (a wave = the TA = 64 atoms of one
+        // frame group): lanes by shuffles in fixed order, one row of cpart[tile][F][3] per frame
+        static_assert(TA == 64, "one wave per frame group");
+        const double m = atom_ok ? masses[a] : 0.0;
+#pragma unroll
+        for (int j = 1; j <= FPT; j++) {
+            const int k = kb - 1 + j;
+            const double sx = wave_sum_dpp(m * px[j]), sy = wave_sum_dpp(m * py[j]), sz = wave_sum_dpp(m * pz[j]);
+            if (al == 63 && k < F) {
+                double *o = cpart + ((size_t)blockIdx.x * (size_t)F + (size_t)k) * 3;
+                o[0] = sx; o[1] = sy; o[2] = sz;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 1; j <= FPT; j++) {
         const int k = kb - 1 + j;
@@ -182,10 +270,66 @@ __global__ __launch_bounds__(THREADS) void delta_transpose_kernel(const double *
     }
 }
 
+// 2-pass form: c_k = (sum over the atom tiles of cpart[t][k]) / M in tile order, dc[comp][k] = c_k - c_k-1 (dc[.][0] = 0)
+constexpr int COMF_FRAMES = 64, COMF_GROUPS = MSD_THREADS / COMF_FRAMES;
+__global__ __launch_bounds__(MSD_THREADS) void com_finish_kernel(const double *__restrict__ cpart, int ntiles, int F, int64_t Fp,
+                                                                 double total_mass, double *__restrict__ dcT,
+                                                                 double *__restrict__ CT, unsigned long long *__restrict__ dcmax)
+{
+    // a block = 64 frames (and the one before them); four thread groups share the tiles (contiguous quarters, eight loads
+    // in flight per thread: a serial walk over 153 tiles paid a memory latency per tile, 0.15 ms on 20 workgroups)
+    __shared__ double part[COMF_GROUPS][COMF_FRAMES + 1][3];
+    __shared__ double cs[COMF_FRAMES + 1][3];
+    const int k0 = blockIdx.x * COMF_FRAMES;
+    const int g = threadIdx.x / COMF_FRAMES, kk = threadIdx.x % COMF_FRAMES;
+    const int per = (ntiles + COMF_GROUPS - 1) / COMF_GROUPS, t0 = min(g * per, ntiles), t1 = min(t0 + per, ntiles);
+    for (int q = kk; q < COMF_FRAMES + 1; q += COMF_FRAMES) {
+        const int k = k0 - 1 + q;       // frames k0 - 1 .. k0 + 63
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        if (k >= 0 && k < F) {
+            for (int t = t0; t < t1; t += 8) {
+                double v[8][3];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const double *__restrict__ c = cpart + ((size_t)min(t + e, t1 - 1) * (size_t)F + (size_t)k) * 3;
+                    v[e][0] = c[0]; v[e][1] = c[1]; v[e][2] = c[2];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if (t + e < t1) { sx += v[e][0]; sy += v[e][1]; sz += v[e][2]; }
+            }
+        }
+        part[g][q][0] = sx; part[g][q][1] = sy; part[g][q][2] = sz;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < (COMF_FRAMES + 1) * 3; q += MSD_THREADS) {
+        const int f = q / 3, c = q % 3;
+        double sum = 0.0;
+        for (int gg = 0; gg < COMF_GROUPS; gg++) sum += part[gg][f][c];
+        cs[f][c] = sum / total_mass;
+    }
+    __syncthreads();
+    if (threadIdx.x < COMF_FRAMES) {
+        const int k = k0 + threadIdx.x;
+        if (k < F) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double d = k == 0 ? 0.0 : cs[threadIdx.x + 1][c] - cs[threadIdx.x][c];
+                dcT[(size_t)c * Fp + k] = d;
+                CT[(size_t)c * Fp + k] = cs[threadIdx.x + 1][c];      // (only differences C[k + m] - C[k] enter the sums)
+                atomicMax(&dcmax[c], (unsigned long long)__double_as_longlong(fabs(d)));      // (non-negative doubles order as integers)
+            }
+            CT[(size_t)3 * Fp + k] = 0.0;
+        }
+    }
+}
+
 // in-place inclusive prefix sum of u[0..F) held in LDS by the whole workgroup: every thread
 // owns one contiguous chunk (serial sum, then serial rewrite), the 256 chunk totals are scanned
 // with wave shuffles -- two barriers per column instead of two per 256 elements.
-__device__ __forceinline__ void lds_scan(double *u, int F, double *wtot, double carry_init)
+// thr / evt (2-pass form): evt is set for the whole workgroup when some entry of the column exceeds thr in magnitude
+__device__ __forceinline__ void lds_scan(double *u, int F, double *wtot, double carry_init, double thr = __builtin_inf(),
+                                         bool *evt = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // odd chunk length: lanes then start an odd number of doubles apart, so the strided LDS accesses of a
@@ -193,15 +337,29 @@ __device__ __forceinline__ void lds_scan(double *u, int F, double *wtot, double 
     const int chunk = ((F + MSD_THREADS - 1) / MSD_THREADS) | 1;
     const int k0 = min(tid * chunk, F), k1 = min(k0 + chunk, F);
     double s = 0.0;
-    for (int k = k0; k < k1; k++) s += u[k];
+    bool big = false;
+    for (int k = k0; k < k1; k++) {
+        const double x = u[k];
+        big |= fabs(x) > thr;
+        s += x;
+    }
+    const bool wbig = evt ? __any(big) != 0 : false;
     double v = s;                                   // inclusive scan of the chunk totals
     for (int off = 1; off < 64; off <<= 1) {
         double n = __shfl_up(v, off, 64);
         if (lane >= off) v += n;
     }
     __syncthreads();
-    if (lane == 63) wtot[wv] = v;
+    if (lane == 63) {
+        wtot[wv] = v;
+        if (evt) wtot[MSD_THREADS / 64 + wv] = wbig ? 1.0 : 0.0;       // (the flags ride behind the totals: no barrier of their own)
+    }
     __syncthreads();
+    if (evt) {
+        double any = 0.0;
+        for (int q = 0; q < MSD_THREADS / 64; q++) any += wtot[MSD_THREADS / 64 + q];
+        *evt = any > 0.0;
+    }
     double run = carry_init + (v - s);              // exclusive prefix of this thread's chunk
     for (int q = 0; q < wv; q++) run += wtot[q];
     for (int k = k0; k < k1; k++) {
@@ -209,6 +367,33 @@ __device__ __forceinline__ void lds_scan(double *u, int F, double *wtot, double 
         u[k] = run;
     }
     __syncthreads();
+}
+
+template <int T>
+__device__ __forceinline__ void lds_scan_t(double *u, int F, double *wtot, double thr = __builtin_inf(), bool *evt = nullptr);
+
+// prefix sums of a column that sits in LDS (barrier done).  2-pass form: the raw column is scanned and C[k] subtracted --
+// unless an entry could wrap again under the centre-of-mass step (rare: see the header); then `reload` brings the raw
+// column back (its own barriers) and it is corrected entry by entry before the scan.
+template <int T, typename Reload>
+__device__ __forceinline__ void scan_column(const Dcom &dc, int comp, double *u, int F, double *red, Reload &&reload)
+{
+    if (!dc.dcT) {
+        lds_scan_t<T>(u, F, red, __builtin_inf(), nullptr);
+        return;
+    }
+    bool evt = false;
+    lds_scan_t<T>(u, F, red, dcom_thr(dc, comp), &evt);
+    if (evt) {
+        reload();
+        dcom_column<T>(dc, comp, u, F);
+        __syncthreads();
+        lds_scan_t<T>(u, F, red, __builtin_inf(), nullptr);
+    } else {
+        const double *__restrict__ cb = dc.CT + (size_t)comp * dc.Fp;
+        for (int k = threadIdx.x; k < F; k += T) u[k] -= cb[k];
+        __syncthreads();
+    }
 }
 
 struct MsdGroup {
@@ -227,12 +412,12 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__
                                                                 const int32_t *__restrict__ perm,
                                                                 const MsdGroup *__restrict__ groups,
                                                                 const int32_t *__restrict__ windows, int W,
-                                                                double *__restrict__ partial)
+                                                                double *__restrict__ partial, Dcom dc)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double *u = reinterpret_cast<double *>(lds_raw);  // [F]
     double *wsum = u + F;                             // [W]
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const int tid = threadIdx.x;
     const MsdGroup gr = groups[blockIdx.x];
     double acc[WREG > 0 ? WREG : 1];
@@ -245,13 +430,16 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel(const double *__
         const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
         __syncthreads();
         // columns start 256-B aligned and are padded to a multiple of 32 frames: 16-B loads
-        for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
-            const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
-            u[k] = v2.x;
-            if (k + 1 < F) u[k + 1] = v2.y;
-        }
-        __syncthreads();
-        lds_scan(u, F, red, 0.0);
+        auto load_raw = [&]() {
+            for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
+                const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
+                u[k] = v2.x;
+                if (k + 1 < F) u[k + 1] = v2.y;
+            }
+            __syncthreads();
+        };
+        load_raw();
+        scan_column<MSD_THREADS>(dc, c % 3, u, F, red, [&]() { __syncthreads(); load_raw(); });
         if (WREG > 0) {
 #pragma unroll
             for (int w = 0; w < WREG; w++) {
@@ -331,11 +519,11 @@ template <int WT>
 __global__ __launch_bounds__(MSD_THREADS) void msd_comb_kernel(const double *__restrict__ DT, int64_t Fp, int F,
                                                                const int32_t *__restrict__ perm,
                                                                const MsdGroup *__restrict__ groups, int d, int W,
-                                                               int Wstride, double *__restrict__ partial)
+                                                               int Wstride, double *__restrict__ partial, Dcom dc)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double *u = reinterpret_cast<double *>(lds_raw);  // [F]
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const int tid = threadIdx.x;
     const MsdGroup gr = groups[blockIdx.x];
     const int nq = (F + d - 1) / d;                    // longest comb
@@ -347,13 +535,16 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_kernel(const double *__r
         const int64_t atom = perm[gr.start + c / 3];
         const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
         __syncthreads();
-        for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
-            const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
-            u[k] = v2.x;
-            if (k + 1 < F) u[k + 1] = v2.y;
-        }
-        __syncthreads();
-        lds_scan(u, F, red, 0.0);
+        auto load_raw = [&]() {
+            for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
+                const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
+                u[k] = v2.x;
+                if (k + 1 < F) u[k + 1] = v2.y;
+            }
+            __syncthreads();
+        };
+        load_raw();
+        scan_column<MSD_THREADS>(dc, c % 3, u, F, red, [&]() { __syncthreads(); load_raw(); });
         for (int t = tid; t < ntask; t += MSD_THREADS) {
             const int r = t % d, J0 = (t / d) * COMB_B;
             const int lim = (F - r + d - 1) / d - J0;   // valid comb entries of this task (from J0 on)
@@ -376,11 +567,11 @@ template <int WT>
 __global__ __launch_bounds__(MSD_THREADS) void msd_comb_db_kernel(const double *__restrict__ DT, int64_t Fp, int F,
                                                                   const int32_t *__restrict__ perm,
                                                                   const MsdGroup *__restrict__ groups, int d, int W,
-                                                                  int Wstride, double *__restrict__ partial)
+                                                                  int Wstride, double *__restrict__ partial, Dcom dc)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double *ubuf = reinterpret_cast<double *>(lds_raw);  // [2][Fp]
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const MsdGroup gr = groups[blockIdx.x];
     const int nq = (F + d - 1) / d;                    // longest comb
@@ -406,7 +597,12 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_db_kernel(const double *
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of column c has landed
         __syncthreads();                                    // everyone's has; column c - 1 is fully consumed
         if (c + 1 < ncol) issue(c + 1, (c + 1) & 1);        // streams in behind the scan and the comb arithmetic
-        lds_scan(u, F, red, 0.0);
+        scan_column<MSD_THREADS>(dc, c % 3, u, F, red, [&]() {
+            __syncthreads();
+            issue(c, c & 1);                                // (rare) the raw column again, behind the next one
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        });
         for (int t = tid; t < ntask; t += MSD_THREADS) {
             const int r = t % d, J0 = (t / d) * COMB_B;
             const int lim = (F - r + d - 1) / d - J0;   // valid comb entries of this task (from J0 on)
@@ -431,21 +627,35 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_db_kernel(const double *
 // column load, scan and arithmetic.  The time origin k = 0 (r = 0, e = 0) is left out as in the reference
 // (amof/msd.py:200); lags beyond W - 1 are computed and dropped.
 template <int T>
-__device__ __forceinline__ void lds_scan_t(double *u, int F, double *wtot)
+__device__ __forceinline__ void lds_scan_t(double *u, int F, double *wtot, double thr, bool *evt)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chunk = ((F + T - 1) / T) | 1;        // odd: strided LDS accesses of a wave spread over the banks
     const int k0 = min(tid * chunk, F), k1 = min(k0 + chunk, F);
     double s = 0.0;
-    for (int k = k0; k < k1; k++) s += u[k];
+    bool big = false;
+    for (int k = k0; k < k1; k++) {
+        const double x = u[k];
+        big |= fabs(x) > thr;
+        s += x;
+    }
+    const bool wbig = evt ? __any(big) != 0 : false;
     double v = s;
     for (int off = 1; off < 64; off <<= 1) {
         double n = __shfl_up(v, off, 64);
         if (lane >= off) v += n;
     }
     __syncthreads();
-    if (lane == 63) wtot[wv] = v;
+    if (lane == 63) {
+        wtot[wv] = v;
+        if (evt) wtot[T / 64 + wv] = wbig ? 1.0 : 0.0;
+    }
     __syncthreads();
+    if (evt) {
+        double any = 0.0;
+        for (int q = 0; q < T / 64; q++) any += wtot[T / 64 + q];
+        *evt = any > 0.0;
+    }
     double run = v - s;
     for (int q = 0; q < wv; q++) run += wtot[q];
     for (int k = k0; k < k1; k++) {
@@ -459,14 +669,16 @@ __device__ __forceinline__ void lds_scan_t(double *u, int F, double *wtot)
 // BLK = 0: the block that starts the comb (e0 = 0): entry e only has e predecessors; BLK = 1: the second block
 // (e0 = L); BLK = 2: any later one.  A pair with entry 0 -- (0, s) in the first block, (0, L) at the start of the
 // second -- carries the factor m0 (0 for the residue class that holds the time origin).  GUARD: entries >= nq do not exist.
-template <int L, int BLK, bool GUARD>
-__device__ __forceinline__ void stream_block(const double *__restrict__ ub, int d, int e0, int nq, double m0,
-                                             double (&ring)[L], double (&acc)[L + 1])
+// FOLD (2-pass form): cb[.] = C[k] of the comb entry, subtracted as it enters the ring (a row of zeros for a column that
+// was corrected entry by entry)
+template <int L, int BLK, bool GUARD, bool FOLD>
+__device__ __forceinline__ void stream_block(const double *__restrict__ ub, const double *__restrict__ cb, int d, int e0, int nq,
+                                             double m0, double (&ring)[L], double (&acc)[L + 1])
 {
 #pragma unroll
     for (int s = 0; s < L; s++) {
         if (!GUARD || e0 + s < nq) {
-            const double x = ub[(size_t)d * (e0 + s)];
+            const double x = FOLD ? ub[(size_t)d * (e0 + s)] - cb[(size_t)d * (e0 + s)] : ub[(size_t)d * (e0 + s)];
 #pragma unroll
             for (int w = 1; w <= L; w++) {
                 if (!(BLK == 0 && w > s)) {                     // (compile time)
@@ -480,15 +692,15 @@ __device__ __forceinline__ void stream_block(const double *__restrict__ ub, int 
     }
 }
 
-template <int L, int T>
+template <int L, int T, bool FOLD>
 __global__ __launch_bounds__(T) void msd_stream_kernel(const double *__restrict__ DT, int64_t Fp, int F,
                                                        const int32_t *__restrict__ perm,
                                                        const MsdGroup *__restrict__ groups, int d, int W, int Wstride,
-                                                       double *__restrict__ partial)
+                                                       double *__restrict__ partial, Dcom dc)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double *u = reinterpret_cast<double *>(lds_raw);  // [Fp]
-    __shared__ double red[T / 64];
+    __shared__ double red[2 * (T / 64)];     // (wave totals | event flags of the scan)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const MsdGroup gr = groups[blockIdx.x];
     const int ncol = 3 * gr.count;
@@ -513,21 +725,40 @@ __global__ __launch_bounds__(T) void msd_stream_kernel(const double *__restrict_
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        lds_scan_t<T>(u, F, red);
+        const double *__restrict__ cb = nullptr;
+        if (FOLD) {
+            bool evt = false;
+            lds_scan_t<T>(u, F, red, dcom_thr(dc, c % 3), &evt);
+            if (evt) {      // (rare) an entry could wrap again under the centre-of-mass step: entry by entry, then scan again
+                __syncthreads();
+                for (int blk = wave; blk * 64 < ngran; blk += T / 64) {
+                    const int gran = blk * 64 + lane;
+                    if (gran < ngran) dma16(col + 2 * gran, reinterpret_cast<unsigned char *>(u) + (size_t)blk * 1024);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                dcom_column<T>(dc, c % 3, u, F);
+                __syncthreads();
+                lds_scan_t<T>(u, F, red);
+            }
+            cb = dc.CT + (size_t)(evt ? 3 : c % 3) * dc.Fp + r;
+        } else {
+            lds_scan_t<T>(u, F, red);
+        }
         if (active) {
             const double *__restrict__ ub = u + r;
 #pragma unroll
             for (int k = 0; k < L; k++) ring[k] = 0.0;
             int e0 = 0;
             if (nq_min >= 2 * L) {
-                stream_block<L, 0, false>(ub, d, 0, nq, m0, ring, acc);
-                stream_block<L, 1, false>(ub, d, L, nq, m0, ring, acc);
-                for (e0 = 2 * L; e0 + L <= nq_min; e0 += L) stream_block<L, 2, false>(ub, d, e0, nq, m0, ring, acc);
-                for (; e0 < nq; e0 += L) stream_block<L, 2, true>(ub, d, e0, nq, m0, ring, acc);
+                stream_block<L, 0, false, FOLD>(ub, cb, d, 0, nq, m0, ring, acc);
+                stream_block<L, 1, false, FOLD>(ub, cb, d, L, nq, m0, ring, acc);
+                for (e0 = 2 * L; e0 + L <= nq_min; e0 += L) stream_block<L, 2, false, FOLD>(ub, cb, d, e0, nq, m0, ring, acc);
+                for (; e0 < nq; e0 += L) stream_block<L, 2, true, FOLD>(ub, cb, d, e0, nq, m0, ring, acc);
             } else {
-                stream_block<L, 0, true>(ub, d, 0, nq, m0, ring, acc);
-                if (L < nq) stream_block<L, 1, true>(ub, d, L, nq, m0, ring, acc);
-                for (e0 = 2 * L; e0 < nq; e0 += L) stream_block<L, 2, true>(ub, d, e0, nq, m0, ring, acc);
+                stream_block<L, 0, true, FOLD>(ub, cb, d, 0, nq, m0, ring, acc);
+                if (L < nq) stream_block<L, 1, true, FOLD>(ub, cb, d, L, nq, m0, ring, acc);
+                for (e0 = 2 * L; e0 < nq; e0 += L) stream_block<L, 2, true, FOLD>(ub, cb, d, e0, nq, m0, ring, acc);
             }
         }
     }
@@ -554,12 +785,12 @@ template <int WT>
 __global__ __launch_bounds__(MSD_THREADS) void msd_comb_hi_kernel(const double *__restrict__ DT, int64_t Fp, int F,
                                                                   const int32_t *__restrict__ perm,
                                                                   const MsdGroup *__restrict__ groups, int d, int w0,
-                                                                  int Wn, int Wstride, double *__restrict__ partial)
+                                                                  int Wn, int Wstride, double *__restrict__ partial, Dcom dc)
 {
     constexpr int NP = COMB_B + WT - 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double *u = reinterpret_cast<double *>(lds_raw);  // [F]
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const int tid = threadIdx.x;
     const MsdGroup gr = groups[blockIdx.x];
     const int nq = (F + d - 1) / d;
@@ -571,13 +802,16 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_hi_kernel(const double *
         const int64_t atom = perm[gr.start + c / 3];
         const double *__restrict__ col = DT + (size_t)(3 * atom + c % 3) * Fp;
         __syncthreads();
-        for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
-            const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
-            u[k] = v2.x;
-            if (k + 1 < F) u[k + 1] = v2.y;
-        }
-        __syncthreads();
-        lds_scan(u, F, red, 0.0);
+        auto load_raw = [&]() {
+            for (int k = 2 * tid; k < F; k += 2 * MSD_THREADS) {
+                const double2 v2 = *reinterpret_cast<const double2 *>(col + k);
+                u[k] = v2.x;
+                if (k + 1 < F) u[k + 1] = v2.y;
+            }
+            __syncthreads();
+        };
+        load_raw();
+        scan_column<MSD_THREADS>(dc, c % 3, u, F, red, [&]() { __syncthreads(); load_raw(); });
         for (int t = tid; t < ntask; t += MSD_THREADS) {
             const int r = t % d, J0 = (t / d) * COMB_B;
             const int limp = (F - r + d - 1) / d - J0 - w0;   // valid partner entries of this task
@@ -624,7 +858,7 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_comb_global_kernel(const doub
     constexpr int NP = COMB_B + WT - 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double *T = reinterpret_cast<double *>(lds_raw);  // [nq][R]
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const int tid = threadIdx.x;
     const MsdGroup gr = groups[blockIdx.x];
     const int nq = (F + d - 1) / d;
@@ -685,7 +919,7 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_reduce_kernel(const double *_
                                                                  const int32_t *__restrict__ sp_group_first, int W,
                                                                  double *__restrict__ sumsq)
 {
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const int s = blockIdx.x / W, w = blockIdx.x % W;
     const int g0 = sp_group_first[s], g1 = sp_group_first[s + 1];
     double acc = 0.0;
@@ -702,7 +936,7 @@ __global__ __launch_bounds__(MSD_THREADS) void scan_column_kernel(const double *
                                                                   int64_t Fp, int F, double *OUT)
 {
     __shared__ double u[SCAN_SEG];
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     __shared__ double carry_s;
     const size_t col = blockIdx.x;
     double carry = x0 ? x0[col] : 0.0;
@@ -728,7 +962,7 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_group_kernel_global(const dou
                                                                        const int32_t *__restrict__ windows, int W,
                                                                        double *__restrict__ partial)
 {
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const MsdGroup gr = groups[blockIdx.x];
     for (int w = blockIdx.y; w < W; w += gridDim.y) {
         const int m = windows[w];
@@ -832,7 +1066,7 @@ __global__ __launch_bounds__(MSD_THREADS) void direct_reduce_kernel(const double
                                                                     const int64_t *__restrict__ sp_first, int S,
                                                                     int64_t N, double *__restrict__ msd)
 {
-    __shared__ double red[MSD_THREADS / 64];
+    __shared__ double red[2 * (MSD_THREADS / 64)];     // (wave totals | event flags of the scan)
     const int t = blockIdx.x;
     const double *__restrict__ row = sq + (size_t)t * 3 * N;
     double total = 0.0;
@@ -920,15 +1154,22 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
     AMOF_TRY(stage_positions(ctx, t, &pos_dev));
     const int64_t Fp = (F + 31) / 32 * 32;
     const size_t dt_bytes = (size_t)3 * N * Fp * sizeof(double);
-    void *d_geom, *d_perm, *d_groups, *d_win, *d_mass = nullptr, *d_com = nullptr, *d_DT, *d_UT = nullptr, *d_part, *d_out;
-    AMOF_TRY(upload(ctx, SLOT_GEOM, grec.data(), grec.size() * sizeof(double), &d_geom));
-    AMOF_TRY(upload(ctx, SLOT_PERM, perm.data(), perm.size() * sizeof(int32_t), &d_perm));
-    AMOF_TRY(upload(ctx, SLOT_TILES, groups.data(), groups.size() * sizeof(MsdGroup), &d_groups));
-    AMOF_TRY(upload(ctx, SLOT_AUX0, windows, (size_t)W * sizeof(int32_t), &d_win));
-    void *d_sgf;
-    AMOF_TRY(upload(ctx, SLOT_PAIRS, sp_group_first.data(), sp_group_first.size() * sizeof(int32_t), &d_sgf));
+    const void *d_geom, *d_perm, *d_groups, *d_win, *d_mass = nullptr, *d_sgf;
+    void *d_com = nullptr, *d_DT, *d_UT = nullptr, *d_part, *d_out;
+    // the call's small tables travel in ONE copy (a copy costs ~5 us of queue time however small: six of them were a tenth
+    // of the pipeline)
+    UploadPack pk;
+    const int i_geom = pk.add(grec.data(), grec.size() * sizeof(double));
+    const int i_perm = pk.add(perm.data(), perm.size() * sizeof(int32_t));
+    const int i_groups = pk.add(groups.data(), groups.size() * sizeof(MsdGroup));
+    const int i_win = pk.add(windows, (size_t)W * sizeof(int32_t));
+    const int i_sgf = pk.add(sp_group_first.data(), sp_group_first.size() * sizeof(int32_t));
+    const int i_mass = remove_com ? pk.add(t->masses, (size_t)N * sizeof(double)) : -1;
+    AMOF_TRY(upload_pack(ctx, SLOT_GEOM, pk));
+    d_geom = pk.ptr<double>(i_geom); d_perm = pk.ptr<int32_t>(i_perm); d_groups = pk.ptr<MsdGroup>(i_groups);
+    d_win = pk.ptr<int32_t>(i_win); d_sgf = pk.ptr<int32_t>(i_sgf);
     if (remove_com) {
-        AMOF_TRY(upload(ctx, SLOT_AUX1, t->masses, (size_t)N * sizeof(double), &d_mass));
+        d_mass = pk.ptr<double>(i_mass);
         AMOF_TRY(ensure(ctx, SLOT_AUX2, (size_t)F * 3 * sizeof(double), &d_com));
     }
     AMOF_TRY(ensure(ctx, SLOT_AUX3, dt_bytes, &d_DT));
@@ -938,30 +1179,62 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
     // transposition tile: 32 frames x 64 atoms, 1024 threads (two consecutive frames per thread).  Measured on the
     // MI355X for the headline shape (profiles/r02/msd_transpose_shapes.txt): 0.52 ms = 4.5 TB/s of read + write; a
     // flat copy of the same bytes (torch) takes 0.46 ms.  Four or eight frames per thread: 0.57 / 1.18 ms.
-    auto transpose = [&](const double *com_dev, int64_t a0, int64_t a1) -> hipError_t {
-        constexpr int TF = 32, TA = 64, TH = 1024;
+    constexpr int TR_TA = 64;
+    auto transpose = [&](const double *com_dev, int64_t a0, int64_t a1, double *cpart) -> hipError_t {
+        constexpr int TF = 32, TA = TR_TA, TH = 1024;
         auto go = [&](auto kern) -> hipError_t {
             const size_t lds = (size_t)TF * (3 * TA + 1) * sizeof(double);
             hipError_t e = allow_max_lds((const void *)kern);
             if (e != hipSuccess) return e;
             dim3 grid((unsigned)((a1 - a0 + TA - 1) / TA), (unsigned)((F + TF - 1) / TF));
             hipLaunchKernelGGL(kern, grid, dim3(TH), lds, ctx->stream, pos_dev, com_dev, (const double *)d_geom,
-                               (int)t->n_cells, N, (int)F, Fp, a0, a1, (double *)d_DT);
+                               (int)t->n_cells, N, (int)F, Fp, a0, a1, (double *)d_DT, (const double *)d_mass, cpart);
             return hipGetLastError();
         };
         return hg.all_ortho ? go(delta_transpose_kernel<TF, TA, TH, true>) : go(delta_transpose_kernel<TF, TA, TH, false>);
     };
-    if (!unwrap) {
+    // windows in arithmetic progression from 0 (the only thing WindowMsd produces): comb kernels
+    int comb_d = 0;
+    if (W >= 2 && W <= (lds_resident ? 128 : 256) && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
+        comb_d = windows[1];
+        for (int w = 0; w < W; w++)
+            if ((int64_t)windows[w] != (int64_t)w * comb_d) comb_d = 0;
+    }
+    // 2-pass form (see the header): diagonal cells, the whole system in one call, the series LDS-resident
+    Dcom dcom = {nullptr, nullptr, nullptr, (const double *)d_geom, {0.0, 0.0, 0.0}, Fp, (int32_t)t->n_cells, 0};
+    const bool fold = !unwrap && remove_com && !com_ext && hg.all_ortho && lds_resident && atom_begin == 0 && atom_end == N &&
+                      !getenv("AMOF_MSD_NOFOLD");
+    if (fold) {
+        const int ntiles = (int)((N + TR_TA - 1) / TR_TA);
+        void *d_cpart, *d_dcT;
+        AMOF_TRY(ensure(ctx, SLOT_AUX6, (size_t)ntiles * (size_t)F * 3 * sizeof(double), &d_cpart));
+        // dc [3][Fp] | C [4][Fp] (row 3 = zeros) | max |dc| [3] (bits)
+        AMOF_TRY(ensure(ctx, SLOT_AUX4, (size_t)7 * Fp * sizeof(double) + 32, &d_dcT));
+        double *d_CT = (double *)d_dcT + (size_t)3 * Fp;
+        unsigned long long *d_dcmax = (unsigned long long *)(d_CT + (size_t)4 * Fp);
+        AMOF_HIP_TRY(ctx, hipMemsetAsync(d_dcmax, 0, 3 * sizeof(unsigned long long), ctx->stream));
+        AMOF_HIP_TRY(ctx, transpose((const double *)nullptr, 0, N, (double *)d_cpart));
+        hipLaunchKernelGGL(com_finish_kernel, dim3((unsigned)((F + COMF_FRAMES - 1) / COMF_FRAMES)), dim3(MSD_THREADS), 0,
+                           ctx->stream, (const double *)d_cpart, ntiles, (int)F, Fp, total_mass, (double *)d_dcT, d_CT, d_dcmax);
+        dcom.dcT = (const double *)d_dcT;
+        dcom.CT = d_CT;
+        dcom.dcmax = d_dcmax;
+        for (int c = 0; c < 3; c++) {
+            double lmin = 1e300;
+            for (int64_t k = 0; k < t->n_cells; k++) lmin = std::min(lmin, fabs(t->cell[9 * k + 4 * c]));
+            dcom.lhalf[c] = t->pbc[c] ? lmin * (0.5 - 1e-6) : 1e300;       // (a non-periodic axis never wraps)
+        }
+    } else if (!unwrap) {
         if (remove_com && !com_ext) {
             hipLaunchKernelGGL(com_kernel, dim3((unsigned)F), dim3(MSD_THREADS), 0, ctx->stream, pos_dev,
                                (const double *)d_mass, N, total_mass, (double *)d_com);
         }
         // only the atoms of this call's range are transposed (atom-sharded ranks each do their share)
-        AMOF_HIP_TRY(ctx, transpose(remove_com && com_ext ? com_ext : (const double *)d_com, atom_begin, atom_end));
+        AMOF_HIP_TRY(ctx, transpose(remove_com && com_ext ? com_ext : (const double *)d_com, atom_begin, atom_end, nullptr));
     } else {
         // the unwrapped centre of mass needs every atom: all columns are transposed and scanned
         AMOF_TRY(ensure(ctx, SLOT_AUX4, dt_bytes, &d_UT));
-        AMOF_HIP_TRY(ctx, transpose((const double *)nullptr, 0, N));
+        AMOF_HIP_TRY(ctx, transpose((const double *)nullptr, 0, N, nullptr));
         hipLaunchKernelGGL(scan_column_kernel, dim3((unsigned)(3 * N)), dim3(MSD_THREADS), 0, ctx->stream,
                            (const double *)d_DT, pos_dev, Fp, (int)F, (double *)d_UT);
         if (remove_com) {
@@ -981,20 +1254,13 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
     }
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_dom_begin(ctx, "msd_global");
-    // windows in arithmetic progression from 0 (the only thing WindowMsd produces): comb kernels
-    int comb_d = 0;
-    if (W >= 2 && W <= (lds_resident ? 128 : 256) && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
-        comb_d = windows[1];
-        for (int w = 0; w < W; w++)
-            if ((int64_t)windows[w] != (int64_t)w * comb_d) comb_d = 0;
-    }
     if (lds_resident) {
         auto launch = [&](auto kern) -> hipError_t {
             hipError_t e = allow_max_lds((const void *)kern);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds_need, ctx->stream,
                                (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
-                               (const int32_t *)d_win, (int)W, (double *)d_part);
+                               (const int32_t *)d_win, (int)W, (double *)d_part, dcom);
             return hipGetLastError();
         };
         // two column buffers (the next column streams in behind the arithmetic) when they fit twice per CU
@@ -1006,11 +1272,11 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
             if (db)
                 hipLaunchKernelGGL(kern_db, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
                                    (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
-                                   comb_d, (int)std::min(W, 32), (int)W, (double *)d_part);
+                                   comb_d, (int)std::min(W, 32), (int)W, (double *)d_part, dcom);
             else
                 hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
                                    (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
-                                   comb_d, (int)std::min(W, 32), (int)W, (double *)d_part);
+                                   comb_d, (int)std::min(W, 32), (int)W, (double *)d_part, dcom);
             return hipGetLastError();
         };
         // windows 32 .. W-1 in further passes of up to 32 (each re-reads the columns)
@@ -1020,7 +1286,7 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(MSD_THREADS), lds, ctx->stream,
                                (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
-                               comb_d, w0, wn, (int)W, (double *)d_part);
+                               comb_d, w0, wn, (int)W, (double *)d_part, dcom);
             return hipGetLastError();
         };
         ctx->last_path = comb_d > 0 ? "msd_comb" : "msd_group";
@@ -1034,11 +1300,13 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
             if (e2 != hipSuccess) return e2;
             hipLaunchKernelGGL(kern, dim3((unsigned)groups.size()), dim3(streamT), (size_t)Fp * sizeof(double), ctx->stream,
                                (const double *)d_DT, Fp, (int)F, (const int32_t *)d_perm, (const MsdGroup *)d_groups,
-                               comb_d, (int)W, (int)W, (double *)d_part);
+                               comb_d, (int)W, (int)W, (double *)d_part, dcom);
             ctx->last_path = "msd_stream";
             return hipGetLastError();
         };
-#define AMOF_STREAM(L) (streamT == 128 ? launch_stream(msd_stream_kernel<L, 128>) : launch_stream(msd_stream_kernel<L, 256>))
+#define AMOF_STREAM(L)                                                                                                     \
+    (fold ? (streamT == 128 ? launch_stream(msd_stream_kernel<L, 128, true>) : launch_stream(msd_stream_kernel<L, 256, true>))  \
+          : (streamT == 128 ? launch_stream(msd_stream_kernel<L, 128, false>) : launch_stream(msd_stream_kernel<L, 256, false>)))
         if (stream && W <= 8) e = AMOF_STREAM(7);
         else if (stream && W <= 16) e = AMOF_STREAM(15);
         else if (stream && W <= 24) e = AMOF_STREAM(23);

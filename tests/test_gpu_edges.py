@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from amof_amd import _hip
-from amof_amd.frames import PackedTrajectory
+from amof_amd.frames import Frame, PackedTrajectory
 from amof_amd.rdf import Rdf
 from amof_amd.msd import WindowMsd
 from oracle import clib, numpy_oracle as no
@@ -319,3 +319,33 @@ def test_headline_shape_properties(hip_ctx):
     from amof_amd import data as eldata
     for e, r in zip(el, ref):
         np.testing.assert_allclose(msd.data[eldata.chemical_symbols[int(e)]].values, r, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("jitter", [0.0, 0.003])
+def test_msd_two_pass_form_and_its_rare_columns(hip_ctx, jitter):
+    """Round 4: diagonal cells fold the centre of mass into the transposition (pos read once) and the window kernels subtract
+    C[k] from the scanned RAW columns -- unless an entry lies within the centre-of-mass step of half the cell, in which case
+    the column is corrected entry by entry with the wrap arithmetic.  A gas whose atoms jump anywhere in the box from frame
+    to frame puts such entries into every column (and gives the centre of mass a large step); a quiet walk has none.  Every
+    window-kernel family, against the numpy restatement and against the 3-pass form (AMOF_MSD_NOFOLD)."""
+    rng = np.random.default_rng(77)
+    F, N = 330, 40
+    cell = np.diag([9.0, 11.0, 13.0])
+    numbers = np.array([1, 8] * (N // 2))
+    cells = np.array([cell * (1 + jitter * rng.normal()) for _ in range(F)]) if jitter else cell
+    gas = PackedTrajectory(rng.uniform(0, 1, (F, N, 3)) @ cell, cells, numbers)
+    walk = H.random_walk(Frame(numbers, rng.uniform(0, 1, (N, 3)) @ cell, cell), F, 0.05, 3, cell_jitter=jitter, ortho=True)
+    for packed in (gas, walk):
+        for window, want in ((np.arange(0, 160, 64), "msd_stream"), (np.arange(0, 160, 8), "msd_comb"),
+                             (np.array([0, 3, 50, 161]), "msd_group")):
+            window = window.astype(np.int32)
+            got, kinds = hip_ctx.msd_window(packed, window)
+            assert hip_ctx.last_path() == want
+            with H_env(AMOF_MSD_NOFOLD="1"):
+                old, _ = hip_ctx.msd_window(packed, window)
+                assert hip_ctx.last_path() == want
+            np.testing.assert_allclose(got, old, rtol=1e-11, atol=1e-9)
+            elements, ref = no.window_msd_fast(packed.pos, packed.cell, packed.numbers, packed.masses, window)
+            for e, r in zip(elements, ref):
+                g = got[kinds.index(int(e))] / (packed.numbers == e).sum() / (F - window)
+                np.testing.assert_allclose(g, r, rtol=1e-9, atol=1e-12)
