@@ -1182,7 +1182,8 @@ struct RdfCellArgs {
     const uint32_t *keyoff;   // [S*S] offset of the pair (sa, sb) in the LDS histogram (pair key * nbins)
     const uint32_t *keyU;     // [npk] offset of pair key k in U ((lo * S + hi) * nbins)
     int32_t nx, ny, nz, npk;
-    int32_t frames_grid;      // frames in the grid (rounded up to a multiple of 8 with the XCD mapping)
+    int32_t frames_grid;      // frame slots of the launch (rounded up to a multiple of 8 with the XCD mapping)
+    int32_t fpc;              // frames per workgroup (round 4): the same block of atoms over fpc frames, ONE histogram flush
     int32_t cpt;              // centre atoms per thread (the workgroup covers 256 * cpt consecutive atoms)
     int32_t trim;             // 1: rows trimmed per lane to the cells within reach (AMOF_RDF_NOTRIM=1: the full 5-cell runs)
 };
@@ -1203,21 +1204,30 @@ __global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs c
     unsigned *koff = hist + (size_t)ca.npk * a.nbins;                // [S * S]
     const int tid = threadIdx.x;
     const int S = a.S, nbins = a.nbins;
-    // all workgroups of a frame on one XCD (its quantised records stay in that L2)
-    unsigned fl = blockIdx.y, bx = blockIdx.x;
+    // all workgroups of a frame on one XCD (its quantised records stay in that L2).  A workgroup keeps its block of atoms
+    // for a chunk of fpc frames (the XCD's own: slot, slot + 8, ...) and flushes its histogram once: flushing per frame was
+    // ~2e6 u64 global atomics a frame on configs[4], 854 MB of the kernel's writes (profiles/r03/pmc_cfg4.json)
+    unsigned chunk = blockIdx.y, bx = blockIdx.x, xcd = 0, fstep = 1;
     if (fa.xcd_map) {
         const unsigned long long lin = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
         const unsigned long long kk = lin >> 3;
-        fl = (unsigned)(kk / gridDim.x) * 8u + (unsigned)(lin & 7ull);
+        xcd = (unsigned)(lin & 7ull);
+        chunk = (unsigned)(kk / gridDim.x);
         bx = (unsigned)(kk % gridDim.x);
+        fstep = 8;
     }
-    if ((int)fl >= fa.nf) return;
+    if ((int)(chunk * (unsigned)ca.fpc * fstep + xcd) >= fa.nf) return;
     for (int k = tid; k < ca.npk * nbins; k += CELL_THREADS) hist[k] = 0u;
     for (int k = tid; k < S * S; k += CELL_THREADS) koff[k] = ca.keyoff[k];
     __syncthreads();
-
-    const int f = fa.f_base + (int)fl;
     const int N = (int)a.N;
+    const int nx = ca.nx, ny = ca.ny, nz = ca.nz;
+    const float half_m_guard = fa.half_m_guard, nb_hi = fa.nb_hi;
+
+    for (int ff = 0; ff < ca.fpc; ff++) {
+    const unsigned fl = (chunk * (unsigned)ca.fpc + (unsigned)ff) * fstep + xcd;
+    if ((int)fl >= fa.nf) break;
+    const int f = fa.f_base + (int)fl;
     const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
     const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
     const int gi = a.n_cells == 1 ? 0 : f;
@@ -1226,9 +1236,7 @@ __global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs c
     float sc[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
-    const int nx = ca.nx, ny = ca.ny, nz = ca.nz;
     const uint32_t *__restrict__ st = ca.start3 + (size_t)fl * ((size_t)nx * ny * nz * S + 1);
-    const float half_m_guard = fa.half_m_guard, nb_hi = fa.nb_hi;
 
     for (int c = 0; c < ca.cpt; c++) {
         const int i = ((int)bx * ca.cpt + c) * CELL_THREADS + tid;
@@ -1307,6 +1315,9 @@ __global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs c
 #pragma unroll
                     for (int u = 0; u < CELL_UNROLL; u++)
                         qv[u] = j < j1 ? *reinterpret_cast<const uint4 *>(Qf + min(j + u, j1 - 1)) : make_uint4(0, 0, 0, 0);
+                    // (round 4, measured and rejected: the tile kernel's always-add histogram with trash words per row -- every
+                    //  lane adds, only candidates near a bin edge branch: 0.0606 -> 0.0692 ms / frame on configs[4]; three
+                    //  quarters of the gathered candidates are out of range and now pay the binning tail too)
 #pragma unroll
                     for (int u = 0; u < CELL_UNROLL; u++) {
                         if (j + u < j1) {
@@ -1328,6 +1339,7 @@ __global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs c
             }
         }
     }
+    }   // frames of the chunk
     __syncthreads();
     for (int k = tid; k < ca.npk * nbins; k += CELL_THREADS) {
         const unsigned v = hist[k];
@@ -1796,6 +1808,17 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                         ca.f.nf = (int32_t)nf;
                         ca.f.xcd_map = nf >= 16 ? 1 : 0;
                         ca.frames_grid = (int32_t)(ca.f.xcd_map ? (nf + 7) / 8 * 8 : nf);
+                        // frames per workgroup: >= ~8k workgroups per launch (32 per CU), at most 8 frames (the u32 counters of
+                        // a chunk: 8 frames x 512 atoms x ~300 partners stay far below 2^32)
+                        {
+                            const int64_t slots = ca.f.xcd_map ? ca.frames_grid / 8 : ca.frames_grid;       // per XCD
+                            int64_t fpc = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)gx * ca.frames_grid / 8192));
+                            if (const char *fe = getenv("AMOF_RDF_CELL_FPC")) fpc = std::max(1, atoi(fe));      // experiments / tests
+                            fpc = std::min<int64_t>(fpc, slots);
+                            ca.fpc = (int32_t)fpc;
+                            const int64_t chunks = (slots + fpc - 1) / fpc;
+                            ca.frames_grid = (int32_t)(ca.f.xcd_map ? chunks * 8 : chunks);
+                        }
                         dim3 grid(gx, (unsigned)ca.frames_grid);
                         if (launches == 0) timing_dom_begin(ctx, "rdf_cell");
                         hipError_t e = ortho ? allow_max_lds((const void *)rdf_cell_kernel<true>)

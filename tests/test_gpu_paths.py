@@ -865,3 +865,18 @@ def test_rdf_triangular_frame_lattice_on_faces_and_edges(hip_ctx):
                 assert hip_ctx.last_path() == "rdf_tile_tri"
             ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rm, nb, cell_list=True)
             assert np.array_equal(got, ref), (cell[2].tolist(), rm, nb)
+
+
+@pytest.mark.parametrize("frames", [5, 19])
+def test_rdf_cell_kernel_frame_chunks(hip_ctx, frames):
+    """round 4: a workgroup of the cell-list kernel keeps its block of atoms over a chunk of frames (one histogram flush):
+    chunk sizes that divide the launch, that leave a ragged last chunk, and that exceed it -- with (>= 16 frames) and without
+    the XCD mapping of the frames"""
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (3, 3, 3)), frames, 0.05, 71)
+    kinds, sp = H.species_of(packed.numbers)
+    ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), 6.0, 600, cell_list=True)
+    for fpc in ("1", "2", "3", "64"):
+        with _env(AMOF_RDF_FORCE_CELL="1", AMOF_RDF_CELL_FPC=fpc):
+            got, _, _ = hip_ctx.rdf_accumulate(packed, 6.0, 600)
+            assert hip_ctx.last_path() == "rdf_cell"
+        assert np.array_equal(got, ref), (frames, fpc)
