@@ -48,6 +48,17 @@ CLOCK_HZ = 2.4e9            # nominal engine clock
 N_SIMD = 1024               # 256 CUs x 4 SIMDs
 
 
+def sources_stamp():
+    """sha256 over the kernel sources (the same files profiles/tools/pmc_to_json.py stamps profiles/traffic.json and
+    profiles/valu_model.json with): counter-derived annotations are only quoted for the kernels they were collected on"""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("rdf.hip", "msd.hip", "quant.hip", "amof_internal.h", "guard_math.h"):
+        with open(os.path.join(ROOT, "amof_amd", "csrc", fn), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def make_trajectory(device, reps, n_frames, sigma, seed):
     """Synthetic trajectory generated directly in HBM (torch), float64."""
     from tests import helpers as H
@@ -90,8 +101,10 @@ def cpu_baseline(packed, rmax, nbins, window, rdf_frames):
             cores = min(cores, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    cores = min(cores, 16)                   # one GPU's share of the host
-    per = 2
+    cores_usable = cores                     # what the process may use (affinity, cgroup quota)
+    if os.environ.get("AMOF_BENCH_CPU_THREADS"):
+        cores = max(1, min(cores, int(os.environ["AMOF_BENCH_CPU_THREADS"])))
+    per = 2 if cores <= 32 else 1            # (bounded sample: about the same CPU seconds whatever the core count)
     pick2 = np.linspace(0, F - 1, per * cores).astype(int)
     pos_p = packed.pos[torch.as_tensor(pick2, device=packed.pos.device)].cpu().numpy()
     t0 = time.perf_counter()
@@ -110,7 +123,7 @@ def cpu_baseline(packed, rmax, nbins, window, rdf_frames):
         pass
     return {
         "value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-        "all_cores": {"value": F / (t_rdf_par * F + t_msd), "unit": "frames/s", "cores": cores,
+        "all_cores": {"value": F / (t_rdf_par * F + t_msd), "unit": "frames/s", "cores": cores, "cores_usable": cores_usable,
                       "sample": "RDF: %d frames on %d threads, %.4f s/frame aggregate; MSD as above (single thread)"
                                 % (per * cores, cores, t_rdf_par)},
         "cpu_model": cpu_model,
@@ -340,7 +353,9 @@ def supplementary(device, local_rank, ctx, do_verify=True):
             out["from_text"] = {
                 "workload": "headline system from a %d-frame XYZ text file (%.0f MB): Rdf(dr=0.01, half cell)" % (Ft, size / 1e6),
                 "read_then_analyse_frames_per_s": Ft / t_serial, "streamed_frames_per_s": Ft / t_stream,
-                "parse_only_frames_per_s": Ft / t_parse, "parse_GB_per_s": size / t_parse / 1e9,
+                "parse_only_frames_per_s": Ft / t_parse, "parse_GB_per_s": size / t_parse / 1e9, "file_bytes": size,
+                "parse_note": "rate on THIS %.0f MB file (page cache warm, /dev/shm); DESIGN 4.4 quotes 6.6 GB/s for a 2.6 GB file "
+                              "-- thread start-up and the frame index weigh more on a small one" % (size / 1e6),
                 "host_threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
                 "streamed_equals_whole": same, "verified": (bool(ok_t and same) if do_verify else None)}
         del pt, host, whole
@@ -589,10 +604,15 @@ def main():
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by
         # profiles/tools/pmc_to_json.py), recorded under profiles/ for this exact workload; null for any other size
         traffic = {}
+        stamp = sources_stamp()
+        counters_current = {"traffic": False, "valu_model": False, "sources_sha256": stamp}
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and (N, F, world) == (9792, 5000, 1):
             with open(tfile) as fh:
-                traffic = json.load(fh).get("cfg3", {})
+                tj = json.load(fh)
+            counters_current["traffic"] = tj.get("_sources_sha256") == stamp
+            if counters_current["traffic"]:       # (counters of another build of the kernels are not quoted)
+                traffic = tj.get("cfg3", {})
         # The bound that applies to the all-pairs kernel is VALU issue.  roofline_valu prices the kernel's
         # EXECUTED vector instructions (SQ counters of this very launch shape, profiles/tools/collect_pmc.sh ->
         # pmc_to_json.py -> profiles/valu_model.json) with the issue cost of each class measured on the box in-kernel
@@ -609,8 +629,10 @@ def main():
         mfile = os.path.join(ROOT, "profiles", "valu_model.json")
         if os.path.exists(mfile) and (N, F, world) == (9792, 5000, 1):
             with open(mfile) as fh:
-                model = json.load(fh).get("rdf_tile_kernel_fast")
-            if model and model.get("effective_clock_ghz"):
+                mj = json.load(fh)
+            model = mj.get("rdf_tile_kernel_fast")
+            counters_current["valu_model"] = mj.get("_sources_sha256") == stamp
+            if model and model.get("effective_clock_ghz") and counters_current["valu_model"]:
                 lo, hi = model["valu_issue_cycles_per_simd"]
                 clock = model["effective_clock_ghz"] * 1e9
                 live_cycles = t_rdf * clock
@@ -658,8 +680,10 @@ def main():
                                  "fraction is tiny by construction and north_star's >= 50 % HBM target does not apply "
                                  "to this kernel -- see valu_issue and pair_evals_per_s"},
             "pair_evals_per_s": pairs / t_rdf, "pairs_in_range_per_s": in_range / t_rdf,
-            "roofline_valu": roofline_valu, "valu_issue": valu,
-            "roofline_msd": {"kernel": "msd pipeline (com + delta_transpose + msd_comb + reduce)", "bound": "hbm",
+            "roofline_valu": roofline_valu, "valu_issue": valu, "counter_files_match_built_sources": counters_current,
+            "roofline_msd": {"kernel": "msd pipeline, 2-pass form (delta_transpose with the tile sums of m p | com_finish | msd_stream | reduce)"
+                                       if world == 1 else "msd pipeline (com share + all-reduce | delta_transpose | msd_stream | reduce)",
+                             "bound": "hbm",
                              "achieved": msd_bytes / mean["msd_all"] / 1e9, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": msd_bytes / mean["msd_all"] / 1e9 / HBM_PEAK_GBPS,
                              "traffic": traffic.get("msd_pipeline"), "pipeline_seconds": mean["msd_all"],

@@ -26,10 +26,22 @@ import re
 import sys
 from collections import defaultdict
 
+import hashlib
+
 N_SIMD = 1024
 N_XCC = 8           # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs: cycles of the launch = value / 8
 src, dst = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def source_stamp():
+    """sha256 over the kernel sources these counters belong to: bench.py drops roofline_valu / traffic when the built sources
+    no longer match (the numbers would be another kernel's)"""
+    h = hashlib.sha256()
+    for fn in ("rdf.hip", "msd.hip", "quant.hip", "amof_internal.h", "guard_math.h"):
+        with open(os.path.join(root, "amof_amd", "csrc", fn), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def short(name):
@@ -104,6 +116,7 @@ if "cn" in tables:
     out["cfg3"]["cn_pipeline"] = traffic(tables["cn"], lambda k: True)
 if "cfg4" in tables:
     out["cfg4_64_frames"] = {k: traffic(tables["cfg4"], lambda q, k=k: q == k) for k in tables["cfg4"]}
+out["_sources_sha256"] = source_stamp()
 with open(os.path.join(root, "profiles", "traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 
@@ -147,6 +160,7 @@ for wl, prefix in (("rdf", "rdf_tile_kernel_fast"), ("cfg4", "rdf_cell_kernel"))
             "lds_instructions": c.get("SQ_INSTS_LDS"), "lds_atomics": c.get("SQ_INSTS_LDS_ATOMIC"),
             "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT"), "lds_active_cycles": c.get("SQ_LDS_IDX_ACTIVE"),
         }
+model["_sources_sha256"] = source_stamp()
 with open(os.path.join(root, "profiles", "valu_model.json"), "w") as fh:
     json.dump(model, fh, indent=1)
 print("wrote", sorted(tables), "->", dst, "; traffic.json, valu_model.json")
