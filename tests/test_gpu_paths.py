@@ -880,3 +880,21 @@ def test_rdf_cell_kernel_frame_chunks(hip_ctx, frames):
             got, _, _ = hip_ctx.rdf_accumulate(packed, 6.0, 600)
             assert hip_ctx.last_path() == "rdf_cell"
         assert np.array_equal(got, ref), (frames, fpc)
+
+
+def test_rdf_range_kernel_is_what_a_thin_long_cell_selects(hip_ctx):
+    """housekeeping (round-3 review): the 2-level range kernel is not dead code -- a cell too thin for five cells of rmax / 2
+    across (so no 3-D cell list) but many cutoffs long selects it WITHOUT any switch; the 1-D slab list beside it"""
+    rng = np.random.default_rng(12)
+    cell = np.diag([19.0, 21.0, 150.0])
+    N = 4000
+    numbers = np.where(np.arange(N) % 3 == 0, 8, 1)
+    packed = PackedTrajectory(rng.uniform(0, 1, (2, N, 3)) @ cell, cell, numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    got, _, _ = hip_ctx.rdf_accumulate(packed, 9.0, 900)
+    assert hip_ctx.last_path() == "rdf_range"
+    with _env(AMOF_RDF_NORANGE="1"):
+        slab, _, _ = hip_ctx.rdf_accumulate(packed, 9.0, 900)
+        assert hip_ctx.last_path() == "rdf_tile_zf"
+    ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), 9.0, 900, cell_list=True)
+    assert np.array_equal(got, ref) and np.array_equal(slab, ref)
