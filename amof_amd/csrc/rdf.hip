@@ -527,7 +527,9 @@ struct TriConst {
 // ZF: (ux, uy) are the centre's folded coordinates already corrected for the piece's slab wrap, zif its f32 slab
 // coordinate; else the raw folded ones (per-pair correction).  NEAR: 0 no second image possible anywhere; 1 only for pairs
 // inside the guard band of the last bin edge, which are flagged anyway: the slow path tests, the fast path does not; 2 the
-// fast path tests y, 3 y and z (the slow path always both: every instruction of its body costs, so NEAR = 0 has none).
+// fast path tests y, 3 y and z (the slow path always both: every instruction of its body costs, so NEAR = 0 has none);
+// 4 as 2, for cells whose second image along y is COMMON (hexagonal: 15 % of the pairs): the slow path evaluates the
+// twin image with the same f32 candidate instead of parking the pair for the canonical arithmetic.
 template <bool ZF, int NEAR, bool XW>
 __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, const TriConst &tc, bool live, float half_m_guard,
                                              uint32_t ux, uint32_t uy, uint32_t uz, uint4 qj, float &q, float zif,
@@ -548,7 +550,7 @@ __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, co
     if (!live_all) q = live ? q : __builtin_inff();
     q = __builtin_fminf(q, clampv);
     bool flag = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
-    if (NEAR == 2) flag |= live && (fabsf(fy) > tc.near_y);
+    if (NEAR == 2 || NEAR == 4) flag |= live && (fabsf(fy) > tc.near_y);
     if (NEAR == 3) flag |= live && ((fabsf(fy) > tc.near_y) | (fabsf(dz) > tc.near_z));
     atomicAdd(&hist[(int)q], 1u);
     return flag;
@@ -567,6 +569,28 @@ __device__ __forceinline__ void rdf_pair_refine_tri(unsigned *hist, const RdfFas
     if (ZF) { ix = (int)(qj.x - ux); iy = (int)(qj.y - uy); iz = (int)(qj.z - uz); }
     else tri_int(qj, ux, uy, uz, tc.kx, tc.ky, ix, iy, iz);
     const int cand = (int)q;
+    if (NEAR == 4) {
+        const float fy = (float)iy, fzb = (float)iz * sc[8];
+        const bool ny = fabsf(fy) > tc.near_y;
+        const bool nother = (fabsf(fzb) > tc.near_z) | (fabsf((float)tri_xwrap<true>(tc.c10, ix, fy)) > tc.near_x);
+        if (ny && !nother) {
+            // the image one cell further along y, its x wrapped again with the new y: same chain, same guards.  Both
+            // candidates stand unless one of them is within the guard of a bin edge -- then both are taken back and the
+            // pair goes the canonical way (every listed image)
+            const float fy2 = fy - copysignf(4294967296.f, fy);
+            float q2 = tri_q<true>(sc, tc.c10, ix, fy2, fzb);
+            q2 = __builtin_fminf(q2, (float)fa.a.nbins + 0.5f);
+            const bool u2 = !(fabsf(__builtin_amdgcn_fractf(q2) - 0.5f) < fa.half_m_guard);
+            const bool u1 = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < fa.half_m_guard);
+            if (u1 | u2) {
+                atomicAdd(&hist[cand], 0xffffffffu);
+                park();
+            } else {
+                atomicAdd(&hist[(int)q2], 1u);          // (bin nbins = the first trash word: out of range)
+            }
+            return;
+        }
+    }
     // (+inf on an axis without second image; x: only pairs inside the guard band of the last bin edge can matter)
     if (NEAR > 0 && ((fabsf((float)iy) > tc.near_y) | (fabsf((float)iz * sc[8]) > tc.near_z) |
                      (fabsf(XW ? (float)tri_xwrap<true>(tc.c10, ix, (float)iy) : fmaf((float)iy, tc.c10, (float)ix)) > tc.near_x))) {
@@ -667,15 +691,15 @@ __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
 template <bool ORTHO, bool CULL, bool IMG = false, bool ZFK = false, int TRI = -1>
 __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
-    // TRI >= 0: general cells in the orthogonalised lattice frame (fast_quad_tri; TRI % 4: near tests, TRI / 4: x wrap with the y term)
+    // TRI >= 0: general cells in the orthogonalised lattice frame (fast_quad_tri; TRI % 5: near tests, TRI / 5: x wrap with the y term)
     static_assert(!ZFK || (ORTHO && !IMG) || TRI >= 0, "f32 slab coordinates: diagonal cells (no image queue) or TRI");
     static_assert(TRI < 0 || (!ORTHO && !IMG && ZFK), "TRI: general cells, f32 slab coordinates, its own queue");
     // always-add histogram scheme (fast_bin<AA>): measured per variant (profiles/r02/tile_variants.txt) -- the plain
     // general-cell variant spills under it (nine scales, 96 VGPRs) and keeps the masked form
     constexpr bool AA = ORTHO || IMG;
     constexpr bool QUEUE = IMG || TRI >= 0;     // parked pairs, drained densely by the canonical arithmetic
-    constexpr int NEAR = TRI >= 0 ? TRI % 4 : 0;
-    constexpr bool XW = TRI >= 4;
+    constexpr int NEAR = TRI >= 0 ? TRI % 5 : 0;
+    constexpr bool XW = TRI >= 5;
     const RdfArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // double-buffered tiles: J (512 entries) and the centre sub-tile (128 entries)
@@ -1526,8 +1550,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         //   Y: tau_y = R / L11 - 1/2 <= 0: unique; else pairs with |iy| > 1/2 - tau_y are flagged near (<= 1.5 % of them)
         //   Z: likewise with L22 (= the slab axis's perpendicular height)
         bool tri = false;
-        int tri_code = 0, tri_ax0 = -1, tri_ax1 = -1, tri_axis = 0;       // code: near tests (0 none, 1 slow path only, 2 fast path y, 3 y + z) + 4 x (x wrap with the y term)
-        double tri_share = 0.0, tri_l10_bins = 0.0, tri_c10 = 0.0;
+        int tri_code = 0, tri_ax0 = -1, tri_ax1 = -1, tri_axis = 0;       // code: near tests (0 none, 1 slow path only, 2 fast path y, 3 y + z, 4 y with its twin image) + 5 x (x wrap with the y term)
+        double tri_share = 0.0, tri_l10_bins = 0.0, tri_c10 = 0.0, tri_tau = 0.0;
         std::vector<double> tri_fold;       // [nc][2] kx, ky
         std::vector<double> tri_rec;        // [nc][9] L00 L10 L11 L22 (bins per 2^-32), thr_y (units), thr_z (bins), kx, ky, thr_x (units)
         const double two32_ = 1.0 / 4294967296.0;
@@ -1545,8 +1569,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 const int a0 = sw ? (tri_axis + 2) % 3 : (tri_axis + 1) % 3, a1 = sw ? (tri_axis + 1) % 3 : (tri_axis + 2) % 3;
                 const int ordt[3] = {a0, a1, tri_axis};
                 bool ok = true;
-                double slack = 1e300, share = 0.0, l10b = 0.0, c10max = 0.0;
+                double slack = 1e300, share = 0.0, l10b = 0.0, c10max = 0.0, tau_max = 0.0;
                 int near = 0;
+                bool twin = false;
                 std::vector<double> fold((size_t)nc * 2), rec((size_t)nc * 9);
                 for (int64_t k = 0; k < nc && ok; k++) {
                     const double *c = t->cell + 9 * k;
@@ -1559,7 +1584,11 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     slack = std::min(slack, 0.5 - 1e-6 - (R / L[0] + 0.5 * fabs(L[3]) / L[0]));
                     c10max = std::max(c10max, fabs(L[3]) / L[0]);
                     double tau_y = R / L[4] - 0.5 + 1e-9, tau_z = R / L[8] - 0.5 + 1e-9;
-                    if (tau_y > 0.0075 || tau_z > 0.0075) { ok = false; break; }
+                    // (a second image along y up to 9 % of the pairs either side -- hexagonal cells: 7.7 % -- is evaluated by the
+                    //  slow path itself, near mode 4; along z only what the canonical queue can take)
+                    if (tau_y > 0.09 || tau_z > 0.0075) { ok = false; break; }
+                    if (tau_y > 0.0075) twin = true;
+                    tau_max = std::max(tau_max, std::max(tau_y, 0.0));
                     // A second image along y (z) can only be in range when L11 / 2 < R0 (canonical rmax with rounding slack);
                     // then its in-plane components are below rho = sqrt(R0^2 - (L/2)^2), the evaluated image's differ from them
                     // by at most the lattice offsets, so it lies between L - R0 and sqrt(D2max) from the origin.  When that
@@ -1581,7 +1610,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     if (0.5 * L[0] >= R0) tau_x = -1.0;
                     else if (covered(L[0], 0.0, 0.0)) near = std::max(near, 1);
                     else { ok = false; break; }
-                    share = std::max(share, 2.0 * std::max(tau_y, 0.0) + 2.0 * std::max(tau_z, 0.0));
+                    share = std::max(share, (tau_y > 0.0075 ? 0.02 : 2.0) * std::max(tau_y, 0.0) + 2.0 * std::max(tau_z, 0.0));
                     l10b = std::max(l10b, fabs(L[3]) / dr);
                     const double c10 = L[3] / L[0], r20 = L[6] / L[0], r21 = L[7] / L[4];
                     fold[(size_t)k * 2] = r20 - c10 * r21;
@@ -1596,11 +1625,17 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 }
                 // cheaper order first: a near test costs a compare per pair, the x wrap two instructions in the chain
                 // (measured: + 8 % per compare, + 24 % for the wrap, profiles/r04/tri_experiments.txt)
-                const int code = near + (slack > 0.0 ? 0 : 4);
-                const double cost = (near == 0 ? 0.0 : near == 1 ? 0.5 : (double)(near - 1) * 1.5) + (slack > 0.0 ? 0.0 : 2.5);
+                if (twin) {
+                    if (near == 3) ok = false;      // (a common twin along y AND near tests along z: the image-aware / exact kernels)
+                    near = 4;
+                }
+                const int code = near + (slack > 0.0 ? 0 : 5);
+                const double cost = (near == 0 ? 0.0 : near == 1 ? 0.5 : near == 4 ? 6.0 : (double)(near - 1) * 1.5) +
+                                    (slack > 0.0 ? 0.0 : 2.5);
                 if (ok && (!tri || cost < best_cost)) {
                     best_cost = cost;
                     tri = true; tri_code = code; tri_ax0 = a0; tri_ax1 = a1; tri_share = share; tri_l10_bins = l10b; tri_c10 = c10max;
+                    tri_tau = tau_max;
                     tri_fold.swap(fold); tri_rec.swap(rec);
                 }
             }
@@ -1608,7 +1643,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
         if (tri) {      // (the guard of its candidate at the widest reach must leave room between the bin edges)
             double hb = 0.0;
             for (int64_t k = 0; k < nc; k++) hb = std::max(hb, geom.rec[(size_t)k * GEOM_STRIDE + 18 + tri_axis] / dr);
-            if (!(fast_guard_tri(nbins, hb, 0.5, tri_l10_bins) + (3.0 + 128.0 * tri_c10) * quant / dr + (double)nbins * 1e-12 < 0.25)) tri = false;
+            if (!(fast_guard_tri(nbins, hb, 0.5, tri_l10_bins) * (1.0 + 4.0 * tri_tau) + 2.0 * quant / dr +
+                  (1.0 + 256.0 * tri_c10) * 1.5 * csum * two32_ / dr + (double)nbins * 1e-12 < 0.25)) tri = false;
         }
         bool done = false;
         const bool fast_plain = fast;      // the cell-list / range kernels below rest on the plain criterion (cutoff clear of every half height)
@@ -1989,8 +2025,11 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 // folded coordinates: two fold roundings and the wrap constant on top of the truncation (2.5 grid units per
                 // axis instead of 1): twice the grid term; XW: the truncated f32 product c10 iy moves the x wrap and the
                 // candidate by < 1 + 256 |c10| units more (quant = 2 units of csum)
-                const double guard_m_tri = (tri_code >= 4 ? 3.0 + 128.0 * tri_c10 : 2.0) * quant / dr + (double)nbins * 1e-12;
-                const double guard_tri = fast_guard_tri(nbins, hb, gfrac, tri_l10_bins) + guard_m_tri;
+                // (in units of the x axis: |A| <= csum; 1.5 for margin)
+                const double guard_m_tri = 2.0 * quant / dr + (tri_code >= 5 || tri_code % 5 == 4 ? (1.0 + 256.0 * tri_c10) * 1.5 * csum * two32_ / dr : 0.0) +
+                                           (double)nbins * 1e-12;
+                // (the twin image of near mode 4 has |iy| up to 2^31 (1 + 2 tau): its candidate's error bound grows with it)
+                const double guard_tri = fast_guard_tri(nbins, hb, gfrac, tri_l10_bins) * (1.0 + 4.0 * tri_tau) + guard_m_tri;
                 if (!(guard_tri < 0.25)) return fail(ctx, AMOF_ECAPACITY, "TRI guard out of range");      // (checked at selection)
                 const double half = 0.5 - guard_tri;
                 float fhalf = (float)half;
@@ -2070,7 +2109,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     case 4: e = AMOF_TRI(4); break;
                     case 5: e = AMOF_TRI(5); break;
                     case 6: e = AMOF_TRI(6); break;
-                    default: e = AMOF_TRI(7); break;
+                    case 7: e = AMOF_TRI(7); break;
+                    case 8: e = AMOF_TRI(8); break;
+                    default: e = AMOF_TRI(9); break;
                     }
 #undef AMOF_TRI
                 }

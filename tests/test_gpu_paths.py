@@ -815,10 +815,17 @@ def _tri_cell(kind):
         cub = H.replicate(Frame(z.numbers, z.positions, np.diag([15.4, 15.4, 15.4])), (2, 2, 2))
         shear = np.eye(3) + np.array([[0, 0, 0], [0.03, 0, 0], [-0.015, 0.03, 0]])
         return Frame(cub.numbers, cub.positions @ shear, cub.cell @ shear)
+    if kind == "hexagonal":         # a = b, gamma = 120 degrees: 15 % of the pairs have a second image along y (twin in the slow path)
+        base = H.replicate(z, (2, 2, 2))
+        d3 = np.diag(np.diag(base.cell))
+        a_hex = float(np.sqrt(d3[0, 0] * d3[1, 1] / (np.sqrt(3.0) / 2.0)))
+        hexc = np.array([[a_hex, 0.0, 0.0], [-0.5 * a_hex, np.sqrt(3.0) / 2.0 * a_hex, 0.0], [0.0, 0.0, d3[2, 2]]])
+        frac = np.linalg.solve(np.asarray(base.cell).T, base.positions.T).T
+        return Frame(base.numbers, frac @ hexc, hexc)
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["fixture", "equal_ab", "short_c", "cubic"])
+@pytest.mark.parametrize("kind", ["fixture", "equal_ab", "short_c", "cubic", "hexagonal"])
 @pytest.mark.parametrize("jitter", [0.0, 0.004])
 def test_rdf_triangular_frame_kernel(hip_ctx, kind, jitter):
     """General cells at the reference's default cutoff (half the shortest cell LENGTH, amof/rdf.py:74): the tile kernel in
@@ -843,7 +850,7 @@ def test_rdf_triangular_frame_kernel(hip_ctx, kind, jitter):
     # a cutoff beyond half the shortest length (only the C ABI allows it): second images along that axis -- as y or z it
     # gets the near test, as x (both in-plane axes too short) the variant is refused
     big, _, _ = hip_ctx.rdf_accumulate(packed, 1.01 * rmax, 800)
-    if kind in ("equal_ab", "cubic"):
+    if kind in ("equal_ab", "cubic", "hexagonal"):
         assert hip_ctx.last_path() != "rdf_tile_tri"
     ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), 1.01 * rmax, 800, cell_list=True)
     assert np.array_equal(big, ref)
@@ -883,11 +890,11 @@ def test_rdf_cell_kernel_frame_chunks(hip_ctx, frames):
 
 
 def test_rdf_range_kernel_is_what_a_thin_long_cell_selects(hip_ctx):
-    """housekeeping (round-3 review): the 2-level range kernel is not dead code -- a cell too thin for five cells of rmax / 2
-    across (so no 3-D cell list) but many cutoffs long selects it WITHOUT any switch; the 1-D slab list beside it"""
+    """housekeeping (round-3 review): the 2-level range kernel is not dead code -- a slab-shaped cell, too thin along ONE axis
+    for five cells of rmax / 2 (so no 3-D cell list) but many cutoffs long and wide, selects it WITHOUT any switch; the 1-D slab list beside it"""
     rng = np.random.default_rng(12)
-    cell = np.diag([19.0, 21.0, 150.0])
-    N = 4000
+    cell = np.diag([19.0, 120.0, 150.0])            # a slab: thin along x only
+    N = 20000
     numbers = np.where(np.arange(N) % 3 == 0, 8, 1)
     packed = PackedTrajectory(rng.uniform(0, 1, (2, N, 3)) @ cell, cell, numbers)
     kinds, sp = H.species_of(packed.numbers)
