@@ -669,16 +669,14 @@ __device__ __forceinline__ void lds_scan_t(double *u, int F, double *wtot, doubl
 // BLK = 0: the block that starts the comb (e0 = 0): entry e only has e predecessors; BLK = 1: the second block
 // (e0 = L); BLK = 2: any later one.  A pair with entry 0 -- (0, s) in the first block, (0, L) at the start of the
 // second -- carries the factor m0 (0 for the residue class that holds the time origin).  GUARD: entries >= nq do not exist.
-// FOLD (2-pass form): cb[.] = C[k] of the comb entry, subtracted as it enters the ring (a row of zeros for a column that
-// was corrected entry by entry)
-template <int L, int BLK, bool GUARD, bool FOLD>
-__device__ __forceinline__ void stream_block(const double *__restrict__ ub, const double *__restrict__ cb, int d, int e0, int nq,
-                                             double m0, double (&ring)[L], double (&acc)[L + 1])
+template <int L, int BLK, bool GUARD>
+__device__ __forceinline__ void stream_block(const double *__restrict__ ub, int d, int e0, int nq, double m0,
+                                             double (&ring)[L], double (&acc)[L + 1])
 {
 #pragma unroll
     for (int s = 0; s < L; s++) {
         if (!GUARD || e0 + s < nq) {
-            const double x = FOLD ? ub[(size_t)d * (e0 + s)] - cb[(size_t)d * (e0 + s)] : ub[(size_t)d * (e0 + s)];
+            const double x = ub[(size_t)d * (e0 + s)];
 #pragma unroll
             for (int w = 1; w <= L; w++) {
                 if (!(BLK == 0 && w > s)) {                     // (compile time)
@@ -692,8 +690,63 @@ __device__ __forceinline__ void stream_block(const double *__restrict__ ub, cons
     }
 }
 
+// The scan in registers (round 4).  Stamps inside the kernel (profiles/r04/msd_experiments.txt) showed the in-place scan at
+// 5 - 6 us of a 20 us column: its second loop reads and writes the same LDS array, and every iteration waited for the LDS.
+// Here a thread reads its chunk (<= CH entries) at once, adds it up in registers and writes it back at once -- with, in the
+// 2-pass form, the centre-of-mass step subtracted on the way: v[] arrives holding the thread's chunk of dc (loaded from
+// global memory while the column's DMA is in flight; the sums are linear: scanning raw - dc gives U_raw - C), one register
+// array for both.  Returns "some entry could wrap again under the centre-of-mass step" (then u is left RAW).
+template <int T, int CH, bool FOLD>
+__device__ __forceinline__ bool reg_scan(double *u, int F, int chunk, double *wtot, double thr, double (&v)[CH])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k0 = min(tid * chunk, F), n = min(k0 + chunk, F) - k0;
+    bool big = false;
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const double x = i < n ? u[k0 + i] : 0.0;
+        if (FOLD) {
+            big |= fabs(x) > thr;
+            v[i] = x - v[i];
+        } else {
+            v[i] = x;
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < CH; i++) v[i] += v[i - 1];
+    const double s = v[CH - 1];
+    const bool wbig = FOLD ? __any(big) != 0 : false;
+    double incl = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        const double nb = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += nb;
+    }
+    __syncthreads();
+    if (lane == 63) {
+        wtot[wv] = incl;
+        if (FOLD) wtot[T / 64 + wv] = wbig ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    bool evt = false;
+    if (FOLD) {
+        double any = 0.0;
+        for (int q = 0; q < T / 64; q++) any += wtot[T / 64 + q];
+        evt = any > 0.0;
+    }
+    double off = incl - s;
+    for (int q = 0; q < wv; q++) off += wtot[q];
+    if (!evt) {
+#pragma unroll
+        for (int i = 0; i < CH; i++)
+            if (i < n) u[k0 + i] = v[i] + off;
+    }
+    __syncthreads();
+    return evt;
+}
+constexpr int STREAM_CH = 42;       // register scan: chunks of up to 42 entries per thread (F <= 41 T: 5248 frames at 128 threads)
+
 template <int L, int T, bool FOLD>
-__global__ __launch_bounds__(T) void msd_stream_kernel(const double *__restrict__ DT, int64_t Fp, int F,
+__global__ __launch_bounds__(T, 2) void msd_stream_kernel(const double *__restrict__ DT, int64_t Fp, int F,
                                                        const int32_t *__restrict__ perm,
                                                        const MsdGroup *__restrict__ groups, int d, int W, int Wstride,
                                                        double *__restrict__ partial, Dcom dc)
@@ -710,6 +763,8 @@ __global__ __launch_bounds__(T) void msd_stream_kernel(const double *__restrict_
     const int nq = active ? (F - r + d - 1) / d : 0;   // entries of this thread's comb
     const int nq_min = F / d;                          // every comb has at least this many
     const double m0 = r == 0 ? 0.0 : 1.0;
+    const int chunk = ((F + T - 1) / T) | 1;           // entries per thread in the scan (odd: LDS banks)
+    const bool regscan = chunk <= STREAM_CH;
     double acc[L + 1], ring[L];
 #pragma unroll
     for (int w = 0; w <= L; w++) acc[w] = 0.0;
@@ -723,27 +778,25 @@ __global__ __launch_bounds__(T) void msd_stream_kernel(const double *__restrict_
             const int gran = blk * 64 + lane;
             if (gran < ngran) dma16(col + 2 * gran, reinterpret_cast<unsigned char *>(u) + (size_t)blk * 1024);
         }
+        // (2-pass form) the thread's chunk of the centre-of-mass steps of this coordinate: in flight together with the column
+        double cc[STREAM_CH];
+        if (FOLD && regscan) {
+            const double *__restrict__ crow = dc.dcT + (size_t)(c % 3) * dc.Fp;
+            const int k0c = min(tid * chunk, F), nc = min(k0c + chunk, F) - k0c;
+#pragma unroll
+            for (int i = 0; i < STREAM_CH; i++) cc[i] = i < nc ? crow[k0c + i] : 0.0;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const double *__restrict__ cb = nullptr;
-        if (FOLD) {
-            bool evt = false;
-            lds_scan_t<T>(u, F, red, dcom_thr(dc, c % 3), &evt);
-            if (evt) {      // (rare) an entry could wrap again under the centre-of-mass step: entry by entry, then scan again
-                __syncthreads();
-                for (int blk = wave; blk * 64 < ngran; blk += T / 64) {
-                    const int gran = blk * 64 + lane;
-                    if (gran < ngran) dma16(col + 2 * gran, reinterpret_cast<unsigned char *>(u) + (size_t)blk * 1024);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                dcom_column<T>(dc, c % 3, u, F);
+        if (regscan) {
+            const bool evt = reg_scan<T, STREAM_CH, FOLD>(u, F, chunk, red, FOLD ? dcom_thr(dc, c % 3) : 0.0, cc);
+            if (FOLD && evt) {      // (rare) an entry could wrap again under the centre-of-mass step: the raw column (still in
+                dcom_column<T>(dc, c % 3, u, F);        //  LDS) entry by entry with the wrap arithmetic, then the plain scan
                 __syncthreads();
                 lds_scan_t<T>(u, F, red);
             }
-            cb = dc.CT + (size_t)(evt ? 3 : c % 3) * dc.Fp + r;
         } else {
-            lds_scan_t<T>(u, F, red);
+            lds_scan_t<T>(u, F, red);       // (FOLD is only launched when the register scan applies)
         }
         if (active) {
             const double *__restrict__ ub = u + r;
@@ -751,14 +804,14 @@ __global__ __launch_bounds__(T) void msd_stream_kernel(const double *__restrict_
             for (int k = 0; k < L; k++) ring[k] = 0.0;
             int e0 = 0;
             if (nq_min >= 2 * L) {
-                stream_block<L, 0, false, FOLD>(ub, cb, d, 0, nq, m0, ring, acc);
-                stream_block<L, 1, false, FOLD>(ub, cb, d, L, nq, m0, ring, acc);
-                for (e0 = 2 * L; e0 + L <= nq_min; e0 += L) stream_block<L, 2, false, FOLD>(ub, cb, d, e0, nq, m0, ring, acc);
-                for (; e0 < nq; e0 += L) stream_block<L, 2, true, FOLD>(ub, cb, d, e0, nq, m0, ring, acc);
+                stream_block<L, 0, false>(ub, d, 0, nq, m0, ring, acc);
+                stream_block<L, 1, false>(ub, d, L, nq, m0, ring, acc);
+                for (e0 = 2 * L; e0 + L <= nq_min; e0 += L) stream_block<L, 2, false>(ub, d, e0, nq, m0, ring, acc);
+                for (; e0 < nq; e0 += L) stream_block<L, 2, true>(ub, d, e0, nq, m0, ring, acc);
             } else {
-                stream_block<L, 0, true, FOLD>(ub, cb, d, 0, nq, m0, ring, acc);
-                if (L < nq) stream_block<L, 1, true, FOLD>(ub, cb, d, L, nq, m0, ring, acc);
-                for (e0 = 2 * L; e0 < nq; e0 += L) stream_block<L, 2, true, FOLD>(ub, cb, d, e0, nq, m0, ring, acc);
+                stream_block<L, 0, true>(ub, d, 0, nq, m0, ring, acc);
+                if (L < nq) stream_block<L, 1, true>(ub, d, L, nq, m0, ring, acc);
+                for (e0 = 2 * L; e0 < nq; e0 += L) stream_block<L, 2, true>(ub, d, e0, nq, m0, ring, acc);
             }
         }
     }
@@ -1202,8 +1255,13 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
     }
     // 2-pass form (see the header): diagonal cells, the whole system in one call, the series LDS-resident
     Dcom dcom = {nullptr, nullptr, nullptr, (const double *)d_geom, {0.0, 0.0, 0.0}, Fp, (int32_t)t->n_cells, 0};
+    // (the streaming window kernel subtracts C in its register scan: chunks of at most STREAM_CH entries per thread)
+    const bool stream = lds_resident && comb_d >= 64 && comb_d <= 256 && W <= 32 && (size_t)Fp * sizeof(double) <= 150 * 1024 &&
+                        !getenv("AMOF_MSD_NOSTREAM");
+    const int streamT = comb_d <= 128 ? 128 : 256;
+    const bool stream_regscan = (((F + streamT - 1) / streamT) | 1) <= STREAM_CH;
     const bool fold = !unwrap && remove_com && !com_ext && hg.all_ortho && lds_resident && atom_begin == 0 && atom_end == N &&
-                      !getenv("AMOF_MSD_NOFOLD");
+                      !(stream && !stream_regscan) && !getenv("AMOF_MSD_NOFOLD");
     if (fold) {
         const int ntiles = (int)((N + TR_TA - 1) / TR_TA);
         void *d_cpart, *d_dcT;
@@ -1292,9 +1350,6 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
         ctx->last_path = comb_d > 0 ? "msd_comb" : "msd_group";
         hipError_t e;
         // streaming comb kernel: one thread per residue class (window spacing 64 .. 256 frames, <= 32 windows)
-        const bool stream = comb_d >= 64 && comb_d <= 256 && W <= 32 && (size_t)Fp * sizeof(double) <= 150 * 1024 &&
-                            !getenv("AMOF_MSD_NOSTREAM");
-        const int streamT = comb_d <= 128 ? 128 : 256;
         auto launch_stream = [&](auto kern) -> hipError_t {
             hipError_t e2 = allow_max_lds((const void *)kern);
             if (e2 != hipSuccess) return e2;
