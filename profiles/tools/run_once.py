@@ -22,7 +22,7 @@ if what == "cfg4":
     base = H.replicate(H.zif4_frame(), (7, 7, 8))
     shear = np.eye(3) + np.array([[0, 0.15, 0.10], [0, 0, 0.20], [0, 0, 0]])
     sheared = Frame(base.numbers, base.positions @ shear, base.cell @ shear)
-    host = H.random_walk(sheared, min(F, 64), 0.05, 51)
+    host = H.random_walk(sheared, min(F, int(os.environ.get("RUN_ONCE_CFG4_FRAMES", "64"))), 0.05, 51)
     packed = PackedTrajectory(torch.tensor(host.pos, device=dev), host.cell, host.numbers)
     for _ in range(reps):
         ctx.rdf_accumulate(packed, 10.0, 999)
