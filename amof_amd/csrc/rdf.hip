@@ -528,8 +528,11 @@ struct TriConst {
 // coordinate; else the raw folded ones (per-pair correction).  NEAR: 0 no second image possible anywhere; 1 only for pairs
 // inside the guard band of the last bin edge, which are flagged anyway: the slow path tests, the fast path does not; 2 the
 // fast path tests y, 3 y and z (the slow path always both: every instruction of its body costs, so NEAR = 0 has none);
-// 4 as 2, for cells whose second image along y is COMMON (hexagonal: 15 % of the pairs): the slow path evaluates the
-// twin image with the same f32 candidate instead of parking the pair for the canonical arithmetic.
+// 4 for cells whose second image along y is COMMON (hexagonal: 15 % of the pairs): the fast path evaluates BOTH candidates
+// of every pair -- the image it minimised and the one a cell further along y, x wrapped again with the new y; for a pair
+// that is not near, the second lands in the trash words -- and a pair with either candidate inside the guard of a bin
+// edge is parked for the canonical arithmetic (first version: the twin in the slow path, which then ran on every
+// wave-level pair with a few live lanes: 4.4x the diagonal cell's cost per visited pair).
 template <bool ZF, int NEAR, bool XW>
 __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, const TriConst &tc, bool live, float half_m_guard,
                                              uint32_t ux, uint32_t uy, uint32_t uz, uint4 qj, float &q, float zif,
@@ -550,9 +553,16 @@ __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, co
     if (!live_all) q = live ? q : __builtin_inff();
     q = __builtin_fminf(q, clampv);
     bool flag = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
-    if (NEAR == 2 || NEAR == 4) flag |= live && (fabsf(fy) > tc.near_y);
+    if (NEAR == 2) flag |= live && (fabsf(fy) > tc.near_y);
     if (NEAR == 3) flag |= live && ((fabsf(fy) > tc.near_y) | (fabsf(dz) > tc.near_z));
     atomicAdd(&hist[(int)q], 1u);
+    if (NEAR == 4) {
+        float q2 = tri_q<true>(sc, tc.c10, ix, fy - copysignf(4294967296.f, fy), dz);
+        if (!live_all) q2 = live ? q2 : __builtin_inff();
+        q2 = __builtin_fminf(q2, clampv);
+        flag |= !(fabsf(__builtin_amdgcn_fractf(q2) - 0.5f) < half_m_guard);
+        atomicAdd(&hist[(int)q2], 1u);
+    }
     return flag;
 }
 
@@ -563,33 +573,21 @@ __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, co
 template <bool ZF, int NEAR, bool XW, typename Park>
 __device__ __forceinline__ void rdf_pair_refine_tri(unsigned *hist, const RdfFastArgs &fa, const float *sc, const TriConst &tc,
                                                     const double *sc64, float q, uint32_t ux, uint32_t uy, uint32_t uz,
-                                                    uint4 qj, Park &&park)
+                                                    uint4 qj, float zif, float clampv, Park &&park)
 {
     int ix, iy, iz;
     if (ZF) { ix = (int)(qj.x - ux); iy = (int)(qj.y - uy); iz = (int)(qj.z - uz); }
     else tri_int(qj, ux, uy, uz, tc.kx, tc.ky, ix, iy, iz);
     const int cand = (int)q;
     if (NEAR == 4) {
-        const float fy = (float)iy, fzb = (float)iz * sc[8];
-        const bool ny = fabsf(fy) > tc.near_y;
-        const bool nother = (fabsf(fzb) > tc.near_z) | (fabsf((float)tri_xwrap<true>(tc.c10, ix, fy)) > tc.near_x);
-        if (ny && !nother) {
-            // the image one cell further along y, its x wrapped again with the new y: same chain, same guards.  Both
-            // candidates stand unless one of them is within the guard of a bin edge -- then both are taken back and the
-            // pair goes the canonical way (every listed image)
-            const float fy2 = fy - copysignf(4294967296.f, fy);
-            float q2 = tri_q<true>(sc, tc.c10, ix, fy2, fzb);
-            q2 = __builtin_fminf(q2, (float)fa.a.nbins + 0.5f);
-            const bool u2 = !(fabsf(__builtin_amdgcn_fractf(q2) - 0.5f) < fa.half_m_guard);
-            const bool u1 = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < fa.half_m_guard);
-            if (u1 | u2) {
-                atomicAdd(&hist[cand], 0xffffffffu);
-                park();
-            } else {
-                atomicAdd(&hist[(int)q2], 1u);          // (bin nbins = the first trash word: out of range)
-            }
-            return;
-        }
+        // one of the pair's two candidates is within the guard of a bin edge: both provisional counts back (the second
+        // candidate recomputed exactly as fast_bin_tri formed it), the pair goes the canonical way with every listed image
+        const float fy = (float)iy, dzf = ZF ? __uint_as_float(qj.w) - zif : (float)iz * sc[8];
+        const float q2 = __builtin_fminf(tri_q<true>(sc, tc.c10, ix, fy - copysignf(4294967296.f, fy), dzf), clampv);
+        atomicAdd(&hist[cand], 0xffffffffu);
+        atomicAdd(&hist[(int)q2], 0xffffffffu);
+        park();
+        return;
     }
     // (+inf on an axis without second image; x: only pairs inside the guard band of the last bin edge can matter)
     if (NEAR > 0 && ((fabsf((float)iy) > tc.near_y) | (fabsf((float)iz * sc[8]) > tc.near_z) |
@@ -669,8 +667,8 @@ __device__ __forceinline__ void fast_quad_tri(unsigned *hist, const RdfFastArgs 
                     rdf_pair_images<false>(hist, fa, g, p, idc, idj, gi);
                 }
             };
-            if (na[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qa[u], uax, uay, uaz, qj[u], [&]() { park(ida); });
-            if (nb[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qb[u], ubx, uby, ubz, qj[u], [&]() { park(idb); });
+            if (na[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qa[u], uax, uay, uaz, qj[u], zaf, clampv, [&]() { park(ida); });
+            if (nb[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qb[u], ubx, uby, ubz, qj[u], zbf, clampv, [&]() { park(idb); });
         }
     }
 }
@@ -1610,7 +1608,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     if (0.5 * L[0] >= R0) tau_x = -1.0;
                     else if (covered(L[0], 0.0, 0.0)) near = std::max(near, 1);
                     else { ok = false; break; }
-                    share = std::max(share, (tau_y > 0.0075 ? 0.02 : 2.0) * std::max(tau_y, 0.0) + 2.0 * std::max(tau_z, 0.0));
+                    share = std::max(share, tau_y > 0.0075 ? 0.012 : 2.0 * std::max(tau_y, 0.0) + 2.0 * std::max(tau_z, 0.0));
                     l10b = std::max(l10b, fabs(L[3]) / dr);
                     const double c10 = L[3] / L[0], r20 = L[6] / L[0], r21 = L[7] / L[4];
                     fold[(size_t)k * 2] = r20 - c10 * r21;
