@@ -151,6 +151,50 @@ __global__ __launch_bounds__(CN_TILE) void cn_kernel(NbrArgs a)
 // (e0, en = first / last edge, inv_w = nb / (en - e0): the first guess only -- the comparisons with the edges decide)
 // step > 0: the host has verified edges[k] == (double)k * step bit for bit (numpy.arange(n) * dtheta, amof/bad.py:143):
 // the edges are then recomputed instead of loaded -- two dependent global loads per angle otherwise
+// arccos of the angle kernels.  numpy.arccos (what ase.geometry.get_angles calls) is a different routine on different CPUs and
+// the device library's acos a third one; they differ in the last place for a few percent of the arguments, which bins an
+// angle that sits on a histogram edge (exact lattices) differently.  Every angle here goes through ONE published algorithm
+// instead -- fdlibm's acos: (asin(t) - t) / t ~ z P(z) / Q(z), z = t^2, error < 1 ulp -- in operations that are correctly
+// rounded on the device (+ - * / sqrt, no contraction: -ffp-contract=off), the same algorithm the CPU oracle evaluates.
+__device__ __forceinline__ double acos_pq(double z)
+{
+    double p = 3.47933107596021167570e-05;
+    p = 7.91534994289814532176e-04 + z * p;
+    p = -4.00555345006794114027e-02 + z * p;
+    p = 2.01212532134862925881e-01 + z * p;
+    p = -3.25565818622400915405e-01 + z * p;
+    p = 1.66666666666666657415e-01 + z * p;
+    p = z * p;
+    double q = 7.70381505559019352791e-02;
+    q = -6.88283971605453293030e-01 + z * q;
+    q = 2.02094576023350569471e+00 + z * q;
+    q = -2.40339491173441421878e+00 + z * q;
+    q = 1.0 + z * q;
+    return p / q;
+}
+__device__ __forceinline__ double acos_fd(double x)
+{
+    constexpr double HALF_PI_HEAD = 1.57079632679489655800e+00, HALF_PI_TAIL = 6.12323399573676603587e-17;
+    constexpr double PI_HEAD = 3.14159265358979311600e+00;
+    const double mag = fabs(x);
+    if (mag >= 1.0) return x > 0.0 ? 0.0 : PI_HEAD + 2.0 * HALF_PI_TAIL;      // (the callers clip to [-1, 1])
+    if (mag < 0.5) {
+        if (mag < 0x1p-57) return HALF_PI_HEAD + HALF_PI_TAIL;
+        const double t = x * acos_pq(x * x);
+        return HALF_PI_HEAD - (x - (HALF_PI_TAIL - t));
+    }
+    if (x < 0.0) {
+        const double z = (1.0 + x) * 0.5, root = sqrt(z);
+        const double corr = acos_pq(z) * root - HALF_PI_TAIL;
+        return PI_HEAD - 2.0 * (root + corr);
+    }
+    const double z = (1.0 - x) * 0.5, root = sqrt(z);
+    const double head = __longlong_as_double(__double_as_longlong(root) & (long long)0xffffffff00000000ull);
+    const double tail = (z - head * head) / (root + head);
+    const double corr = acos_pq(z) * root + tail;
+    return 2.0 * (head + corr);
+}
+
 __device__ __forceinline__ int hist_bin(const double *__restrict__ edges, int nb, double x, double e0, double en, double inv_w,
                                         double step = 0.0)
 {
@@ -279,7 +323,7 @@ __global__ __launch_bounds__(BAD_TILE) void bad_kernel(NbrArgs a)
                 double dot = ax * ux[(size_t)v * BAD_TILE + tid] + ay * uy[(size_t)v * BAD_TILE + tid] + az * uz[(size_t)v * BAD_TILE + tid];
                 if (dot > 1.0) dot = 1.0;
                 if (dot < -1.0) dot = -1.0;
-                double ang = (180.0 / M_PI) * acos(dot);
+                double ang = (180.0 / M_PI) * acos_fd(dot);
                 int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
                 if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
                     const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n, a.cn_max) : (size_t)trip;
@@ -545,9 +589,14 @@ constexpr uint32_t NBRW_SLOT1 = 0x80000000u;          // record idx word: atom i
 
 struct FrameItem {
     int32_t sa, sb;            // centre species, partner species (sa == sb: one species staged)
-    int32_t nx, ny, nz;        // this item's cell grid (cells >= its cutoff, >= 3 per axis)
+    int32_t nx, ny, nz;        // this item's cell grid (cells >= its cutoff, >= 3 per axis); a slab: nz = ITS layers (core + 2)
     int32_t set;               // CN: output set
     int32_t reg_ab, reg_ba;    // lists: first row of region (sa, sb) / (sb, sa); -1: direction not wanted
+    // z-slabs (the streaming kernels, PT = 0): a workgroup keeps the layers zoff .. zoff + nz - 1 (mod nzg) of the pair's
+    // grid of nzg layers -- centres from its core layers c0 .. c0 + cn - 1 (local), partners from all of them (the core
+    // and one halo layer either side).  A whole frame is zoff = 0, nz = nzg, c0 = 0, cn = nz (layers wrap as before).
+    int32_t zoff, nzg, c0, cn;
+    int32_t cap;               // slab kernels: records the workgroup's LDS holds (more atoms in the slab: the call falls back)
 };
 
 struct FrameArgs {
@@ -562,6 +611,10 @@ struct FrameArgs {
     float guard_abs16;         // the absolute guard of 16-bit coordinates
     uint2 *sidx;               // [frames of the batch][items of the launch][sidx_stride]
     int32_t sidx_stride;
+    // slab kernels: the batch quantised beforehand (quantize_kernel: axis order (0, 1, 2), every species segment counting-
+    // sorted into 256 bins along z), so that a slab reads only the bins its layers can lie in
+    const QAtom *Q;            // [frames of the batch][N]
+    const uint32_t *zstart;    // [frames of the batch][S][QSLABS + 1] first record of every bin, relative to the species segment
 };
 
 struct FrameLds {
@@ -670,6 +723,122 @@ __device__ __forceinline__ void frame_sort(const NbrArgs &a, const FrameArgs &fr
     __syncthreads();
 }
 
+// ---- z-slabs (round 4): pairs with more atoms than one workgroup's LDS (or its registers: frame_sort keeps a thread's atoms
+// in registers between its two passes) holds.  The batch is quantised beforehand into records sorted by species and by 256
+// bins along z (quantize_kernel, the RDF path's: positions read once per call instead of once per pair); a workgroup reads
+// the bins its layers can lie in -- twice: count, then place -- and keeps the partners of its core layers and of one halo
+// layer either side, and the centres of its core layers.  Two species: the centres are compacted (in arrival order) to
+// positions [0, ncen), the partners cell-sorted behind them.  One species: everything is cell-sorted and the centres are the
+// contiguous run of the core layers.
+// Returns false when the slab holds more atoms than it.cap (then *fr.qflag is raised: the gather kernels take the call).
+constexpr int NBRS_RT = 4;      // records per thread and round
+__device__ __forceinline__ bool frame_sort_slab(const NbrArgs &a, const FrameArgs &fr, const FrameItem &it, const FrameLds &L,
+                                                int f, int nB, unsigned *wsum, unsigned *ctl /* LDS [4] */,
+                                                int &ncen, int &cbeg, int &first, int &total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nx = it.nx, ny = it.ny, nzl = it.nz, ntab = nx * ny * nzl;
+    const bool two = nB > 0;
+    const uint4 *__restrict__ Qf = reinterpret_cast<const uint4 *>(fr.Q + (size_t)(f - fr.f_base) * (size_t)a.N);
+    const uint32_t *__restrict__ zs = fr.zstart + (size_t)(f - fr.f_base) * (size_t)a.S * (QSLABS + 1);
+    for (int c = tid; c < ntab; c += NBRW_THREADS) L.cell_end[c] = 0u;
+    if (tid < 4) ctl[tid] = 0u;
+    __syncthreads();
+    // The records of species sp whose layer can be one of l0 .. l0 + ln - 1 (mod nzg): up to two runs of its z-sorted
+    // segment.  fn(record, is a partner of this slab, is a centre of this slab, its cell) is called by all lanes for
+    // every record of the runs, so that fn may aggregate over the wave.
+    auto walk = [&](int sp, int l0, int ln, bool centres, auto &&fn) {
+        const uint32_t *__restrict__ st = zs + (size_t)sp * (QSLABS + 1);
+        const int seg = (int)fr.sp_first[sp];
+        l0 -= l0 >= it.nzg ? it.nzg : 0;
+        const int b0 = (l0 * QSLABS) / it.nzg, b1 = ((l0 + ln) * QSLABS + it.nzg - 1) / it.nzg;
+        int r0, e0, r1 = 0, e1 = 0;
+        if (b1 - b0 >= QSLABS) { r0 = 0; e0 = (int)st[QSLABS]; }
+        else if (b1 <= QSLABS) { r0 = (int)st[b0]; e0 = (int)st[b1]; }
+        else { r0 = (int)st[b0]; e0 = (int)st[QSLABS]; r1 = 0; e1 = (int)st[b1 - QSLABS]; }
+        const int len0 = e0 - r0, M = len0 + e1 - r1;
+        for (int base = 0; base < M; base += NBRS_RT * NBRW_THREADS) {
+            uint4 q[NBRS_RT];
+#pragma unroll
+            for (int i = 0; i < NBRS_RT; i++) {
+                const int k = min(base + tid + i * NBRW_THREADS, M - 1);
+                q[i] = Qf[seg + (k < len0 ? r0 + k : r1 + (k - len0))];
+            }
+#pragma unroll
+            for (int i = 0; i < NBRS_RT; i++) {
+                const int k = base + tid + i * NBRW_THREADS;
+                int lz = (int)__umulhi(q[i].z, (unsigned)it.nzg) - it.zoff;
+                lz += lz < 0 ? it.nzg : 0;
+                const bool partner = !centres && k < M && lz < nzl;
+                const bool centre = centres && k < M && (unsigned)(lz - it.c0) < (unsigned)it.cn;
+                const uint32_t key = ((unsigned)min(lz, nzl - 1) * (unsigned)ny + __umulhi(q[i].y, (unsigned)ny)) * (unsigned)nx + __umulhi(q[i].x, (unsigned)nx);
+                fn(make_uint4(q[i].x, q[i].y, q[i].z, q[i].w | ((two && !centres) ? NBRW_SLOT1 : 0u)), partner, centre, key);
+            }
+        }
+    };
+    auto walk_all = [&](auto &&fn) {
+        if (two) walk(it.sa, it.zoff + it.c0, it.cn, true, fn);
+        walk(it.sb, it.zoff, nzl, false, fn);
+    };
+    walk_all([&](const uint4 &, bool partner, bool centre, uint32_t key) {
+        if (partner) atomicAdd(&L.cell_end[key], 1u);
+        if (two) {
+            const unsigned long long m = __ballot(centre);
+            if (lane == 0 && m) atomicAdd(&ctl[0], (unsigned)__popcll(m));
+        }
+    });
+    __syncthreads();
+    ncen = two ? (int)ctl[0] : 0;
+    first = ncen;
+    // exclusive scan of the counters, as in frame_sort; the thread that holds the table's end publishes the total
+    const int chunk = (ntab + NBRW_THREADS - 1) / NBRW_THREADS;
+    const int c0 = min(tid * chunk, ntab), c1 = min(c0 + chunk, ntab);
+    unsigned sum = 0;
+    for (int c = c0; c < c1; c++) sum += L.cell_end[c];
+    unsigned incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - sum + (unsigned)ncen;
+    for (int q = 0; q < wave; q++) run += wsum[q];
+    for (int c = c0; c < c1; c++) {
+        const unsigned v = L.cell_end[c];
+        L.cell_end[c] = run;
+        run += v;
+    }
+    if (c0 < c1 && c1 == ntab) ctl[1] = run;
+    __syncthreads();
+    total = (int)ctl[1];
+    if (total > it.cap) {
+        if (tid == 0) *fr.qflag = 1;
+        return false;
+    }
+    walk_all([&](const uint4 &rec, bool partner, bool centre, uint32_t key) {
+        if (partner) reinterpret_cast<uint4 *>(L.rec)[atomicAdd(&L.cell_end[key], 1u)] = rec;
+        if (two) {
+            const unsigned long long m = __ballot(centre);
+            if (m) {
+                unsigned b = 0;
+                if (lane == 0) b = atomicAdd(&ctl[2], (unsigned)__popcll(m));
+                b = __shfl(b, 0, 64) + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                if (centre) reinterpret_cast<uint4 *>(L.rec)[b] = rec;
+            }
+        }
+    });
+    __syncthreads();
+    if (two) {
+        cbeg = 0;
+    } else {    // one species: the centres are the sorted run of the core layers
+        const int lo = it.c0 * ny * nx, hi = (it.c0 + it.cn) * ny * nx;
+        cbeg = lo > 0 ? (int)L.cell_end[lo - 1] : 0;
+        ncen = (int)L.cell_end[hi - 1] - cbeg;
+    }
+    return true;
+}
+
 // One task = one centre x one of the 9 rows (dz, dy) of cells around it: its x-run cx-1 .. cx+1 (two index ranges when
 // the run wraps) among the partners of species slot `slot` (0 / 1) of the sorted frame.  Nine lanes share a centre, so a
 // wave's trip count is the fullest ROW of its lanes, not the fullest neighbourhood (per-lane loops over all 27 cells ran
@@ -686,7 +855,9 @@ __device__ __forceinline__ void frame_row_neighbours(const FrameArgs &fr, const 
     const float rcf = (float)rc;
     const float gd = rcf * fr.guard_rel + (COMPACT ? fr.guard_abs16 : fr.guard_abs);
     const float r_in = rcf - gd, r_out = rcf + gd;
-    const int cx = (int)__umulhi(qc.x, (unsigned)nx), cy = (int)__umulhi(qc.y, (unsigned)ny), cz = (int)__umulhi(qc.z, (unsigned)nz);
+    const int cx = (int)__umulhi(qc.x, (unsigned)nx), cy = (int)__umulhi(qc.y, (unsigned)ny);
+    int cz = (int)__umulhi(qc.z, (unsigned)it.nzg) - it.zoff;      // (the layer inside this workgroup's slab; a whole frame: zoff = 0)
+    cz += cz < 0 ? it.nzg : 0;
     const int dz = r9 / 3 - 1, dy = r9 - 3 * (r9 / 3) - 1;
     int cz2 = cz + dz, cy2 = cy + dy;
     cz2 += cz2 < 0 ? nz : 0; cz2 -= cz2 >= nz ? nz : 0;
@@ -724,14 +895,27 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void c
     const int f = fr.f_base + (int)blockIdx.y;
     const int nA = (int)(fr.sp_first[it.sa + 1] - fr.sp_first[it.sa]);
     const int nB = it.sa == it.sb ? 0 : (int)(fr.sp_first[it.sb + 1] - fr.sp_first[it.sb]);
+    constexpr bool SLAB = PT == 0;
+    static_assert(!(SLAB && COMPACT), "slabs keep 16-byte records");
     L.rec = lds_raw;                                                    // (every item lays LDS out for its own atom count)
-    L.cell_end = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(nA + nB) * (COMPACT ? sizeof(uint2) : sizeof(uint4)));
+    L.cell_end = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(SLAB ? it.cap : nA + nB) * (COMPACT ? sizeof(uint2) : sizeof(uint4)));
     L.sidx = COMPACT ? fr.sidx + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)fr.sidx_stride : nullptr;
     const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
     int32_t *__restrict__ pa = a.per_atom ? a.per_atom + ((size_t)f * a.n_sets + it.set) * (size_t)a.N : nullptr;
-    if (pa)     // every centre starts at zero (the barriers of the sort order these stores before the atomics below)
-        for (int c = tid; c < nA; c += NBRW_THREADS) pa[a.perm[fr.sp_first[it.sa] + c]] = 0;
-    frame_sort<PT, COMPACT>(a, fr, it, L, f, nA, nB, wsum);
+    int ncen = nA, cbeg = 0, first = nB > 0 ? nA : 0;
+    if constexpr (SLAB) {
+        __shared__ unsigned ctl[4];
+        int total;
+        if (!frame_sort_slab(a, fr, it, L, f, nB, wsum, ctl, ncen, cbeg, first, total)) return;
+        if (pa) {   // the centres of THIS slab start at zero (a centre belongs to one slab: nobody else adds to it)
+            for (int c = tid; c < ncen; c += NBRW_THREADS) pa[reinterpret_cast<const uint4 *>(L.rec)[cbeg + c].w & ~NBRW_SLOT1] = 0;
+            __syncthreads();
+        }
+    } else {
+        if (pa)     // every centre starts at zero (the barriers of the sort order these stores before the atomics below)
+            for (int c = tid; c < nA; c += NBRW_THREADS) pa[a.perm[fr.sp_first[it.sa] + c]] = 0;
+        frame_sort<PT, COMPACT>(a, fr, it, L, f, nA, nB, wsum);
+    }
     const int gi = a.n_cells == 1 ? 0 : f;
     const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
     float sc[9];
@@ -739,12 +923,12 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void c
     for (int k = 0; k < 9; k++) sc[k] = fr.cells[gi].sc[k];
     const double rc = a.cutoff[it.sa * a.S + it.sb];
     unsigned long long sum = 0;
-    const int tasks = nA * 9;
+    const int tasks = ncen * 9;
     for (int t = tid; t < tasks; t += NBRW_THREADS) {
-        const int c = t / 9, r9 = t - 9 * c;
+        const int c = cbeg + t / 9, r9 = t % 9;
         const uint4 qc = frame_rec<COMPACT>(L, c);
         int cnt = 0;
-        frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, nB > 0 ? nA : 0, sc, geo, p, c, nB == 0, qc, r9, rc,
+        frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, first, sc, geo, p, c, nB == 0, qc, r9, rc,
                                              [&](bool nbr, int) { cnt += nbr ? 1 : 0; });
         if (pa && cnt) atomicAdd(&pa[frame_atom<COMPACT>(L, c, qc)], cnt);
         sum += (unsigned long long)cnt;
@@ -810,7 +994,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_fast_kernel(NbrFastArgs fa)
         double dot = ax * bx + ay * by + az * bz;
         if (dot > 1.0) dot = 1.0;
         if (dot < -1.0) dot = -1.0;
-        const double ang = (180.0 / M_PI) * acos(dot);
+        const double ang = (180.0 / M_PI) * acos_fd(dot);
         const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
         if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
             const size_t slot = a.cn_max > 0 ? (size_t)trip * (a.cn_max + 1) + min(n_centre, a.cn_max) : (size_t)trip;
@@ -1015,7 +1199,7 @@ __global__ __launch_bounds__(256) void bad_transposed_kernel(NbrFastArgs fa, con
                 double dot = ax * bx + ay * by + az * bz;
                 if (dot > 1.0) dot = 1.0;
                 if (dot < -1.0) dot = -1.0;
-                const double ang = (180.0 / M_PI) * acos(dot);
+                const double ang = (180.0 / M_PI) * acos_fd(dot);
                 const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
                 if (direct) {
                     atomicAdd(&a.n_angles[hslot], 1ull);
@@ -1066,6 +1250,14 @@ struct NbrListArgs {
     int32_t R;
 };
 
+#ifdef NBR_PHASE_STAMPS
+__device__ unsigned long long nbr_phase_ticks[16][5];   // [entry][sort, search, unit vectors, counts, workgroups] (diagnostic build only)
+#define NBR_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memrealtime();
+#define NBR_PHASE(k, t1, t0) if (threadIdx.x == 0) atomicAdd(&nbr_phase_ticks[blockIdx.x & 15][k], (t1) - (t0));
+#else
+#define NBR_STAMP(v)
+#define NBR_PHASE(k, t1, t0)
+#endif
 template <bool ORTHO, int PT, bool COMPACT>
 __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void lists_frame_kernel(NbrArgs a, FrameArgs fr, NbrListArgs la)
 {
@@ -1077,10 +1269,14 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
     const int fl = (int)blockIdx.y, f = fr.f_base + fl;
     const int nA = (int)(fr.sp_first[it.sa + 1] - fr.sp_first[it.sa]);
     const int nB = it.sa == it.sb ? 0 : (int)(fr.sp_first[it.sb + 1] - fr.sp_first[it.sb]);
+    constexpr bool SLAB = PT == 0;
+    static_assert(!(SLAB && COMPACT), "slabs keep 16-byte records");
     L.rec = lds_raw;
-    L.cell_end = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(nA + nB) * (COMPACT ? sizeof(uint2) : sizeof(uint4)));
+    L.cell_end = reinterpret_cast<uint32_t *>(lds_raw + (size_t)(SLAB ? it.cap : nA + nB) * (COMPACT ? sizeof(uint2) : sizeof(uint4)));
     L.sidx = COMPACT ? fr.sidx + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)fr.sidx_stride : nullptr;
-    const int n = nA + nB, ntab = it.nx * it.ny * it.nz;
+    const int n = SLAB ? it.cap : nA + nB, ntab = it.nx * it.ny * it.nz;
+    // (a slab of a pair: a partner may sit in the halo of other slabs too, so its row's slots are claimed in global memory)
+    const bool shared_partners = SLAB && it.cn != it.nzg;
     // neighbours found so far, one BYTE per atom (sorted position), four to a word: a lane claims a slot with
     // atomicAdd(word, 1 << 8 * (c & 3)) (an atom past 16 fails the call anyway, so a carry into the next byte is harmless)
     uint32_t *cnt = L.cell_end + ntab;
@@ -1090,7 +1286,16 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
     __shared__ unsigned nhits;
     for (int c = tid; c < (n + 3) / 4; c += NBRW_THREADS) cnt[c] = 0u;
     if (tid == 0) nhits = 0u;
-    frame_sort<PT, COMPACT>(a, fr, it, L, f, nA, nB, wsum);
+    int ncen = nA, cbeg = 0, first = nB > 0 ? nA : 0, total = nA + nB;
+    NBR_STAMP(ts0)
+    if constexpr (SLAB) {
+        __shared__ unsigned ctl[4];
+        if (!frame_sort_slab(a, fr, it, L, f, nB, wsum, ctl, ncen, cbeg, first, total)) return;
+    } else {
+        frame_sort<PT, COMPACT>(a, fr, it, L, f, nA, nB, wsum);
+    }
+    NBR_STAMP(ts1)
+    NBR_PHASE(0, ts1, ts0)
     const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
     const int gi = a.n_cells == 1 ? 0 : f;
     const double *__restrict__ geo = a.geom + (size_t)gi * GEOM_STRIDE;
@@ -1104,17 +1309,18 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
         const unsigned sh = 8u * ((unsigned)c & 3u);
         return (atomicAdd(&cnt[c >> 2], 1u << sh) >> sh) & 0xffu;
     };
-    const int tasks = nA * 9;
+    const int tasks = ncen * 9;
     for (int t0 = 0; t0 < tasks; t0 += NBRW_THREADS) {
         const int t = t0 + tid;
+        NBR_STAMP(tr0)
         // a task keeps its first two pairs in registers and the wave appends them with ONE LDS atomic after the search (a
         // ballot + atomic + shuffle on every trip of the candidate loop tripled the search: 24 us against 7 in cn_frame_kernel);
         // a third pair of one centre in one row of cells is appended on the spot
         int h0 = 0, h1 = 0, mine = 0;
-        const int c = t < tasks ? t / 9 : 0;
+        const int c = cbeg + (t < tasks ? t / 9 : 0);
         if (t < tasks) {
-            const int r9 = t - 9 * c;
-            frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, nB > 0 ? nA : 0, sc, geo, p, c, nB == 0, frame_rec<COMPACT>(L, c), r9, rc,
+            const int r9 = t % 9;
+            frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, first, sc, geo, p, c, nB == 0, frame_rec<COMPACT>(L, c), r9, rc,
                                                  [&](bool nbr, int j) {
                 if (!nbr) return;
                 if (mine == 0) h0 = j;
@@ -1148,6 +1354,8 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
         // flush once the buffer is a third full, and after the last round (the OR makes the decision uniform: a thread may
         // read the counter while slower ones still append)
         const bool filling = __syncthreads_or(nhits > (unsigned)NBRW_HITS / 3);
+        NBR_STAMP(tr1)
+        NBR_PHASE(1, tr1, tr0)
         if (!filling && t0 + NBRW_THREADS < tasks) continue;
         // one lane per pair: the canonical unit vector once, to the centre's row and, negated, to the partner's
         const unsigned nh = min(nhits, (unsigned)NBRW_HITS);
@@ -1159,7 +1367,7 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
                 const uint2 ic = L.sidx[c], ij = L.sidx[j];
                 atom_c = ic.x; rank_c = (int)ic.y; atom_j = ij.x; rank_j = (int)ij.y;
             } else {
-                atom_c = reinterpret_cast<const uint4 *>(L.rec)[c].w;
+                atom_c = reinterpret_cast<const uint4 *>(L.rec)[c].w & ~NBRW_SLOT1;
                 atom_j = reinterpret_cast<const uint4 *>(L.rec)[j].w & ~NBRW_SLOT1;
                 rank_c = la.inv_rank[atom_c]; rank_j = la.inv_rank[atom_j];                // (loaded beside the positions)
             }
@@ -1177,7 +1385,7 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
                 }
             }
             if (it.reg_ba >= 0 && nB > 0) {
-                const unsigned k = claim(j);
+                const unsigned k = shared_partners ? atomicAdd(&la.count[base + (size_t)(it.reg_ba + rank_j)], 1u) : claim(j);
                 if (k < (unsigned)NBRL_CAP) {
                     double2 *e = reinterpret_cast<double2 *>(la.rows + ((size_t)k * la.plane + base + (size_t)(it.reg_ba + rank_j)) * NBRL_EW);
                     e[0] = make_double2(-ux, -uy); e[1] = make_double2(-uz, 0.0);
@@ -1189,15 +1397,29 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
         __syncthreads();
         if (tid == 0) nhits = 0u;
         __syncthreads();
+        NBR_STAMP(tr2)
+        NBR_PHASE(2, tr2, tr1)
     }
     __syncthreads();
-    for (int c = tid; c < n; c += NBRW_THREADS) {
-        const int reg = c < nA ? it.reg_ab : it.reg_ba;
+    NBR_STAMP(tc0)
+    for (int c = tid; c < total; c += NBRW_THREADS) {
+        // (one species: only the centres of the slab's core own their rows here; partners counted in global memory: nothing to store)
+        const bool is_centre = nB > 0 ? c < ncen : (c >= cbeg && c < cbeg + ncen);
+        if (!is_centre && (nB == 0 || shared_partners)) continue;
+        const int reg = is_centre ? it.reg_ab : it.reg_ba;
         if (reg < 0) continue;
         const uint32_t k = (cnt[c >> 2] >> (8u * ((unsigned)c & 3u))) & 0xffu;
         const int rank = COMPACT ? (int)L.sidx[c].y : la.inv_rank[reinterpret_cast<const uint4 *>(L.rec)[c].w & ~NBRW_SLOT1];
         la.count[base + (size_t)(reg + rank)] = min(k, (uint32_t)NBRL_CAP);
     }
+#ifdef NBR_PHASE_STAMPS
+    __syncthreads();
+    {
+        NBR_STAMP(tc1)
+        NBR_PHASE(3, tc1, tc0)
+        if (threadIdx.x == 0) atomicAdd(&nbr_phase_ticks[blockIdx.x & 15][4], 1ull);
+    }
+#endif
 }
 
 // work item (blockIdx.y): (triple, centre species, B or -1, -); blockIdx.x strides over the tiles of 256 (frame, centre)
@@ -1276,7 +1498,7 @@ __global__ __launch_bounds__(NBRF_TILE) void bad_rows_kernel(NbrArgs a, NbrListA
             double dot = ax * bx + ay * by + az * bz;
             if (dot > 1.0) dot = 1.0;
             if (dot < -1.0) dot = -1.0;
-            const double ang = (180.0 / M_PI) * acos(dot);
+            const double ang = (180.0 / M_PI) * acos_fd(dot);
             const int k = hist_bin(a.edges, nb, ang, hb_e0, hb_en, hb_inv_w, a.edge_step);
             if (direct) {           // BadByCn: keyed by the number of B-neighbours of this centre
                 atomicAdd(&a.n_angles[hslot], 1ull);
@@ -1398,7 +1620,7 @@ __global__ __launch_bounds__(NBRM_THREADS) void bad_rows_merged_kernel(NbrArgs a
         double dot = a01.x * b01.x + a01.y * b01.y + a2.x * b2.x;
         if (dot > 1.0) dot = 1.0;
         if (dot < -1.0) dot = -1.0;
-        return hist_bin(a.edges, nb, (180.0 / M_PI) * acos(dot), hb_e0, hb_en, hb_inv_w, a.edge_step);
+        return hist_bin(a.edges, nb, (180.0 / M_PI) * acos_fd(dot), hb_e0, hb_en, hb_inv_w, a.edge_step);
     };
     auto angles_of = [&](const Centre &ce) {
         const int n = ce.c0 + ce.c1 + ce.c2;
@@ -1774,8 +1996,107 @@ static bool frame_item_grid(const double hmin[3], double rc, int64_t n, int slot
     }
     if ((int64_t)nk[0] * nk[1] * nk[2] > cells_budget) return false;
     it.nx = nk[0]; it.ny = nk[1]; it.nz = nk[2];
+    it.zoff = 0; it.nzg = nk[2]; it.c0 = 0; it.cn = nk[2]; it.cap = (int32_t)n;
     lds = std::max(lds, rec_bytes + (size_t)slots * 4 * (size_t)nk[0] * nk[1] * nk[2]);
     return true;
+}
+
+// z-slab entries of one species pair for the streaming kernels (PT = 0, 16-byte records): the fewest slabs whose records
+// (the expected share of the atoms + 20 % + 128: a denser slab raises the overflow flag and the gather kernels answer) and
+// a useful table fit `budget` bytes of LDS beside `fixed` bytes and `per_atom` bytes per record.  nB = 0: one species.
+// thin = false asks for at least two cells per expected partner (or the finest grid the cutoff allows).
+static bool frame_item_slabs(const double hmin[3], double rc, int64_t nA, int64_t nB, const FrameItem &proto, std::vector<FrameItem> &out,
+                             size_t &lds, size_t budget, size_t fixed, size_t per_atom, bool thin)
+{
+    int nk0[3];
+    for (int x = 0; x < 3; x++) {
+        nk0[x] = (int)std::min(1024.0, floor(1.0 / (rc * (1.0 + 1e-5) / hmin[x])));
+        if (nk0[x] < 3) return false;
+    }
+    const int64_t partners = nB > 0 ? nB : nA;
+    {   // the whole frame's granularity first, as frame_item_grid: about four cells per partner
+        const int64_t want = std::max<int64_t>(27, std::max<int64_t>(4 * partners, 4096));
+        while ((int64_t)nk0[0] * nk0[1] * nk0[2] > want) {
+            int big = 0;
+            for (int x = 1; x < 3; x++)
+                if (nk0[x] > nk0[big]) big = x;
+            if (nk0[big] <= 3) break;
+            nk0[big]--;
+        }
+    }
+    const size_t rec = sizeof(uint4) + per_atom;
+    for (int nsl = 1; nsl == 1 || (nk0[2] >= 4 && nsl <= nk0[2] / 2); nsl++) {
+        int nk[3] = {nk0[0], nk0[1], nk0[2]};
+        const int zn = (nk[2] + nsl - 1) / nsl;
+        if (nsl > 1 && zn + 2 > nk[2]) continue;
+        if (nsl > 1 && (nsl - 1) * zn >= nk[2]) continue;           // (the last slab would be empty: a smaller count covers it)
+        const int nzl = nsl == 1 ? nk[2] : zn + 2;
+        const double share_c = nsl == 1 ? 1.0 : (double)zn / nk[2], share_p = nsl == 1 ? 1.0 : (double)nzl / nk[2];
+        const int64_t est_p = (int64_t)ceil((double)partners * share_p);
+        const int64_t est = nB > 0 ? (int64_t)ceil((double)nA * share_c) + est_p : est_p;
+        const int64_t need = nsl == 1 ? est : est + est / 5 + 128;
+        if (need > NBRW_MAX_ATOMS) continue;
+        if (fixed + (size_t)need * rec + 4 * 27 > budget) continue;
+        const int64_t cells_budget = (int64_t)((budget - fixed - (size_t)need * rec) / 4);
+        while ((int64_t)nk[0] * nk[1] * nzl > cells_budget) {       // coarser in x / y (the slabs keep their layers)
+            const int big = nk[1] > nk[0] ? 1 : 0;
+            if (nk[big] <= 3) break;
+            nk[big]--;
+        }
+        const int64_t cells = (int64_t)nk[0] * nk[1] * nzl;
+        if (cells > cells_budget) continue;
+        const bool finest = nk[0] == nk0[0] && nk[1] == nk0[1];
+        if (!thin && !finest && cells < 2 * est_p) continue;
+        const int64_t cap = std::min<int64_t>(NBRW_MAX_ATOMS, (int64_t)((budget - fixed - 4 * (size_t)cells) / rec));
+        for (int sl = 0; sl < nsl; sl++) {
+            FrameItem it = proto;
+            it.nx = nk[0]; it.ny = nk[1]; it.nzg = nk[2];
+            if (nsl == 1) {
+                it.nz = nk[2]; it.zoff = 0; it.c0 = 0; it.cn = nk[2];
+            } else {
+                const int z0 = sl * zn, cn = std::min(zn, nk[2] - z0);
+                it.nz = cn + 2; it.zoff = (z0 - 1 + nk[2]) % nk[2]; it.c0 = 1; it.cn = cn;
+            }
+            it.cap = (int32_t)cap;
+            out.push_back(it);
+        }
+        lds = std::max(lds, fixed + (size_t)cap * rec + 4 * (size_t)cells);
+        return true;
+    }
+    return false;
+}
+
+// the whole call in slabs: budget of two workgroups per CU with useful tables, then one per CU, then whatever fits.
+// items_of(budget, thin, out, lds) builds every pair's entries and says whether all fit.
+template <typename Build>
+static bool frame_slab_passes(Build &&build, std::vector<FrameItem> &items, size_t &lds)
+{
+    const size_t budgets[3] = {76 * 1024, 152 * 1024, 152 * 1024};
+    for (int pass = 0; pass < 3; pass++) {
+        items.clear();
+        lds = 0;
+        if (build(budgets[pass], pass == 2, items, lds)) return true;
+    }
+    return false;
+}
+static bool frame_slabs_forced() { const char *e = getenv("AMOF_NBR_SLABS"); return e && e[0] == '1'; }
+static bool frame_slabs_forbidden() { const char *e = getenv("AMOF_NBR_SLABS"); return e && e[0] == '0'; }
+
+// the slab kernels' input: room for FB frames of records (at most 2 GiB: FB shrinks) and their bin tables
+static int frame_slab_buffers(amof_ctx *ctx, const amof_traj *t, NbrFrame &nw, int64_t &FB)
+{
+    FB = std::max<int64_t>(1, std::min<int64_t>(FB, (int64_t)(((size_t)2 << 30) / ((size_t)t->n_atoms * sizeof(QAtom)))));
+    void *d_Q, *d_z;
+    AMOF_TRY(ensure(ctx, SLOT_HISTU, (size_t)FB * (size_t)t->n_atoms * sizeof(QAtom), &d_Q));
+    AMOF_TRY(ensure(ctx, SLOT_SELF, (size_t)FB * (size_t)t->n_species * (QSLABS + 1) * sizeof(uint32_t), &d_z));
+    nw.fr.Q = (const QAtom *)d_Q;
+    nw.fr.zstart = (const uint32_t *)d_z;
+    return AMOF_OK;
+}
+static int frame_slab_quantize(amof_ctx *ctx, const amof_traj *t, const NbrArgs &a, NbrFrame &nw, int64_t fb, int64_t nfr)
+{
+    return launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, nw.d_spfirst, t->n_species, t->n_atoms, (int)fb, (int)nfr, 2,
+                           (QAtom *)nw.fr.Q, (uint32_t *)nw.fr.zstart, (int32_t *)nw.d_qflag, 0, 1);
 }
 
 // Record size of the tier, three passes: 0 = 16-byte records, 1 = COMPACT 8-byte ones, 2 = 16-byte again.  AMOF_NBR_COMPACT=1
@@ -1928,6 +2249,25 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
             if (pass == 0) ok16 = nw.ok;
             if (frame_pass_done(pass, nw.ok, nw.lds, ok16)) break;
         }
+        // pairs too big for one workgroup (or AMOF_NBR_SLABS=1): every pair in z-slabs, the streaming kernels
+        bool slabs = false;
+        if (tier_ok && !frame_slabs_forbidden() && (frame_slabs_forced() || !nw.ok)) {
+            bool zero_set = false;
+            slabs = frame_slab_passes([&](size_t budget, bool thin, std::vector<FrameItem> &out, size_t &lds) {
+                for (int s2 = 0; s2 < n_sets; s2++) {
+                    const int A = sets[2 * s2], B = sets[2 * s2 + 1];
+                    const int64_t nA = st.tiles.nsp[A], nB = st.tiles.nsp[B];
+                    if (!(cutoff[A * S + B] > 0.0) || nA == 0 || nB == 0) { zero_set = true; continue; }
+                    FrameItem it{};
+                    it.sa = A; it.sb = B; it.set = s2; it.reg_ab = it.reg_ba = -1;
+                    if (!frame_item_slabs(hmin, cutoff[A * S + B], nA, A == B ? 0 : nB, it, out, lds, budget, 0, 0, thin)) return false;
+                }
+                return true;
+            }, nw.items, nw.lds);
+            if (zero_set && per_atom) slabs = false;        // (a zero-cutoff set with per-atom output keeps the gather kernels)
+            if (slabs) { nw.ok = true; nw.compact = false; }
+            else if (frame_slabs_forced()) { nw.ok = false; }
+        }
         if (nw.ok && !nw.items.empty()) {
             AMOF_TRY(nbr_frame_commit(ctx, nw));
             int64_t most = 0;
@@ -1943,13 +2283,15 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
                 nw.fr.sidx = (uint2 *)d_sidx;
                 nw.fr.sidx_stride = (int32_t)most;
             }
+            if (slabs) AMOF_TRY(frame_slab_buffers(ctx, t, nw, FB));
             const int64_t FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
             for (int64_t fb = 0, cur = FB0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
                 const int64_t nfr = std::min<int64_t>(cur, t->n_frames - fb);
                 AMOF_TRY(stager_need(st.stage, fb + nfr));
                 nw.fr.f_base = (int32_t)fb;
                 nw.fr.nf = (int32_t)nfr;
-                if (launches == 0) timing_dom_begin(ctx, "cn_frame");
+                if (launches == 0) timing_dom_begin(ctx, slabs ? "cn_frame_slabs" : "cn_frame");
+                if (slabs) AMOF_TRY(frame_slab_quantize(ctx, t, a, nw, fb, nfr));
                 const dim3 grid((unsigned)nw.items.size(), (unsigned)nfr);
                 auto launch = [&](auto kern) -> hipError_t {
                     hipError_t e2 = allow_max_lds((const void *)kern);
@@ -1957,7 +2299,8 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
                     return e2;
                 };
                 hipError_t e;
-                if (most > 4 * NBRW_THREADS && nw.compact) e = nw.ortho ? launch(cn_frame_kernel<true, 8, true>) : launch(cn_frame_kernel<false, 8, true>);
+                if (slabs) e = nw.ortho ? launch(cn_frame_kernel<true, 0, false>) : launch(cn_frame_kernel<false, 0, false>);
+                else if (most > 4 * NBRW_THREADS && nw.compact) e = nw.ortho ? launch(cn_frame_kernel<true, 8, true>) : launch(cn_frame_kernel<false, 8, true>);
                 else if (most > 4 * NBRW_THREADS) e = nw.ortho ? launch(cn_frame_kernel<true, 8, false>) : launch(cn_frame_kernel<false, 8, false>);
                 else if (nw.compact) e = nw.ortho ? launch(cn_frame_kernel<true, 4, true>) : launch(cn_frame_kernel<false, 4, true>);
                 else e = nw.ortho ? launch(cn_frame_kernel<true, 4, false>) : launch(cn_frame_kernel<false, 4, false>);
@@ -2156,6 +2499,31 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             if (pass == 0) ok16 = nw.ok;
             if (frame_pass_done(pass, nw.ok, nw.lds, ok16)) break;
         }
+        // pairs too big for one workgroup (or AMOF_NBR_SLABS=1): every pair in z-slabs, the streaming kernels
+        bool slabs = false, shared_rows = false;
+        if (tier_ok && !frame_slabs_forbidden() && (frame_slabs_forced() || !nw.ok)) {
+            slabs = frame_slab_passes([&](size_t budget, bool thin, std::vector<FrameItem> &out, size_t &lds) {
+                for (int x = 0; x < S; x++)
+                    for (int y = x; y < S; y++) {
+                        if (!needed[(size_t)x * S + y] && !needed[(size_t)y * S + x]) continue;
+                        FrameItem it{};
+                        it.sa = st.tiles.nsp[y] < st.tiles.nsp[x] ? y : x;      // the species with fewer atoms searches
+                        it.sb = it.sa == x ? y : x;
+                        it.set = 0;
+                        it.reg_ab = region_of[(size_t)it.sa * S + it.sb];
+                        it.reg_ba = x == y ? -1 : region_of[(size_t)it.sb * S + it.sa];
+                        if (!frame_item_slabs(hmin, cutoff[x * S + y], st.tiles.nsp[it.sa], x == y ? 0 : st.tiles.nsp[it.sb], it, out, lds,
+                                              budget, (size_t)NBRW_HITS * sizeof(uint32_t) + 4, 1, thin)) return false;
+                    }
+                return true;
+            }, nw.items, nw.lds);
+            if (slabs) {
+                nw.ok = true; nw.compact = false;
+                for (const FrameItem &it : nw.items) shared_rows = shared_rows || (it.cn != it.nzg && it.reg_ba >= 0);
+            } else if (frame_slabs_forced()) {
+                nw.ok = false;
+            }
+        }
         if (nw.ok && !awork.empty() && R > 0 && R < (1ll << 30) && t->n_frames > 0) {
             // merged angle passes: one per centre species, every angle computed once (histograms in LDS; BadByCn keys, more
             // bins than LDS holds, a centre species with more than three partner species or a triple named twice keep
@@ -2226,6 +2594,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 if (rc_rows != AMOF_ENOMEM || FB == 1) return rc_rows;
                 FB = std::max<int64_t>(1, FB / 4);
             }
+            if (slabs) AMOF_TRY(frame_slab_buffers(ctx, t, nw, FB));
             const int64_t FB0 = st.stage.lazy ? std::min<int64_t>(FB, 512) : FB;
             if (nw.compact) {
                 void *d_sidx;
@@ -2248,7 +2617,10 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 AMOF_TRY(stager_need(st.stage, fb + nfr));
                 nw.fr.f_base = (int32_t)fb;
                 nw.fr.nf = (int32_t)nfr;
-                if (launches == 0) timing_dom_begin(ctx, "bad_frame");
+                if (launches == 0) timing_dom_begin(ctx, slabs ? "bad_frame_slabs" : "bad_frame");
+                if (slabs) AMOF_TRY(frame_slab_quantize(ctx, t, a, nw, fb, nfr));
+                if (shared_rows)    // (partners of several slabs claim their rows' slots with global atomics: the counts start at zero)
+                    AMOF_HIP_TRY(ctx, hipMemsetAsync(la.count, 0, (size_t)FB * (size_t)R * sizeof(uint32_t), ctx->stream));
                 const dim3 sgrid((unsigned)nw.items.size(), (unsigned)nfr);
                 auto launch = [&](auto kern) -> hipError_t {
                     hipError_t e2 = allow_max_lds((const void *)kern);
@@ -2256,7 +2628,8 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                     return e2;
                 };
                 hipError_t e;
-                if (most > 4 * NBRW_THREADS && nw.compact) e = nw.ortho ? launch(lists_frame_kernel<true, 8, true>) : launch(lists_frame_kernel<false, 8, true>);
+                if (slabs) e = nw.ortho ? launch(lists_frame_kernel<true, 0, false>) : launch(lists_frame_kernel<false, 0, false>);
+                else if (most > 4 * NBRW_THREADS && nw.compact) e = nw.ortho ? launch(lists_frame_kernel<true, 8, true>) : launch(lists_frame_kernel<false, 8, true>);
                 else if (most > 4 * NBRW_THREADS) e = nw.ortho ? launch(lists_frame_kernel<true, 8, false>) : launch(lists_frame_kernel<false, 8, false>);
                 else if (nw.compact) e = nw.ortho ? launch(lists_frame_kernel<true, 4, true>) : launch(lists_frame_kernel<false, 4, true>);
                 else e = nw.ortho ? launch(lists_frame_kernel<true, 4, false>) : launch(lists_frame_kernel<false, 4, false>);
@@ -2305,6 +2678,20 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 launches++;
             }
             timing_dom_end(ctx, launches);
+#ifdef NBR_PHASE_STAMPS
+            {
+                unsigned long long ph[16][5];
+                hipDeviceSynchronize();
+                hipMemcpyFromSymbol(ph, HIP_SYMBOL(nbr_phase_ticks), sizeof ph);
+                for (size_t e = 0; e < nw.items.size() && e < 16; e++)
+                    if (ph[e][4])
+                        fprintf(stderr, "lists entry %zu (species %d+%d, layers %d of %d, grid %dx%dx%d): us per workgroup: sort %.1f search %.1f unit vectors %.1f counts %.1f\n",
+                                e, nw.items[e].sa, nw.items[e].sb, nw.items[e].cn, nw.items[e].nzg, nw.items[e].nx, nw.items[e].ny, nw.items[e].nz,
+                                0.01 * ph[e][0] / ph[e][4], 0.01 * ph[e][1] / ph[e][4], 0.01 * ph[e][2] / ph[e][4], 0.01 * ph[e][3] / ph[e][4]);
+                memset(ph, 0, sizeof ph);
+                hipMemcpyToSymbol(HIP_SYMBOL(nbr_phase_ticks), ph, sizeof ph);
+            }
+#endif
             int32_t qflag = 0;
             AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nw.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
             AMOF_TRY(read_flags(flags));

@@ -108,6 +108,14 @@ def cn_counts(pos, cell, species, S, rcm, sets, pbc=(True, True, True), per_atom
     return (sums, pa) if per_atom else sums
 
 
+def acos(x):
+    """the fixed-algorithm arccos the angle code uses (amof_oracle_acos: fdlibm's rational approximation), elementwise"""
+    f = lib().amof_oracle_acos
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_double]
+    return np.array([f(float(v)) for v in np.asarray(x, dtype=np.float64).ravel()]).reshape(np.shape(x))
+
+
 def bad_hist(pos, cell, species, S, rcm, triples, edges, pbc=(True, True, True)):
     """``(hist u64 [T][nb], n_angles u64 [T])``."""
     pos, cell, pbc, species, F, N = _prep(pos, cell, pbc, species)

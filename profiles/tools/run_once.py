@@ -1,6 +1,6 @@
 """A few calls of one analysis on the headline workload, for rocprofv3 (kernel trace or --pmc passes).
 
-    rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES ... -d gpurun_out/pmc -- python3 profiles/tools/run_once.py msd|rdf|bad|cn|cfg4 [frames]
+    rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES ... -d gpurun_out/pmc -- python3 profiles/tools/run_once.py msd|rdf|bad|cn|bad3|cn3|cfg4 [frames]
 """
 import os
 import sys
@@ -39,6 +39,17 @@ elif what == "rdf":
     rmax = float(np.min(packed.cell_lengths()) / 2)
     for _ in range(reps):
         ctx.rdf_accumulate(packed, rmax, int(rmax // 0.01))
+elif what in ("bad3", "cn3"):       # the three-cutoff case: 17 triples / 3 + 3 sets over Zn+N, C+N, C+H
+    rcm = amatom.cutoff_matrix(amatom.format_cutoff({'Zn-N': 2.5, 'C-N': 1.6, 'C-H': 1.3}), kinds)
+    S = len(kinds)
+    if what == "bad3":
+        from amof_amd.bad import Bad
+        for _ in range(reps):
+            Bad.from_trajectory(packed, {'Zn-N': 2.5, 'C-N': 1.6, 'C-H': 1.3}, dtheta=0.05)
+    else:
+        sets = [(a, b) for a in range(S) for b in range(S) if rcm[a, b] > 0]
+        for _ in range(reps):
+            ctx.cn_count(packed, rcm, sets)
 else:
     rcm = amatom.cutoff_matrix(amatom.format_cutoff({'Zn-N': 2.5}), kinds)
     zn, n = kinds.index(30), kinds.index(7)

@@ -107,6 +107,33 @@ def by_triples(by, kinds):
     return out
 
 
+@pytest.mark.parametrize("path_env", [None, ("AMOF_NBR_NOFRAME", "1"), ("AMOF_NBR_SLABS", "1"), ("AMOF_NBR_KERNEL", "v1")])
+def test_angles_that_sit_on_histogram_edges(hip_ctx, monkeypatch, path_env):
+    """An exact simple cubic lattice with cutoff a sqrt(2): every angle is 45, 60, 90, 120, 135 or 180 degrees up to the last
+    place, and the edges are whole degrees -- the bin then depends on the last bit of arccos.  numpy's, glibc's and the
+    device library's arccos differ there (a soak case of round 4 found 73 angles binned differently); the kernels and the
+    oracle evaluate one published algorithm (fdlibm's), so every kernel family agrees with the oracle bit for bit."""
+    if path_env:
+        monkeypatch.setenv(*path_env)
+    m, a0 = 12, 2.7356674770047027
+    g = np.array([[x, y, z] for x in range(m) for y in range(m) for z in range(m)], dtype=float) / m
+    cell = np.diag([m * a0] * 3)
+    rng = np.random.default_rng(3)
+    numbers = np.where(rng.uniform(size=len(g)) < 0.5, 30, 7)
+    packed = PackedTrajectory((g @ cell)[None], cell, numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    for rc in (a0 * np.sqrt(2.0), np.nextafter(a0, 9.0)):
+        rcm = np.full((2, 2), rc)
+        rcm[1, 1] = 0.0
+        triples = [(0, 0), (-1, 0), (-1, 1), (1, 0), (0, -1), (1, -1), (-1, -1)]
+        edges = np.arange(182) * 1.0
+        got = hip_ctx.bad_hist(packed, rcm, triples, edges)
+        ref = clib.bad_hist(packed.pos, packed.cell, sp, 2, rcm, triples, edges)
+        assert np.array_equal(got[1], ref[1])
+        assert np.array_equal(got[0], ref[0]), (hip_ctx.last_path(), int(np.abs(got[0].astype(np.int64) - ref[0].astype(np.int64)).sum()))
+        assert ref[0][:, [45, 60, 90, 120, 135]].sum() + ref[0][:, [44, 59, 89, 119, 134]].sum() > 0
+
+
 def test_more_neighbours_than_the_lds_lists_hold(hip_ctx):
     """The reference has no limit on the neighbours of a centre (amof/bad.py:87-100).  A dense gas with ~100
     neighbours per atom exceeds the 32-entry LDS lists of the BAD kernels: the call goes through the big-list pass

@@ -728,8 +728,8 @@ def test_frame_tier_on_a_host_trajectory_staged_in_batches(hip_ctx):
 
 @pytest.mark.parametrize("n_pair", [4096, 4097, 8192, 8193])
 def test_frame_tier_atom_count_boundaries(hip_ctx, n_pair):
-    """4096 / 4097 atoms in a pair switch between the 4- and the 8-atoms-per-thread kernels, 8192 / 8193 between the
-    whole-frame tier and the gather kernels: one species alone, and two species sharing the count unevenly"""
+    """4096 / 4097 atoms in a pair switch between the 4- and the 8-atoms-per-thread kernels, 8192 / 8193 between one
+    workgroup per frame and z-slabs of the frame: one species alone, and two species sharing the count unevenly"""
     rng = np.random.default_rng(n_pair)
     L = (n_pair / 0.06) ** (1 / 3)
     cell = np.diag([L, 1.1 * L, 0.9 * L])
@@ -745,14 +745,99 @@ def test_frame_tier_atom_count_boundaries(hip_ctx, n_pair):
         got = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
         path = hip_ctx.last_path()
         # (two species: every pair of the call must fit -- the same-species pairs are smaller than the mixed one)
-        assert (path == "cn_frame") == (n_pair <= 8192), (n_pair, split, path)
+        assert path == ("cn_frame" if n_pair <= 8192 else "cn_frame_slabs"), (n_pair, split, path)
         ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (n_pair, split, path)
         triples = [(0, 0), (0, -1), (-1, -1)] if S == 1 else [(0, 1), (1, 0), (1, -1), (-1, -1)]
         hg = hip_ctx.bad_hist(packed, rcm, triples, edges)
-        assert (hip_ctx.last_path() == "bad_frame") == (n_pair <= 8192), (n_pair, split, hip_ctx.last_path())
+        assert hip_ctx.last_path() == ("bad_frame" if n_pair <= 8192 else "bad_frame_slabs"), (n_pair, split, hip_ctx.last_path())
         hr = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
         assert np.array_equal(hg[0], hr[0]) and np.array_equal(hg[1], hr[1]), (n_pair, split)
+
+
+@pytest.mark.parametrize("ortho", [True, False])
+def test_frame_tier_in_slabs_forced_on_small_frames(hip_ctx, monkeypatch, ortho):
+    """AMOF_NBR_SLABS=1 sends pairs that fit one workgroup through the streaming slab kernels (one or several z-slabs per
+    pair): counts per atom and all 17 triples of three cutoffs equal the oracle's and the whole-frame kernels', on the
+    orthorhombic and on the fixture's own triclinic lattice, frames in several batches"""
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (2, 2, 3)), 6, 0.04, 11, ortho=ortho)
+    kinds, sp = H.species_of(packed.numbers)
+    S = len(kinds)
+    zn, n, c, h = (kinds.index(z) for z in (30, 7, 6, 1))
+    rcm = np.zeros((S, S))
+    rcm[zn, n] = rcm[n, zn] = 2.5
+    rcm[c, n] = rcm[n, c] = 1.6
+    rcm[c, h] = rcm[h, c] = 1.25
+    rcm[c, c] = 1.6
+    rcm[zn, zn] = 6.3
+    sets = [(zn, n), (n, zn), (c, n), (n, c), (h, c), (c, c), (zn, zn)]
+    triples = [(a, b) for a in range(S) for b in range(S)] + [(-1, -1)]
+    edges = np.arange(182) * 1.0
+    whole = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+    assert hip_ctx.last_path() == "cn_frame"
+    h_whole = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_frame"
+    monkeypatch.setenv("AMOF_NBR_SLABS", "1")
+    got = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+    assert hip_ctx.last_path() == "cn_frame_slabs"
+    ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[0], whole[0]) and np.array_equal(got[1], whole[1])
+    monkeypatch.setenv("AMOF_BAD_ROWS_MB", "8")             # (several batches of neighbour rows)
+    hg = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_frame_slabs"
+    hr = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
+    assert np.array_equal(hg[0], hr[0]) and np.array_equal(hg[1], hr[1])
+    assert np.array_equal(hg[0], h_whole[0]) and np.array_equal(hg[1], h_whole[1])
+
+
+def test_frame_tier_keeps_a_4x4x4_supercell(hip_ctx):
+    """Review item (round 3): 17 408 atoms (4 x 4 x 4 ZIF-4; C + H = 12 288 atoms, C + N = 10 240) stay on the frame tier,
+    in z-slabs; counts and angles equal the oracle's"""
+    packed = H.random_walk(H.replicate(H.zif4_frame(), (4, 4, 4)), 2, 0.05, 3, ortho=False)
+    assert packed.pos.shape[1] == 17408
+    kinds, sp = H.species_of(packed.numbers)
+    S = len(kinds)
+    zn, n, c, h = (kinds.index(z) for z in (30, 7, 6, 1))
+    rcm = np.zeros((S, S))
+    rcm[zn, n] = rcm[n, zn] = 2.5
+    rcm[c, n] = rcm[n, c] = 1.6
+    rcm[c, h] = rcm[h, c] = 1.25
+    sets = [(zn, n), (n, zn), (c, n), (n, c), (h, c), (c, h)]
+    got = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+    assert hip_ctx.last_path() == "cn_frame_slabs"
+    ref = clib.cn_counts(packed.pos, packed.cell, sp, S, rcm, sets, per_atom=True)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    triples = [(a, b) for a in range(S) for b in range(S)] + [(-1, -1)]
+    edges = np.arange(182) * 1.0
+    hg = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert hip_ctx.last_path() == "bad_frame_slabs"
+    hr = clib.bad_hist(packed.pos, packed.cell, sp, S, rcm, triples, edges)
+    assert np.array_equal(hg[0], hr[0]) and np.array_equal(hg[1], hr[1])
+
+
+def test_frame_tier_slab_denser_than_its_records_falls_back(hip_ctx):
+    """a slab sized for its expected share of the atoms (+ 20 % + 128) that meets a much denser layer raises the overflow
+    flag; the gather kernels then answer, with the oracle's counts"""
+    rng = np.random.default_rng(9)
+    N, L = 12000, 60.0
+    z = np.concatenate([rng.normal(30.0, 2.0, 8000), rng.uniform(0, L, N - 8000)]) % L
+    pos = np.column_stack([rng.uniform(0, L, (N, 2)), z])[None]
+    numbers = np.where(np.arange(N) % 2 == 0, 30, 7)
+    packed = PackedTrajectory(pos, np.diag([L] * 3), numbers)
+    kinds, sp = H.species_of(packed.numbers)
+    rcm = np.full((2, 2), 1.5)
+    sets = [(0, 1), (1, 1)]
+    got = hip_ctx.cn_count(packed, rcm, sets, per_atom=True)
+    assert hip_ctx.last_path() in ("cn_cell", "cn_fast"), hip_ctx.last_path()
+    ref = clib.cn_counts(packed.pos, packed.cell, sp, 2, rcm, sets, per_atom=True)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    triples = [(0, 1), (1, 0), (-1, -1)]
+    edges = np.arange(182) * 1.0
+    hg = hip_ctx.bad_hist(packed, rcm, triples, edges)
+    assert not hip_ctx.last_path().startswith("bad_frame"), hip_ctx.last_path()
+    hr = clib.bad_hist(packed.pos, packed.cell, sp, 2, rcm, triples, edges)
+    assert np.array_equal(hg[0], hr[0]) and np.array_equal(hg[1], hr[1])
 
 
 @pytest.mark.parametrize("records", ["1", "0"])

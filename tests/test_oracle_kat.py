@@ -228,3 +228,25 @@ def test_ideal_gas_discriminates_the_shell_volume(monkeypatch):
     np.testing.assert_allclose(g_mid / g_exact, 1.0 + 1.0 / (3.0 * (2 * b + 1) ** 2), rtol=1e-13)
     # the midpoint shell is off by 33 % / 3.7 % in the first two bins: tens of sigma
     assert abs(g_mid[0] / expect - 1.0) > 0.3 and abs(g_mid[1] / expect - 1.0) > 10 * sigma[1]
+
+
+def test_arccos_of_the_angle_code_is_the_published_algorithm_within_one_ulp():
+    """The oracle (and the GPU kernels) evaluate arccos by ONE fixed algorithm (fdlibm's rational approximation) instead
+    of whatever library is at hand: numpy's float64 arccos is itself CPU-dependent and differs from the correctly rounded
+    value in the last place for a few percent of the arguments.  Pinned here: within one unit in the last place of the
+    true value (mpmath, 200 bits) over the whole domain, exact at the ends, and within one ulp of numpy's."""
+    mpmath = pytest.importorskip("mpmath")
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.uniform(-1, 1, 4000), 1 - 10.0 ** rng.uniform(-16, 0, 1500), -1 + 10.0 ** rng.uniform(-16, 0, 1500),
+                        [0.0, 0.5, -0.5, 1.0, -1.0, 0.7071067811865476, 0.7071067811865475, -0.7071067811865476, 1e-20, -1e-20]])
+    got = clib.acos(x)
+    worst = 0.0
+    for xv, yv in zip(x, got):
+        t = mpmath.acos(mpmath.mpf(float(xv)))
+        ulp = np.spacing(float(t)) if float(t) != 0.0 else 5e-324
+        worst = max(worst, abs(float((mpmath.mpf(float(yv)) - t) / ulp)))
+    assert worst < 1.0, worst
+    assert clib.acos(1.0) == 0.0 and clib.acos(-1.0) == np.pi and clib.acos(0.0) == np.pi / 2
+    ref = np.arccos(x)
+    assert np.all(np.abs(got - ref) <= np.spacing(np.maximum(ref, 1e-300)))

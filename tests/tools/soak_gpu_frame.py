@@ -1,5 +1,5 @@
 """Randomized parity soak for the whole-frame-in-LDS tier of CN / BAD (cn_frame_kernel, lists_frame_kernel,
-bad_rows_kernel): random gases, jittered lattices (pairs near the cutoff) and ZIF-4 walks, orthorhombic / sheared /
+bad_rows_kernel; whole frames and z-slabs): random gases, jittered lattices (pairs near the cutoff) and ZIF-4 walks, orthorhombic / sheared /
 breathing cells, sparse cutoff matrices, same-species pairs, 'X' triples, per-atom counts, BadByCn keys, uniform and
 ragged bin edges -- against the C oracle.  Run by hand on a GPU box: `python tests/tools/soak_gpu_frame.py SECONDS`
 (not collected by pytest)."""
@@ -27,13 +27,19 @@ while time.time() < t_end:
     seed += 1
     rng = np.random.default_rng(seed)
     mode = seed % 4
+    # every third case through the z-slab kernels whatever its size (the others: slabs only where a pair is too big for one
+    # workgroup -- N = 14000 below)
+    if seed % 3 == 1:
+        os.environ["AMOF_NBR_SLABS"] = "1"
+    else:
+        os.environ.pop("AMOF_NBR_SLABS", None)
     if mode == 0:       # ZIF-4 supercell walk (the bench's system, smaller)
         rep = tuple(int(x) for x in rng.integers(1, 4, 3))
         packed = H.random_walk(H.replicate(H.zif4_frame(), rep), int(rng.integers(1, 4)), float(rng.choice([0.02, 0.1, 0.3])),
                                seed, ortho=bool(seed % 8 < 4), cell_jitter=0.01 if seed % 16 < 4 else 0.0)
     else:
         S = int(rng.integers(1, 5))
-        N = int(rng.choice([300, 900, 2500, 6000, 9000]))
+        N = int(rng.choice([300, 900, 2500, 6000, 9000, 14000]))
         rho = rng.uniform(0.03, 0.09)
         shape = rng.choice([1.0, 1.0, 2.0, 3.0], 3)
         L = shape * (N / rho / shape.prod()) ** (1 / 3)
