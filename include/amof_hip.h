@@ -104,8 +104,10 @@ int64_t amof_last_kernel_launches(const amof_ctx *ctx);
  *        lattice frame, f32 slab coordinates), "rdf_tile" (plain general tile kernel), "rdf_tile_img" (cutoffs beyond
  *        half a cell height where "rdf_tile_tri" does not apply), "rdf_cell" (3-D cell list), "rdf_range" (2-level list),
  *        "rdf_exact" (canonical float64 arithmetic per pair)
- *   CN   "cn_frame" (whole frame in LDS), "cn_cell", "cn_fast", "cn_exact"
- *   BAD  "bad_frame" (whole frame in LDS), "bad_cell", "bad_fast", "bad_exact", "bad_exact_biglist"
+ *   CN   "cn_frame" (whole frame in LDS), "cn_frame_slabs" (z-slabs of a frame in LDS: pairs of more than 8192 atoms),
+ *        "cn_cell", "cn_fast", "cn_exact"
+ *   BAD  "bad_frame" (whole frame in LDS), "bad_frame_slabs" (z-slabs of a frame in LDS), "bad_cell", "bad_fast",
+ *        "bad_exact", "bad_exact_biglist"
  *   MSD  "msd_stream" (register-ring comb, window spacing 64..256), "msd_comb" (block comb kernels incl. the
  *        double-buffered and > 32-window passes), "msd_group" (arbitrary window lists), "msd_comb_global" /
  *        "msd_global" (series too long for LDS), "msd_direct", "msd_com" (amof_msd_com_dev alone) */
