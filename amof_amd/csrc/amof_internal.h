@@ -274,10 +274,12 @@ __device__ __forceinline__ void fold_atom(QAtom &q, const double *__restrict__ f
     q.uy += (uint32_t)(long long)rint(z * fold[1]);
 }
 
-// ax0, ax1: the stored order of the two axes that are not the slab axis; d_fold (optional, device [n_cells][2]): fold_atom
+// ax0, ax1: the stored order of the two axes that are not the slab axis; d_fold (optional, device [n_cells][2]): fold_atom;
+// used_mask: bit s clear = species s (< 64) is neither sorted nor written
 int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                     const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis, QAtom *d_Q,
-                    uint32_t *d_slab_start, int32_t *d_flag, int ax0 = -1, int ax1 = -1, const double *d_fold = nullptr);
+                    uint32_t *d_slab_start, int32_t *d_flag, int ax0 = -1, int ax1 = -1, const double *d_fold = nullptr,
+                    unsigned long long used_mask = ~0ull);
 
 int launch_quantize2(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                      const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis_z, int axis_y, int nz,

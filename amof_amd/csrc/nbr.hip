@@ -2097,8 +2097,13 @@ static int frame_slab_buffers(amof_ctx *ctx, const amof_traj *t, NbrFrame &nw, i
 }
 static int frame_slab_quantize(amof_ctx *ctx, const amof_traj *t, const NbrArgs &a, NbrFrame &nw, int64_t fb, int64_t nfr)
 {
+    unsigned long long used = 0ull;         // only the species some pair of the call reads
+    for (const FrameItem &it : nw.items) {
+        used |= it.sa < 64 ? 1ull << it.sa : 0ull;
+        used |= it.sb < 64 ? 1ull << it.sb : 0ull;
+    }
     return launch_quantize(ctx, a.pos, a.geom, (int)t->n_cells, a.perm, nw.d_spfirst, t->n_species, t->n_atoms, (int)fb, (int)nfr, 2,
-                           (QAtom *)nw.fr.Q, (uint32_t *)nw.fr.zstart, (int32_t *)nw.d_qflag, 0, 1);
+                           (QAtom *)nw.fr.Q, (uint32_t *)nw.fr.zstart, (int32_t *)nw.d_qflag, 0, 1, nullptr, used);
 }
 
 // Record size of the tier, three passes: 0 = 16-byte records, 1 = COMPACT 8-byte ones, 2 = 16-byte again.  AMOF_NBR_COMPACT=1

@@ -20,8 +20,10 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_kernel(const double *_
                                                        const int64_t *__restrict__ sp_first, int S, int64_t N,
                                                        int f0, int axis, QAtom *__restrict__ Q,
                                                        uint32_t *__restrict__ slab_start, int32_t *flag, int cache_cap,
-                                                       int ax0, int ax1, const double *__restrict__ fold)
+                                                       int ax0, int ax1, const double *__restrict__ fold,
+                                                       unsigned long long used_mask)
 {
+    if (blockIdx.x < 64 && !((used_mask >> blockIdx.x) & 1ull)) return;    // (a species nobody reads: neither sorted nor written)
     // species segments of up to cache_cap atoms keep their quantised records in LDS between the
     // counting pass and the placement pass, so the positions are read from HBM once
     extern __shared__ __align__(16) unsigned char qcache_raw[];
@@ -358,7 +360,7 @@ int launch_quantize_cells(amof_ctx *ctx, const double *pos_dev, const double *d_
 
 int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_perm,
                     const int64_t *d_spfirst, int S, int64_t N, int f0, int nf, int axis, QAtom *d_Q,
-                    uint32_t *d_slab_start, int32_t *d_flag, int ax0, int ax1, const double *d_fold)
+                    uint32_t *d_slab_start, int32_t *d_flag, int ax0, int ax1, const double *d_fold, unsigned long long used_mask)
 {
     if (ax0 < 0 || ax1 < 0) { ax0 = (axis + 1) % 3; ax1 = (axis + 2) % 3; }
     if (nf <= 0 || S <= 0) return AMOF_OK;
@@ -370,7 +372,7 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
     const size_t lds = (size_t)cache_cap * sizeof(QAtom);
     AMOF_HIP_TRY(ctx, allow_max_lds((const void *)quantize_kernel));
     hipLaunchKernelGGL(quantize_kernel, qgrid, dim3(QUANT_THREADS), lds, ctx->stream, pos_dev, d_geom, n_cells, d_perm, d_spfirst,
-                       S, N, f0, axis, d_Q, d_slab_start, d_flag, cache_cap, ax0, ax1, d_fold);
+                       S, N, f0, axis, d_Q, d_slab_start, d_flag, cache_cap, ax0, ax1, d_fold, used_mask);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     return AMOF_OK;
 }
