@@ -687,7 +687,10 @@ __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
 }
 
 template <bool ORTHO, bool CULL, bool IMG = false, bool ZFK = false, int TRI = -1>
-__global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
+// (TRI variants with near tests in the fast path, NEAR 2 / 3: four workgroups per CU at 128 VGPRs -- at 96 they spill 160 - 240
+//  bytes per lane into the quad loops, 7x the vector-memory instructions of the diagonal kernel: NPT cell 1.24 -> 1.17x the
+//  diagonal cell, 10 % shear 2.5 -> 2.1x; the variants without such tests lose more to the fifth workgroup than to their spills)
+__global__ __launch_bounds__(FAST_THREADS, (TRI >= 0 && (TRI % 5 == 2 || TRI % 5 == 3)) ? 4 : 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
     // TRI >= 0: general cells in the orthogonalised lattice frame (fast_quad_tri; TRI % 5: near tests, TRI / 5: x wrap with the y term)
     static_assert(!ZFK || (ORTHO && !IMG) || TRI >= 0, "f32 slab coordinates: diagonal cells (no image queue) or TRI");
@@ -1644,6 +1647,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             if (!(fast_guard_tri(nbins, hb, 0.5, tri_l10_bins) * (1.0 + 4.0 * tri_tau) + 2.0 * quant / dr +
                   (1.0 + 256.0 * tri_c10) * 1.5 * csum * two32_ / dr + (double)nbins * 1e-12 < 0.25)) tri = false;
         }
+        if (tri && getenv("AMOF_RDF_DEBUG"))
+            fprintf(stderr, "rdf_tile_tri: code %d (near mode %d, x wrap %d) axes (%d, %d | %d) parked share %.4f tau %.5f c10 %.5f\n", tri_code, tri_code % 5,
+                    tri_code / 5, tri_ax0, tri_ax1, tri_axis, tri_share, tri_tau, tri_c10);
         bool done = false;
         const bool fast_plain = fast;      // the cell-list / range kernels below rest on the plain criterion (cutoff clear of every half height)
         if (tri) { fast = true; fast_img = false; }
