@@ -18,6 +18,8 @@ import logging
 import numpy as np
 import pandas as pd
 
+from ._lazy import EmptyUntilComputed
+
 from . import _hip
 from . import atom as amatom
 from . import data as _data
@@ -68,9 +70,11 @@ class Bad(CoreBad):
     Main class for bad
     """
 
+    data = EmptyUntilComputed("theta")      # (the reference's empty first-column frame, built on first look)
+
     def __init__(self):
         """default constructor"""
-        self.data = pd.DataFrame({"theta": np.empty([0])})
+        self.data = None
 
     def compute_bad(self, trajectory, nb_set_and_cutoff, dtheta, normalization='total', parallel=False,
                     device=None, distributed=None):

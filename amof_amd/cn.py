@@ -11,6 +11,8 @@ import logging
 import numpy as np
 import pandas as pd
 
+from ._lazy import EmptyUntilComputed
+
 from . import _hip
 from . import atom as amatom
 from . import data as _data
@@ -27,9 +29,11 @@ class CoordinationNumber(object):
     Main class to compute CoordinationNumber
     """
 
+    data = EmptyUntilComputed("Step")      # (the reference's empty first-column frame, built on first look)
+
     def __init__(self):
         """default constructor"""
-        self.data = pd.DataFrame({"Step": np.empty([0])})
+        self.data = None
 
     @classmethod
     def from_trajectory(cls, trajectory, nb_set_and_cutoff, delta_Step=1, first_frame=0, parallel=False,

@@ -16,6 +16,8 @@ import logging
 import numpy as np
 import pandas as pd
 
+from ._lazy import EmptyUntilComputed
+
 from . import _hip
 from . import data as _data
 from . import dist as _dist
@@ -60,9 +62,11 @@ class DirectMsd(Msd):
     for orthogonal cells.  Better to use WindowMsd.
     """
 
+    data = EmptyUntilComputed("Step")      # (the reference's empty first-column frame, built on first look)
+
     def __init__(self):
         """default constructor"""
-        self.data = pd.DataFrame({"Step": np.empty([0])})
+        self.data = None
         logger.warning('DirectMsd is deprecated and not suitable for non-orthogonal cells, use WindowMsd instead')
 
     @classmethod
@@ -103,9 +107,11 @@ class WindowMsd(Msd):
     Time is expressed in fs.
     """
 
+    data = EmptyUntilComputed("Time")      # (the reference's empty first-column frame, built on first look)
+
     def __init__(self):
         """default constructor"""
-        self.data = pd.DataFrame({"Time": np.empty([0])})
+        self.data = None
 
     @classmethod
     def from_trajectory(cls, trajectory, delta_time=100, max_time="half", timestep=1, parallel=False,

@@ -14,6 +14,8 @@ import os
 import numpy as np
 import pandas as pd
 
+from ._lazy import EmptyUntilComputed
+
 from . import _hip
 from . import data as _data
 from . import dist as _dist
@@ -63,9 +65,11 @@ class Rdf(object):
     Main class for rdf
     """
 
+    data = EmptyUntilComputed("r")      # (the reference's empty first-column frame, built on first look)
+
     def __init__(self):
         """default constructor"""
-        self.data = pd.DataFrame({"r": np.empty([0])})
+        self.data = None
 
     @classmethod
     def from_trajectory(cls, trajectory, dr=0.01, rmax='half_cell', device=None, distributed=None):
@@ -295,10 +299,12 @@ class CoordinationNumber(object):
     (amof/rdf.py:181-185); what is computed here is the evident intent, the RDF of that frame.
     """
 
+    data = EmptyUntilComputed("Step")      # (the reference's empty first-column frame, built on first look)
+
     def __init__(self):
         """default constructor"""
         logger.warning('Compute CoordinationNumber from RDF, best to use amof.cn.CoordinationNumber')
-        self.data = pd.DataFrame({"Step": np.empty([0])})
+        self.data = None
 
     @classmethod
     def from_trajectory(cls, trajectory, nb_set_and_cutoff, delta_Step=1, first_frame=0, dr=0.0001, parallel=False,
