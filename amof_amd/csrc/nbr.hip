@@ -1236,9 +1236,10 @@ __global__ __launch_bounds__(256) void bad_transposed_kernel(NbrFastArgs fa, con
 // three sorts and three LDS searches.
 constexpr int NBRL_CAP = NBRF_NLIST;      // a fuller centre sends the call to the exact kernels, as in bad_fast_kernel
 constexpr int NBRL_EW = 4;                // doubles per row entry: (ux, uy, uz, -) -- one aligned 32-byte sector per unit vector
-constexpr int NBRW_HITS = 3072;           // pairs lists_frame_kernel buffers in LDS, flushed once a third full: a round of 1024
-                                          // tasks may then add 2048 (two neighbours per centre and ROW of cells) before the call
-                                          // has to fall back to the exact kernels
+constexpr int NBRW_HITS = 4096;           // pairs lists_frame_kernel buffers in LDS: 256 per wave, flushed by the wave itself once it
+                                          // holds more than 64 -- its next 64 tasks may then add 128 (two neighbours per centre and
+                                          // ROW of cells) and 64 more (third neighbours) before the call falls back to the exact kernels
+constexpr int NBRW_HITS_WAVE = NBRW_HITS / (NBRW_THREADS / 64);
 
 struct NbrListArgs {
     const int32_t *region_of;  // [S][S] first row of the ordered pair (centre species, partner species); -1: not kept
@@ -1283,9 +1284,12 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
     // pairs found, (centre << 13 | partner) by sorted position, waiting for their unit vector: computing it inside the
     // search loop made every wave pay the float64 path on every trip (some lane always has a hit)
     uint32_t *hits = cnt + (n + 3) / 4;
-    __shared__ unsigned nhits;
+    // Every wave has its own piece of the buffer and flushes it itself: no barrier between the sort and the counts.  (Round 3
+    // flushed the whole buffer behind a barrier after every round of 1024 tasks: a round then lasted as long as the fullest of
+    // its 1024 rows, 2.4 us -- 71 of the 94 us of a C + H frame.)
+    __shared__ unsigned nh_w[NBRW_THREADS / 64];
     for (int c = tid; c < (n + 3) / 4; c += NBRW_THREADS) cnt[c] = 0u;
-    if (tid == 0) nhits = 0u;
+    if (tid < NBRW_THREADS / 64) nh_w[tid] = 0u;
     int ncen = nA, cbeg = 0, first = nB > 0 ? nA : 0, total = nA + nB;
     NBR_STAMP(ts0)
     if constexpr (SLAB) {
@@ -1304,63 +1308,19 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
     for (int k = 0; k < 9; k++) sc[k] = fr.cells[gi].sc[k];
     const double rc = a.cutoff[it.sa * a.S + it.sb];
     const size_t base = (size_t)fl * la.R;
-    const int lane = tid & 63;
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t *hw = hits + wave * NBRW_HITS_WAVE;
+    unsigned *nhp = &nh_w[wave];
     auto claim = [&](int c) -> unsigned {       // next free slot of the atom at sorted position c
         const unsigned sh = 8u * ((unsigned)c & 3u);
         return (atomicAdd(&cnt[c >> 2], 1u << sh) >> sh) & 0xffu;
     };
-    const int tasks = ncen * 9;
-    for (int t0 = 0; t0 < tasks; t0 += NBRW_THREADS) {
-        const int t = t0 + tid;
-        NBR_STAMP(tr0)
-        // a task keeps its first two pairs in registers and the wave appends them with ONE LDS atomic after the search (a
-        // ballot + atomic + shuffle on every trip of the candidate loop tripled the search: 24 us against 7 in cn_frame_kernel);
-        // a third pair of one centre in one row of cells is appended on the spot
-        int h0 = 0, h1 = 0, mine = 0;
-        const int c = cbeg + (t < tasks ? t / 9 : 0);
-        if (t < tasks) {
-            const int r9 = t % 9;
-            frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, first, sc, geo, p, c, nB == 0, frame_rec<COMPACT>(L, c), r9, rc,
-                                                 [&](bool nbr, int j) {
-                if (!nbr) return;
-                if (mine == 0) h0 = j;
-                else if (mine == 1) h1 = j;
-                else {
-                    const unsigned h = atomicAdd(&nhits, 1u);
-                    if (h < (unsigned)NBRW_HITS) hits[h] = ((uint32_t)c << 13) | (uint32_t)j;
-                    else a.flags[1] = 1;
-                }
-                mine++;
-            });
-        }
-        {
-            const unsigned long long m1 = __ballot(mine >= 1), m2 = __ballot(mine >= 2);
-            if (m1) {
-                const int leader = __ffsll((long long)m1) - 1;
-                unsigned h = 0;
-                if (lane == leader) h = atomicAdd(&nhits, (unsigned)(__popcll(m1) + __popcll(m2)));
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                h = __shfl(h, leader, 64) + (unsigned)(__popcll(m1 & lt) + __popcll(m2 & lt));
-                if (mine >= 1) {
-                    if (h < (unsigned)NBRW_HITS) hits[h] = ((uint32_t)c << 13) | (uint32_t)h0;
-                    else a.flags[1] = 1;        // (absurdly many pairs: the exact kernels take the call)
-                }
-                if (mine >= 2) {
-                    if (h + 1 < (unsigned)NBRW_HITS) hits[h + 1] = ((uint32_t)c << 13) | (uint32_t)h1;
-                    else a.flags[1] = 1;
-                }
-            }
-        }
-        // flush once the buffer is a third full, and after the last round (the OR makes the decision uniform: a thread may
-        // read the counter while slower ones still append)
-        const bool filling = __syncthreads_or(nhits > (unsigned)NBRW_HITS / 3);
-        NBR_STAMP(tr1)
-        NBR_PHASE(1, tr1, tr0)
-        if (!filling && t0 + NBRW_THREADS < tasks) continue;
-        // one lane per pair: the canonical unit vector once, to the centre's row and, negated, to the partner's
-        const unsigned nh = min(nhits, (unsigned)NBRW_HITS);
-        for (unsigned h = tid; h < nh; h += NBRW_THREADS) {
-            const int c = (int)(hits[h] >> 13), j = (int)(hits[h] & 0x1fffu);
+    // one lane per buffered pair of this wave: the canonical unit vector once, to the centre's row and, negated, to the partner's
+    auto flush = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (a wave's LDS operations execute in order: its appends are in place)
+        const unsigned nh = min(__atomic_load_n(nhp, __ATOMIC_RELAXED), (unsigned)NBRW_HITS_WAVE);
+        for (unsigned h = lane; h < nh; h += 64) {
+            const int c = (int)(hw[h] >> 13), j = (int)(hw[h] & 0x1fffu);
             uint32_t atom_c, atom_j;
             int rank_c, rank_j;
             if (COMPACT) {
@@ -1394,12 +1354,56 @@ __global__ __launch_bounds__(NBRW_THREADS, (PT == 8 && !COMPACT) ? 4 : 8) void l
                 }
             }
         }
-        __syncthreads();
-        if (tid == 0) nhits = 0u;
-        __syncthreads();
-        NBR_STAMP(tr2)
-        NBR_PHASE(2, tr2, tr1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __atomic_store_n(nhp, 0u, __ATOMIC_RELAXED);
+    };
+    const int tasks = ncen * 9;
+    for (int t0 = wave * 64; t0 < tasks; t0 += NBRW_THREADS) {
+        const int t = t0 + lane;
+        // a task keeps its first two pairs in registers and the wave appends them with ONE LDS atomic after the search (a
+        // ballot + atomic + shuffle on every trip of the candidate loop tripled the search: 24 us against 7 in cn_frame_kernel);
+        // a third pair of one centre in one row of cells is appended on the spot
+        int h0 = 0, h1 = 0, mine = 0;
+        const int c = cbeg + (t < tasks ? t / 9 : 0);
+        if (t < tasks) {
+            const int r9 = t % 9;
+            frame_row_neighbours<ORTHO, COMPACT>(fr, it, L, first, sc, geo, p, c, nB == 0, frame_rec<COMPACT>(L, c), r9, rc,
+                                                 [&](bool nbr, int j) {
+                if (!nbr) return;
+                if (mine == 0) h0 = j;
+                else if (mine == 1) h1 = j;
+                else {
+                    const unsigned h = atomicAdd(nhp, 1u);
+                    if (h < (unsigned)NBRW_HITS_WAVE) hw[h] = ((uint32_t)c << 13) | (uint32_t)j;
+                    else a.flags[1] = 1;
+                }
+                mine++;
+            });
+        }
+        {
+            const unsigned long long m1 = __ballot(mine >= 1), m2 = __ballot(mine >= 2);
+            if (m1) {
+                const int leader = __ffsll((long long)m1) - 1;
+                unsigned h = 0;
+                if (lane == leader) h = atomicAdd(nhp, (unsigned)(__popcll(m1) + __popcll(m2)));
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                h = __shfl(h, leader, 64) + (unsigned)(__popcll(m1 & lt) + __popcll(m2 & lt));
+                if (mine >= 1) {
+                    if (h < (unsigned)NBRW_HITS_WAVE) hw[h] = ((uint32_t)c << 13) | (uint32_t)h0;
+                    else a.flags[1] = 1;        // (absurdly many pairs: the exact kernels take the call)
+                }
+                if (mine >= 2) {
+                    if (h + 1 < (unsigned)NBRW_HITS_WAVE) hw[h + 1] = ((uint32_t)c << 13) | (uint32_t)h1;
+                    else a.flags[1] = 1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (__atomic_load_n(nhp, __ATOMIC_RELAXED) > 64u) flush();          // (the same word for every lane: a uniform decision)
     }
+    flush();
+    NBR_STAMP(tr2)
+    NBR_PHASE(1, tr2, ts1)
     __syncthreads();
     NBR_STAMP(tc0)
     for (int c = tid; c < total; c += NBRW_THREADS) {
@@ -2692,7 +2696,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
                 hipMemcpyFromSymbol(ph, HIP_SYMBOL(nbr_phase_ticks), sizeof ph);
                 for (size_t e = 0; e < nw.items.size() && e < 16; e++)
                     if (ph[e][4])
-                        fprintf(stderr, "lists entry %zu (species %d+%d, layers %d of %d, grid %dx%dx%d): us per workgroup: sort %.1f search %.1f unit vectors %.1f counts %.1f\n",
+                        fprintf(stderr, "lists entry %zu (species %d+%d, layers %d of %d, grid %dx%dx%d): us per workgroup: sort %.1f search + unit vectors (wave 0) %.1f (-) %.1f counts %.1f\n",
                                 e, nw.items[e].sa, nw.items[e].sb, nw.items[e].cn, nw.items[e].nzg, nw.items[e].nx, nw.items[e].ny, nw.items[e].nz,
                                 0.01 * ph[e][0] / ph[e][4], 0.01 * ph[e][1] / ph[e][4], 0.01 * ph[e][2] / ph[e][4], 0.01 * ph[e][3] / ph[e][4]);
                 memset(ph, 0, sizeof ph);
