@@ -667,8 +667,13 @@ __device__ __forceinline__ void fast_quad_tri(unsigned *hist, const RdfFastArgs 
                     rdf_pair_images<false>(hist, fa, g, p, idc, idj, gi);
                 }
             };
-            if (na[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qa[u], uax, uay, uaz, qj[u], zaf, clampv, [&]() { park(ida); });
-            if (nb[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qb[u], ubx, uby, ubz, qj[u], zbf, clampv, [&]() { park(idb); });
+            // (the partner's record is read from LDS again here: four records held in registers across the eight slow-path
+            //  bodies of a quad are 16 of the 96 VGPRs, and the TRI variants spilled 136 - 240 bytes per lane into these loops)
+            if (na[u] | nb[u]) {
+                const uint4 qr = tq[j0 + u];
+                if (na[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qa[u], uax, uay, uaz, qr, zaf, clampv, [&]() { park(ida); });
+                if (nb[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qb[u], ubx, uby, ubz, qr, zbf, clampv, [&]() { park(idb); });
+            }
         }
     }
 }
