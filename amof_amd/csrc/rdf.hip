@@ -656,16 +656,14 @@ __device__ __forceinline__ void fast_quad_tri(unsigned *hist, const RdfFastArgs 
         nb[u] = fast_bin_tri<ZF, NEAR, XW>(hist, sc, tc, lb, half_m_guard, ubx, uby, ubz, qj[u], qb[u], zbf, clampv, ZF && !DIAG && !TAIL);
     }
     if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {
+        unsigned ovf = 0u;      // pairs of this lane that found the queue full: bit 2 u + (0: centre a, 1: centre b)
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             auto park = [&](uint32_t idc) {
                 const uint32_t idj = scalar_idx(qseg + (j0 + u));
                 const unsigned slot = atomicAdd(nq_count, 1u);
-                if (slot < nq_cap) {
-                    nq[slot] = make_uint2(idc, idj);
-                } else {        // queue full (perfect lattices: every pair on a bin edge): in place
-                    rdf_pair_images<false>(hist, fa, g, p, idc, idj, gi);
-                }
+                if (slot < nq_cap) nq[slot] = make_uint2(idc, idj);
+                else ovf |= 1u << (2 * u + (idc == idb ? 1 : 0));       // (evaluated below: ONE copy of the canonical body per quad loop, not eight)
             };
             // (the partner's record is read from LDS again here: four records held in registers across the eight slow-path
             //  bodies of a quad are 16 of the 96 VGPRs, and the TRI variants spilled 136 - 240 bytes per lane into these loops)
@@ -674,6 +672,11 @@ __device__ __forceinline__ void fast_quad_tri(unsigned *hist, const RdfFastArgs 
                 if (na[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qa[u], uax, uay, uaz, qr, zaf, clampv, [&]() { park(ida); });
                 if (nb[u]) rdf_pair_refine_tri<ZF, NEAR, XW>(hist, fa, sc, tc, sc64, qb[u], ubx, uby, ubz, qr, zbf, clampv, [&]() { park(idb); });
             }
+        }
+        if (ovf) {      // queue full (perfect lattices: every pair on a bin edge): in place
+#pragma unroll 1
+            for (int k = 0; k < 8; k++)
+                if ((ovf >> k) & 1u) rdf_pair_images<false>(hist, fa, g, p, (k & 1) ? idb : ida, scalar_idx(qseg + (j0 + (k >> 1))), gi);
         }
     }
 }
@@ -692,10 +695,11 @@ __device__ __forceinline__ void dma_1k(const QAtom *src_lane, uint4 *dst_wave)
 }
 
 template <bool ORTHO, bool CULL, bool IMG = false, bool ZFK = false, int TRI = -1>
-// (TRI variants with near tests in the fast path, NEAR 2 / 3: four workgroups per CU at 128 VGPRs -- at 96 they spill 160 - 240
-//  bytes per lane into the quad loops, 7x the vector-memory instructions of the diagonal kernel: NPT cell 1.24 -> 1.17x the
-//  diagonal cell, 10 % shear 2.5 -> 2.1x; the variants without such tests lose more to the fifth workgroup than to their spills)
-__global__ __launch_bounds__(FAST_THREADS, (TRI >= 0 && (TRI % 5 == 2 || TRI % 5 == 3)) ? 4 : 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
+// (five workgroups per CU, 96 VGPRs.  The TRI variants once spilled 136 - 240 bytes per lane at that budget -- 7x the vector-
+//  memory instructions of the diagonal kernel -- and the ones with near tests in the fast path ran better at four workgroups
+//  and 128 VGPRs; since their slow path reads the partner's record from LDS again and the canonical fallback of a full queue
+//  exists once per quad loop instead of eight times, all of them fit: profiles/r04/tri_experiments.txt)
+__global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastArgs fa)
 {
     // TRI >= 0: general cells in the orthogonalised lattice frame (fast_quad_tri; TRI % 5: near tests, TRI / 5: x wrap with the y term)
     static_assert(!ZFK || (ORTHO && !IMG) || TRI >= 0, "f32 slab coordinates: diagonal cells (no image queue) or TRI");
