@@ -290,3 +290,24 @@ def test_every_kernel_family_is_pinned_by_a_forced_path_test():
                 if "last_path()" in line or "want" in line:
                     tested |= set(re.findall(r'"((?:rdf|cn|bad|msd)_[a-z_0-9]+)"', line))
     assert emitted <= tested, sorted(emitted - tested)
+
+
+def test_constructors_start_with_the_reference_s_empty_frame_built_on_first_look():
+    """The reference's constructors hold an empty DataFrame with the first column (amof/rdf.py:62-64, msd.py:31-33,174-176,
+    bad.py:44-46, cn.py:30-32); here it is built when first looked at (amof_amd/_lazy.py) -- same columns, one object per
+    instance, replaced by assignment, survives pickling"""
+    import pickle
+    from amof_amd.rdf import Rdf, CoordinationNumber as RdfCn
+    from amof_amd.msd import WindowMsd, DirectMsd
+    from amof_amd.bad import Bad, BadByCn
+    from amof_amd.cn import CoordinationNumber
+    for cls, col in ((Rdf, "r"), (RdfCn, "Step"), (WindowMsd, "Time"), (DirectMsd, "Step"), (Bad, "theta"), (CoordinationNumber, "Step")):
+        a, b = cls(), cls()
+        assert "_data" not in a.__dict__ or a.__dict__["_data"] is None
+        assert list(a.data.columns) == [col] and len(a.data) == 0 and a.data.dtypes[col] == np.float64
+        assert a.data is a.data and a.data is not b.data
+        c = pickle.loads(pickle.dumps(a))
+        assert list(c.data.columns) == [col]
+        a.data = pd.DataFrame({col: [1.0, 2.0]})
+        assert len(a.data) == 2 and len(b.data) == 0
+    assert BadByCn().data is None          # (as the reference: amof/bad.py:175-178)
