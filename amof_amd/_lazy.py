@@ -1,7 +1,7 @@
 """The `data` attribute of the analysis classes.
 
-The reference's constructors start every object with an empty DataFrame holding the first column (`amof/rdf.py:62-64`,
-`amof/msd.py:31-33,174-176`, `amof/bad.py:44-46`, `amof/cn.py:30-32`).  Building it costs ~0.1 ms of pandas per object --
+The reference's constructors start every object with an empty DataFrame holding the first column (`amof/rdf.py:33-35,144-146`,
+`amof/msd.py:64-66,152-154`, `amof/bad.py:66-68`, `amof/cn.py:30-32`).  Building it costs ~0.1 ms of pandas per object --
 4 % of one rank's 10 ms step in an 8-GPU run (profiles/r04/shards.txt) -- for a frame that `compute_*` replaces at once,
 so it is built when somebody looks at it before a result has been stored: same object for every reader afterwards.
 """

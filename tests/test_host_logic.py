@@ -293,8 +293,8 @@ def test_every_kernel_family_is_pinned_by_a_forced_path_test():
 
 
 def test_constructors_start_with_the_reference_s_empty_frame_built_on_first_look():
-    """The reference's constructors hold an empty DataFrame with the first column (amof/rdf.py:62-64, msd.py:31-33,174-176,
-    bad.py:44-46, cn.py:30-32); here it is built when first looked at (amof_amd/_lazy.py) -- same columns, one object per
+    """The reference's constructors hold an empty DataFrame with the first column (amof/rdf.py:33-35,144-146, msd.py:64-66,152-154,
+    bad.py:66-68, cn.py:30-32); here it is built when first looked at (amof_amd/_lazy.py) -- same columns, one object per
     instance, replaced by assignment, survives pickling"""
     import pickle
     from amof_amd.rdf import Rdf, CoordinationNumber as RdfCn
@@ -310,4 +310,4 @@ def test_constructors_start_with_the_reference_s_empty_frame_built_on_first_look
         assert list(c.data.columns) == [col]
         a.data = pd.DataFrame({col: [1.0, 2.0]})
         assert len(a.data) == 2 and len(b.data) == 0
-    assert BadByCn().data is None          # (as the reference: amof/bad.py:175-178)
+    assert BadByCn().data is None          # (the reference starts with an empty xarray.DataArray, amof/bad.py:183-187; xarray is not installed here)
