@@ -24,10 +24,10 @@ AMOF_ENOMEM = -4
 AMOF_EHIP = -5
 AMOF_ECAPACITY = -6
 AMOF_ENODEVICE = -7
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = [
-    "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_destroy", "amof_last_error",
+    "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_create2", "amof_ctx_destroy", "amof_last_error",
     "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_ctx_wait_stream", "amof_ctx_debug_poison", "amof_last_kernel_seconds", "amof_last_kernel_launches",
     "amof_last_path",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
@@ -62,6 +62,7 @@ class AmofTraj(ctypes.Structure):
 
 _lib = None
 _lib_lock = threading.Lock()
+_ctx_lock = threading.Lock()
 
 
 def load_library():
@@ -86,6 +87,7 @@ def load_library():
         lib.amof_abi_version.restype = ctypes.c_int
         lib.amof_device_count.restype = ctypes.c_int
         lib.amof_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(P)]
+        lib.amof_ctx_create2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(P)]
         lib.amof_ctx_destroy.argtypes = [P]
         lib.amof_ctx_destroy.restype = None
         lib.amof_last_error.argtypes = [P]
@@ -217,24 +219,90 @@ def _locked(method):
     return wrapper
 
 
-class Context(object):
-    """One ``amof_ctx``: a device, a stream and its scratch memory."""
+AMOF_CTX_HIGH_PRIORITY = 1
 
-    def __init__(self, device=0):
+_tls = threading.local()      # .producer_stream: the stream a lane job orders itself after (see Lane.submit)
+
+
+class Lane(object):
+    """One worker thread that runs jobs in submission order (the analysis classes enqueue their computation here and
+    return: amof_amd/_lazy.py).  Mixed into :class:`Context`; ``device`` is the GPU whose current torch stream a job is
+    ordered after (None: no GPU involved -- the CPU stand-ins of the test-suite)."""
+
+    device = None
+    _lane = None
+    _lane_thread = None
+    _last_job = None
+    _lane_name = "amof-lane"
+
+    def submit(self, fn):
+        """Run ``fn()`` on the worker thread, after everything submitted before; returns the
+        ``concurrent.futures.Future``.  The job orders the context's stream after the work queued so far on the
+        CALLER's current torch stream of this device (captured here: what produced a device-resident trajectory)."""
+        from concurrent.futures import ThreadPoolExecutor
+        if self._lane is None:
+            with _ctx_lock:
+                if self._lane is None:
+                    self._lane = ThreadPoolExecutor(1, thread_name_prefix=self._lane_name)
+        producer = None
+        if self.device is not None:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    producer = torch.cuda.current_stream(self.device).cuda_stream
+            except ImportError:
+                pass
+
+        def job():
+            self._lane_thread = threading.get_ident()
+            _tls.producer_stream = producer
+            try:
+                return fn()
+            finally:
+                _tls.producer_stream = None
+        fut = self._lane.submit(job)
+        self._last_job = fut
+        return fut
+
+    def drain(self):
+        """wait for every job submitted to the lane (their errors stay with their futures)"""
+        fut = self._last_job
+        if fut is None or threading.get_ident() == self._lane_thread:
+            return
+        fut.exception()         # (jobs run in submission order: the last one done = all done)
+
+    def close_lane(self):
+        self.drain()
+        if self._lane is not None:
+            self._lane.shutdown(wait=True)
+            self._lane = None
+
+
+class Context(Lane):
+    """One ``amof_ctx``: a device, a stream and its scratch memory -- and, for the analysis classes, a LANE: one worker
+    thread that runs the (synchronous) entry points of this context in submission order, so that a class constructor
+    can enqueue its analysis and return (``submit``; amof_amd/_lazy.py).  A device has two cached contexts
+    (``get_context``): lane 0 for the pair-evaluation-bound RDF, lane 1 -- a stream of the highest priority -- for the
+    memory-bound MSD / BAD / CN, whose kernels and host work then run beside an RDF launch instead of behind it."""
+
+    def __init__(self, device=0, high_priority=False):
         self._lib = load_library()
         n = self._lib.amof_device_count()
         if n <= 0:
             raise RuntimeError("amof_amd: no GPU visible to HIP; the MI355X kernels cannot run "
                                "(there is no CPU fallback)")
         h = ctypes.c_void_p()
-        rc = self._lib.amof_ctx_create(int(device), ctypes.byref(h))
+        rc = self._lib.amof_ctx_create2(int(device), AMOF_CTX_HIGH_PRIORITY if high_priority else 0, ctypes.byref(h))
         if rc != AMOF_OK:
-            raise AmofError(rc, "amof_ctx_create(device=%d) failed" % device)
+            raise AmofError(rc, "amof_ctx_create2(device=%d) failed" % device)
         self._h = h
         self.device = int(device)
+        self.high_priority = bool(high_priority)
+        self._lane_name = "amof-lane-%d%s" % (self.device, "h" if high_priority else "")
         self._lock = threading.RLock()
 
     def close(self):
+        self.close_lane()
         if getattr(self, "_h", None):
             self._lib.amof_ctx_destroy(self._h)
             self._h = None
@@ -263,25 +331,37 @@ class Context(object):
         import torch
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
-    @_locked
     def synchronize(self):
-        self._check(self._lib.amof_ctx_synchronize(self._h))
+        self.drain()
+        with self._lock:
+            self._check(self._lib.amof_ctx_synchronize(self._h))
 
-    @_locked
     def debug_poison(self, byte=0xA5):
         """Test hook: overwrite every scratch buffer the context owns (no call may rely on a previous call's scratch)."""
-        self._check(self._lib.amof_ctx_debug_poison(self._h, int(byte)))
+        self.drain()
+        with self._lock:
+            self._check(self._lib.amof_ctx_debug_poison(self._h, int(byte)))
 
     @_locked
     def wait_stream(self, stream_ptr):
         """Order this context's stream after the work queued so far on another HIP stream."""
         self._check(self._lib.amof_ctx_wait_stream(self._h, ctypes.c_void_p(stream_ptr or None)))
 
+    def _torch_stream(self):
+        """the torch stream whose queued work this call must run after: the current stream of the calling thread -- in a
+        lane job, the current stream of the thread that SUBMITTED the job (and the lane thread's own, on which the job
+        may have zeroed its output tensors)"""
+        import torch
+        own = torch.cuda.current_stream(self.device).cuda_stream
+        producer = getattr(_tls, "producer_stream", None)
+        if producer is not None and producer != own:
+            self.wait_stream(producer)
+        return own
+
     def _order_after_torch(self):
         """device outputs (``out=`` tensors) were zeroed / last written by torch: run after that.  The "_dev" entry
         points are synchronous like all others, so torch work queued afterwards needs no further ordering."""
-        import torch
-        self.wait_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.wait_stream(self._torch_stream())
 
     def _traj(self, packed, frame_range=None):
         """``_TrajHandle`` of a trajectory this context may read.  A device-resident ``pos`` must live on this
@@ -292,22 +372,33 @@ class Context(object):
             if th.device_index != self.device:
                 raise ValueError("trajectory positions live on cuda:%d but this context drives cuda:%d; use "
                                  "device=%d or copy the trajectory" % (th.device_index, self.device, th.device_index))
-            import torch
-            self.wait_stream(torch.cuda.current_stream(self.device).cuda_stream)
+            self.wait_stream(self._torch_stream())
         return th
 
-    @_locked
-    def last_kernel_seconds(self, dominant=True):
-        return self._lib.amof_last_kernel_seconds(self._h, 1 if dominant else 0)
+    def job_stats(self):
+        """the library's record of the call that just returned on this thread"""
+        with self._lock:
+            return {"kernel_s_all": self._lib.amof_last_kernel_seconds(self._h, 0),
+                    "kernel_s_dominant": self._lib.amof_last_kernel_seconds(self._h, 1),
+                    "kernel_launches": self._lib.amof_last_kernel_launches(self._h),
+                    "path": self._lib.amof_last_path(self._h).decode()}
 
-    @_locked
+    # (diagnostics describe the last COMPLETED call: they wait for the lane first)
+    def last_kernel_seconds(self, dominant=True):
+        self.drain()
+        with self._lock:
+            return self._lib.amof_last_kernel_seconds(self._h, 1 if dominant else 0)
+
     def last_path(self):
         """Kernel family that produced the last result ("rdf_tile", "rdf_cell", "cn_fast", "msd_comb", ...)."""
-        return self._lib.amof_last_path(self._h).decode()
+        self.drain()
+        with self._lock:
+            return self._lib.amof_last_path(self._h).decode()
 
-    @_locked
     def last_kernel_launches(self):
-        return self._lib.amof_last_kernel_launches(self._h)
+        self.drain()
+        with self._lock:
+            return self._lib.amof_last_kernel_launches(self._h)
 
     # ------------------------------------------------------------ analyses --
     @_locked
@@ -563,12 +654,12 @@ class MultiContext(object):
 
 
 _contexts = {}
-_ctx_lock = threading.Lock()
 
 
-def get_context(device=None):
+def get_context(device=None, lane=0):
     """Cached :class:`Context` of a device (default: LOCAL_RANK or 0); a list / tuple of devices gives
-    a cached :class:`MultiContext` (several GPUs driven from this process)."""
+    a cached :class:`MultiContext` (several GPUs driven from this process).  ``lane=1``: the device's second context,
+    on a stream of the highest priority (the memory-bound analyses of the classes run there)."""
     if isinstance(device, (list, tuple)):
         key = tuple(int(d) for d in device)
         with _ctx_lock:
@@ -583,9 +674,19 @@ def get_context(device=None):
         if n > 0 and device >= n:
             raise RuntimeError("LOCAL_RANK=%d but only %d GPU(s) are visible: refusing to pile every rank onto "
                                "cuda:0 (pass device= explicitly to share a GPU on purpose)" % (device, n))
+    key = device if not lane else (device, "lane", int(lane))
     with _ctx_lock:
-        ctx = _contexts.get(device)
+        ctx = _contexts.get(key)
         if ctx is None:
-            ctx = Context(device)
-            _contexts[device] = ctx
+            ctx = Context(device, high_priority=bool(lane))
+            _contexts[key] = ctx
         return ctx
+
+
+def lane_context(device, lane):
+    """the context an analysis class runs on: ``lane`` 1 (memory-bound analyses) only while the classes run
+    asynchronously (amof_amd/_lazy.py); a device list stays one MultiContext"""
+    from . import _lazy
+    if isinstance(device, (list, tuple)) or not lane or not _lazy.async_enabled():
+        return get_context(device)
+    return get_context(device, lane=lane)

@@ -18,7 +18,7 @@ import logging
 import numpy as np
 import pandas as pd
 
-from ._lazy import EmptyUntilComputed
+from ._lazy import Deferred, EmptyUntilComputed
 
 from . import _hip
 from . import atom as amatom
@@ -65,9 +65,12 @@ class CoreBad(object):
         return bad_class
 
 
-class Bad(CoreBad):
+class Bad(CoreBad, Deferred):
     """
     Main class for bad
+
+    ``from_trajectory`` enqueues the analysis on its device's second lane and returns; ``.data``, ``.hist``,
+    ``.n_angles`` wait for it (amof_amd/_lazy.py; ``AMOF_ASYNC=0``: synchronous).
     """
 
     data = EmptyUntilComputed("theta")      # (the reference's empty first-column frame, built on first look)
@@ -116,7 +119,20 @@ class Bad(CoreBad):
         F = len(packed)
         frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
         dev = device if device is not None else getattr(packed, "device_index", None)
-        ctx = _hip.get_context(dev)
+        ctx = _hip.lane_context(dev, 1)
+        db = np.array(np.diff(theta_bins), float)
+
+        def assemble(hist, nang):
+            self.hist = hist
+            self.n_angles = nang
+            self.columns = names
+            cols = {"theta": theta}
+            for k, aba_str in enumerate(names):
+                if nang[k] != 0:            # columns without any angle are omitted (amof/bad.py:159)
+                    n = hist[k].astype(np.int64)
+                    cols[aba_str] = n / db / n.sum()      # numpy.histogram(density=True)
+            self.data = pd.DataFrame(cols)
+
         if getattr(packed, "is_stream", False):
             if merge:
                 raise ValueError("a streamed trajectory is analysed by one process (distributed=False)")
@@ -125,34 +141,35 @@ class Bad(CoreBad):
                 if triples:
                     h, a = ctx.bad_hist(batch, rcm, triples, theta_bins)
                     hist, nang = hist + h, nang + a
-        elif triples and merge and _dist.device_collectives():
-            # counts stay in HBM from the kernels through ONE RCCL all-reduce (amof_bad_hist_dev)
-            import torch
-            T, nb = len(triples), bins + 1
-            both = torch.zeros(T * nb + T, dtype=torch.int64, device=torch.device("cuda", ctx.device))
-            ctx.bad_hist(packed, rcm, triples, theta_bins, frame_range=frame_range, out=(both[:T * nb], both[T * nb:]))
-            _dist.all_reduce_sum(both)
-            both = both.cpu().numpy().view(np.uint64)
-            hist, nang = both[:T * nb].reshape(T, nb), both[T * nb:]
-        else:
+            assemble(hist, nang)
+            return
+        on_device = bool(triples) and merge and _dist.device_collectives()
+        T, nb = len(triples), bins + 1
+
+        def local():
+            # this rank's kernels (a lane job: amof_amd/_lazy.py)
+            if on_device:
+                # counts stay in HBM from the kernels through ONE RCCL all-reduce (amof_bad_hist_dev)
+                import torch
+                both = torch.zeros(T * nb + T, dtype=torch.int64, device=torch.device("cuda", ctx.device))
+                ctx.bad_hist(packed, rcm, triples, theta_bins, frame_range=frame_range, out=(both[:T * nb], both[T * nb:]))
+                return both, None
             if triples:
-                hist, nang = ctx.bad_hist(packed, rcm, triples, theta_bins, frame_range=frame_range)
-            else:
-                hist, nang = np.zeros((0, bins + 1), dtype=np.uint64), np.zeros(0, dtype=np.uint64)
-            if merge:
+                return ctx.bad_hist(packed, rcm, triples, theta_bins, frame_range=frame_range)
+            return np.zeros((0, bins + 1), dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+
+        def finish(raw):
+            hist, nang = raw
+            if on_device:
+                _dist.all_reduce_sum(hist)
+                both = hist.cpu().numpy().view(np.uint64)
+                hist, nang = both[:T * nb].reshape(T, nb), both[T * nb:]
+            elif merge:
                 hist = _dist.all_reduce_sum(hist, device=ctx.device)
                 nang = _dist.all_reduce_sum(nang, device=ctx.device)
-        self.hist = hist
-        self.n_angles = nang
-        self.columns = names
+            assemble(hist, nang)
 
-        cols = {"theta": theta}
-        db = np.array(np.diff(theta_bins), float)
-        for k, aba_str in enumerate(names):
-            if nang[k] != 0:            # columns without any angle are omitted (amof/bad.py:159)
-                n = hist[k].astype(np.int64)
-                cols[aba_str] = n / db / n.sum()      # numpy.histogram(density=True)
-        self.data = pd.DataFrame(cols)
+        self._defer(ctx, local, finish, collective=merge)
 
     def write_to_file(self, filename):
         filename = _path.append_suffix(filename, 'bad')

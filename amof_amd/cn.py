@@ -11,7 +11,7 @@ import logging
 import numpy as np
 import pandas as pd
 
-from ._lazy import EmptyUntilComputed
+from ._lazy import Deferred, EmptyUntilComputed
 
 from . import _hip
 from . import atom as amatom
@@ -24,9 +24,12 @@ from .frames import pack_trajectory
 logger = logging.getLogger(__name__)
 
 
-class CoordinationNumber(object):
+class CoordinationNumber(Deferred):
     """
     Main class to compute CoordinationNumber
+
+    ``from_trajectory`` enqueues the analysis on its device's second lane and returns; ``.data`` waits for it
+    (amof_amd/_lazy.py; ``AMOF_ASYNC=0``: synchronous).
     """
 
     data = EmptyUntilComputed("Step")      # (the reference's empty first-column frame, built on first look)
@@ -74,33 +77,46 @@ class CoordinationNumber(object):
         F = len(packed)
         frame_range = _dist.shard_range(F, rank, world) if (merge and distributed != 'local') else (0, F)
         dev = device if device is not None else getattr(packed, "device_index", None)
-        ctx = _hip.get_context(dev)
+        ctx = _hip.lane_context(dev, 1)
+        counts = packed.species_counts()
+
+        def assemble(sums):
+            data = {'Step': np.asarray(step)[:len(sums)] if distributed == 'local' else step}
+            k = 0
+            for name, s, has_a in zip(names, sets, present):
+                a = _data.atomic_numbers[name.split('-')[0]]
+                n_a = counts.get(a, 0)
+                if s is not None:
+                    col = sums[:, k].astype(np.float64) / n_a   # np.mean of integer counts (amof/cn.py:73)
+                    k += 1
+                elif has_a:
+                    col = np.zeros(len(sums))                   # centres exist, partner species absent
+                else:
+                    col = np.full(len(sums), np.nan)            # np.mean([]) in the reference
+                data[name] = col
+            self.data = pd.DataFrame(data)
+
         if getattr(packed, "is_stream", False):
             if merge:
                 raise ValueError("a streamed trajectory is analysed by one process (distributed=False)")
             rows = [ctx.cn_count(batch, rcm, live) if live else np.zeros((len(batch), 0), dtype=np.int64)
                     for batch in packed.batches()]
-            sums = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(live)), dtype=np.int64)
-        else:
-            sums = ctx.cn_count(packed, rcm, live, frame_range=frame_range) if live else \
-                np.zeros((frame_range[1] - frame_range[0], 0), dtype=np.int64)
-        if merge and distributed != 'local':
-            sums = _dist.all_gather_rows(sums, device=ctx.device)
+            assemble(np.concatenate(rows, axis=0) if rows else np.zeros((0, len(live)), dtype=np.int64))
+            return
+        sharded = merge and distributed != 'local'
 
-        data = {'Step': np.asarray(step)[:len(sums)] if distributed == 'local' else step}
-        k = 0
-        for name, s, has_a in zip(names, sets, present):
-            a = _data.atomic_numbers[name.split('-')[0]]
-            n_a = packed.species_counts().get(a, 0)
-            if s is not None:
-                col = sums[:, k].astype(np.float64) / n_a   # np.mean of integer counts (amof/cn.py:73)
-                k += 1
-            elif has_a:
-                col = np.zeros(len(sums))                   # centres exist, partner species absent
-            else:
-                col = np.full(len(sums), np.nan)            # np.mean([]) in the reference
-            data[name] = col
-        self.data = pd.DataFrame(data)
+        def local():
+            # this rank's kernels (a lane job: amof_amd/_lazy.py)
+            if live:
+                return ctx.cn_count(packed, rcm, live, frame_range=frame_range)
+            return np.zeros((frame_range[1] - frame_range[0], 0), dtype=np.int64)
+
+        def finish(sums):
+            if sharded:
+                sums = _dist.all_gather_rows(sums, device=ctx.device)
+            assemble(sums)
+
+        self._defer(ctx, local, finish, collective=sharded)
 
     @classmethod
     def from_file(cls, filename):

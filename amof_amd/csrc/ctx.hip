@@ -336,7 +336,9 @@ int amof_device_count(void)
     return n;
 }
 
-int amof_ctx_create(int device, amof_ctx **out)
+int amof_ctx_create(int device, amof_ctx **out) { return amof_ctx_create2(device, 0, out); }
+
+int amof_ctx_create2(int device, int flags, amof_ctx **out)
 {
     if (!out) return AMOF_EINVAL;
     *out = nullptr;
@@ -347,7 +349,15 @@ int amof_ctx_create(int device, amof_ctx **out)
     amof_ctx *ctx = new (std::nothrow) amof_ctx();
     if (!ctx) return AMOF_ENOMEM;
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    hipError_t se;
+    if (flags & AMOF_CTX_HIGH_PRIORITY) {
+        int least = 0, greatest = 0;      // (numerically lowest = highest priority)
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+        se = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, greatest);
+    } else {
+        se = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    }
+    if (se != hipSuccess) {
         delete ctx;
         return AMOF_EHIP;
     }

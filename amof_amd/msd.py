@@ -16,7 +16,7 @@ import logging
 import numpy as np
 import pandas as pd
 
-from ._lazy import EmptyUntilComputed
+from ._lazy import Deferred, EmptyUntilComputed
 
 from . import _hip
 from . import data as _data
@@ -97,9 +97,12 @@ class DirectMsd(Msd):
             self.data[_data.chemical_symbols[int(x)]] = msd[:, 1 + kinds.index(int(x))]
 
 
-class WindowMsd(Msd):
+class WindowMsd(Msd, Deferred):
     """
     Window MSD
+
+    ``from_trajectory`` enqueues the analysis on its device's second lane (a high-priority stream beside an RDF
+    launch) and returns; ``.data`` and ``.sumsq`` wait for it (amof_amd/_lazy.py; ``AMOF_ASYNC=0``: synchronous).
 
     MSD(m) = 1/N_particles sum_i 1/(N-m) sum_k (r_i(k+m) - r_i(k))^2, with the
     reference's actual summation range k = 1 .. N-m-1 (amof/msd.py:195-204:
@@ -154,30 +157,51 @@ class WindowMsd(Msd):
         N, F = packed.n_atoms, len(packed)
         atom_range = _dist.shard_range(N, rank, world) if merge and distributed != 'local' else (0, N)
         dev = device if device is not None else getattr(packed, "device_index", None)
-        ctx = _hip.get_context(dev)
+        ctx = _hip.lane_context(dev, 1)
         sharded = merge and distributed != 'local'
-        if sharded and _dist.device_collectives():
+        on_device = sharded and _dist.device_collectives()
+        com = None
+        if on_device and unwrap != True and packed.on_device:  # noqa: E712  (the unwrapped centre of mass is another quantity)
             # atoms are sharded (reference: one joblib worker per element, amof/msd.py:252-256); what every rank would
             # otherwise repeat -- the centre of mass of EVERY frame from all atoms -- is frame-sharded: each rank fills
             # its rows of a zeroed [F][3] table, one all-reduce (120 kB at 5000 frames; x + 0 = x, exact) completes it.
-            # The S x W sums stay in HBM from the kernels through their all-reduce.
+            # (Here, in the calling thread: collectives are issued in program order, never from a lane.)
             import torch
-            dev = torch.device("cuda", ctx.device)
-            com = None
-            if unwrap != True and packed.on_device:  # noqa: E712  (the unwrapped centre of mass is another quantity)
-                com = torch.zeros((F, 3), dtype=torch.float64, device=dev)
-                ctx.msd_com(packed, _dist.shard_range(F, rank, world), com)
-                _dist.all_reduce_sum(com)
-            out = torch.zeros((len(_hip.packed_species(packed)[0]), len(window)), dtype=torch.float64, device=dev)
-            _, kinds = ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
+            com = torch.zeros((F, 3), dtype=torch.float64, device=torch.device("cuda", ctx.device))
+            ctx.msd_com(packed, _dist.shard_range(F, rank, world), com)
+            _dist.all_reduce_sum(com)
+
+        def local():
+            # this rank's kernels (a lane job: amof_amd/_lazy.py)
+            if on_device:
+                # the S x W sums stay in HBM from the kernels through their all-reduce
+                import torch
+                out = torch.zeros((len(_hip.packed_species(packed)[0]), len(window)), dtype=torch.float64,
+                                  device=torch.device("cuda", ctx.device))
+                return ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
                                       atom_range=atom_range, com=com, out=out)
-            _dist.all_reduce_sum(out)
-            sumsq = out.cpu().numpy()
-        else:
-            sumsq, kinds = ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
-                                          atom_range=atom_range)
-            if sharded:
+            return ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
+                                  atom_range=atom_range)
+
+        def finish(raw):
+            sumsq, kinds = raw
+            if on_device:
+                _dist.all_reduce_sum(sumsq)
+                sumsq = sumsq.cpu().numpy()
+            elif sharded:
                 sumsq = _dist.all_reduce_sum(sumsq, device=ctx.device)
+            self._assemble(formula_dict, packed, sumsq, kinds, window, time, elements)
+
+        # formula of the first frame (amof/msd.py:263), read here: the caller's frames are not touched from a lane
+        if isinstance(trajectory, PackedTrajectory) or getattr(trajectory, "is_stream", False):
+            formula_dict = packed.formula_count()
+        else:
+            formula_dict = dict(trajectory[0].symbols.formula._count)
+        self._defer(ctx, local, finish, collective=sharded)
+
+    def _assemble(self, formula_dict, packed, sumsq, kinds, window, time, elements):
+        """normalisation quirk and the formula-weighted total (amof/msd.py:195-204,259-268) from the raw sums"""
+        F = len(packed)
         self.sumsq = sumsq
         idx = {z: k for k, z in enumerate(kinds)}
 
@@ -187,10 +211,6 @@ class WindowMsd(Msd):
         for e in elements:
             cols[_data.chemical_symbols[int(e)]] = sumsq[idx[int(e)]] / counts[int(e)] / denom
         # formula-weighted total (amof/msd.py:263-268)
-        if isinstance(trajectory, PackedTrajectory) or getattr(trajectory, "is_stream", False):
-            formula_dict = packed.formula_count()
-        else:
-            formula_dict = trajectory[0].symbols.formula._count
         acc = 0.0
         for k, v in formula_dict.items():
             acc = acc + cols[k] * v

@@ -14,7 +14,7 @@ import os
 import numpy as np
 import pandas as pd
 
-from ._lazy import EmptyUntilComputed
+from ._lazy import Deferred, EmptyUntilComputed
 
 from . import _hip
 from . import data as _data
@@ -60,9 +60,12 @@ def normalize_rdf_shell(hist, ncount, natoms, mean_volume, rmax, nbins, shell):
     return np.asarray(hist, dtype=np.float64) * (mean_volume / (natoms * ncount)) / vol
 
 
-class Rdf(object):
+class Rdf(Deferred):
     """
     Main class for rdf
+
+    ``from_trajectory`` enqueues the analysis on its device's first lane and returns; ``.data`` (and ``.hist``,
+    ``.rmax``, ...) wait for it (amof_amd/_lazy.py; ``AMOF_ASYNC=0``: synchronous).
     """
 
     data = EmptyUntilComputed("r")      # (the reference's empty first-column frame, built on first look)
@@ -110,7 +113,7 @@ class Rdf(object):
         rank, world = (0, 1) if distributed is False else _dist.world()
         merge = distributed is not False and _dist.merging(world)
         dev = device if device is not None else getattr(packed, "device_index", None)
-        ctx = _hip.get_context(dev)
+        ctx = _hip.lane_context(dev, 0)
 
         # min over ALL frames of the three cell lengths, halved (amof/rdf.py:74)
         rmax_half_cell = np.min(packed.cell_lengths()) / 2
@@ -149,40 +152,53 @@ class Rdf(object):
             frame_range = _dist.shard_range(F_local, rank, world)
         else:
             frame_range = (0, F_local)
-        n_frames = frame_range[1] - frame_range[0]
         sharded = merge and distributed != 'local'
-        if merge and _dist.device_collectives():
-            # the histogram stays in HBM from the kernels through the RCCL all-reduce (amof_rdf_accumulate_dev).  A
-            # frame-sharded run needs ONE collective: every rank holds every cell, so the volume sum of the whole
-            # trajectory is computed locally (PackedTrajectory.volume_sum, the library's own operation order) and the
-            # frame count is known.  Own-block ranks ('local') carry their frame count in a spare word of the same
-            # tensor and all-reduce the float volume sums separately.
-            import torch
-            S = len(_hip.packed_species(packed)[0])
-            buf = torch.zeros(S * S * bins + 1, dtype=torch.int64, device=torch.device("cuda", ctx.device))
-            out = buf[:S * S * bins].view(S, S, bins)
-            _, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range, out=out)
-            if sharded:
-                _dist.all_reduce_sum(out)
-                vol_sum, n_frames = packed.volume_sum(), F_local
-            else:
-                buf[-1] = n_frames
-                _dist.all_reduce_sum(buf)
-                vol_sum = float(_dist.all_reduce_sum(np.array([vol_sum]), device=ctx.device)[0])
-            host = buf.cpu().numpy()
-            hist = host[:S * S * bins].reshape(S, S, bins).view(np.uint64)
-            if not sharded:
-                n_frames = int(host[-1])
-        else:
-            hist, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range)
-            if sharded:
+        on_device = merge and _dist.device_collectives()
+
+        def local():
+            # this rank's kernels (a lane job: amof_amd/_lazy.py)
+            if on_device:
+                # the histogram stays in HBM from the kernels through the RCCL all-reduce (amof_rdf_accumulate_dev)
+                import torch
+                S = len(_hip.packed_species(packed)[0])
+                buf = torch.zeros(S * S * bins + 1, dtype=torch.int64, device=torch.device("cuda", ctx.device))
+                out = buf[:S * S * bins].view(S, S, bins)
+                _, vol_sum, kinds = ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range, out=out)
+                return buf, vol_sum, kinds
+            return ctx.rdf_accumulate(packed, rmax, bins, frame_range=frame_range)
+
+        def finish(raw):
+            # the ranks' merge (the calling thread: collectives in program order) and the DataFrame
+            hist, vol_sum, kinds = raw
+            n_frames = frame_range[1] - frame_range[0]
+            if on_device:
+                # A frame-sharded run needs ONE collective: every rank holds every cell, so the volume sum of the whole
+                # trajectory is computed locally (PackedTrajectory.volume_sum, the library's own operation order) and the
+                # frame count is known.  Own-block ranks ('local') carry their frame count in a spare word of the same
+                # tensor and all-reduce the float volume sums separately.
+                buf = hist
+                S = len(kinds)
+                if sharded:
+                    _dist.all_reduce_sum(buf[:S * S * bins])
+                    vol_sum, n_frames = packed.volume_sum(), F_local
+                else:
+                    buf[-1] = n_frames
+                    _dist.all_reduce_sum(buf)
+                    vol_sum = float(_dist.all_reduce_sum(np.array([vol_sum]), device=ctx.device)[0])
+                host = buf.cpu().numpy()
+                hist = host[:S * S * bins].reshape(S, S, bins).view(np.uint64)
+                if not sharded:
+                    n_frames = int(host[-1])
+            elif sharded:
                 hist = _dist.all_reduce_sum(hist, device=ctx.device)
                 vol_sum, n_frames = packed.volume_sum(), F_local
             elif merge:
                 hist = _dist.all_reduce_sum(hist, device=ctx.device)
                 tot = _dist.all_reduce_sum(np.array([vol_sum, float(n_frames)]), device=ctx.device)
                 vol_sum, n_frames = float(tot[0]), int(round(tot[1]))
-        self._finish(packed, hist, vol_sum, n_frames, kinds, atomic_numbers_unique, rmax, bins, r)
+            self._finish(packed, hist, vol_sum, n_frames, kinds, atomic_numbers_unique, rmax, bins, r)
+
+        self._defer(ctx, local, finish, collective=merge)
 
     def _finish(self, packed, hist, vol_sum, n_frames, kinds, atomic_numbers_unique, rmax, bins, r):
         """normalisation and column assembly (amof/rdf.py:96-114) from the integer counts"""

@@ -124,8 +124,9 @@ def cpu_baseline(packed, rmax, nbins, window, rdf_frames):
     return {
         "value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
         "all_cores": {"value": F / (t_rdf_par * F + t_msd), "unit": "frames/s", "cores": cores, "cores_usable": cores_usable,
-                      "sample": "RDF: %d frames on %d threads, %.4f s/frame aggregate; MSD as above (single thread)"
-                                % (per * cores, cores, t_rdf_par)},
+                      "sample": "RDF: %d frames on %d threads, %.4f s/frame aggregate; MSD as above (single thread); "
+                                "%d threads = what this process may use (affinity and cgroup CPU quota) of the host's %d CPUs"
+                                % (per * cores, cores, t_rdf_par, cores_usable, os.cpu_count() or 0)},
         "cpu_model": cpu_model,
         "sample": "RDF: C oracle (cell list) on %d of %d frames, %.3f s/frame; MSD: numpy restatement of the "
                   "reference loops on all %d frames for 1/8 of the atoms (%.1f s), scaled x%.1f to all atoms"
@@ -218,13 +219,13 @@ def supplementary(device, local_rank, ctx, do_verify=True):
     torch.cuda.synchronize()
     for rep in range(2):
         t0 = time.perf_counter()
-        r1 = Rdf.from_trajectory(p1, dr=0.01, rmax=10.0, device=local_rank, distributed=False)
+        r1 = Rdf.from_trajectory(p1, dr=0.01, rmax=10.0, device=local_rank, distributed=False).result()
         t_r = time.perf_counter() - t0
-        k_r, path_r = ctx.last_kernel_seconds(dominant=False), ctx.last_path()
+        k_r, path_r = r1._stats["kernel_s_all"], r1._stats["path"]
         t0 = time.perf_counter()
-        c1 = CoordinationNumber.from_trajectory(p1, {'Zn-N': 2.5}, device=local_rank, distributed=False)
+        c1 = CoordinationNumber.from_trajectory(p1, {'Zn-N': 2.5}, device=local_rank, distributed=False).result()
         t_c = time.perf_counter() - t0
-        k_c, path_c = ctx.last_kernel_seconds(dominant=False), ctx.last_path()
+        k_c, path_c = c1._stats["kernel_s_all"], c1._stats["path"]
     alg1 = p1.n_frames * (24 * p1.n_atoms + 72)
     pairs1 = float(np.asarray(r1.hist).sum()) / 2.0
     out["configs1"] = {
@@ -284,9 +285,9 @@ def supplementary(device, local_rank, ctx, do_verify=True):
     torch.cuda.synchronize()
     for rep in range(2):
         t0 = time.perf_counter()
-        r4 = Rdf.from_trajectory(p4, dr=0.01, rmax=10.0, device=local_rank, distributed=False)
+        r4 = Rdf.from_trajectory(p4, dr=0.01, rmax=10.0, device=local_rank, distributed=False).result()
         t4 = time.perf_counter() - t0
-        k4_dom, k4_all, path4 = ctx.last_kernel_seconds(True), ctx.last_kernel_seconds(False), ctx.last_path()
+        k4_dom, k4_all, path4 = r4._stats["kernel_s_dominant"], r4._stats["kernel_s_all"], r4._stats["path"]
     alg4 = F4 * (24 * p4.n_atoms + 72)
     out["configs4"] = {
         "workload": "configs[4]: %d-atom sheared (triclinic) ZIF-4 7x7x8, %d frames, Rdf(dr=0.01, rmax=10 -> %d bins)"
@@ -296,7 +297,7 @@ def supplementary(device, local_rank, ctx, do_verify=True):
         "roofline": {"kernel": path4, "bound": "hbm", "achieved": alg4 / k4_dom / 1e9, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": alg4 / k4_dom / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg4,
                      "incl_cell_sort_frac": alg4 / k4_all / 1e9 / HBM_PEAK_GBPS},
-        "kernel_launches": int(ctx.last_kernel_launches()),
+        "kernel_launches": int(r4._stats["kernel_launches"]),
     }
     if do_verify:
         try:
@@ -339,10 +340,10 @@ def supplementary(device, local_rank, ctx, do_verify=True):
                 t0 = time.perf_counter()
                 whole = T.read_lammps_traj(path, ":", cell=cell)
                 t_parse = time.perf_counter() - t0
-                r_a = Rdf.from_trajectory(whole, device=local_rank, distributed=False)
+                r_a = Rdf.from_trajectory(whole, device=local_rank, distributed=False).result()
                 t_serial = time.perf_counter() - t0
                 t0 = time.perf_counter()
-                r_b = Rdf.from_trajectory(XyzStream(path, cell=cell, batch_frames=50), device=local_rank, distributed=False)
+                r_b = Rdf.from_trajectory(XyzStream(path, cell=cell, batch_frames=50), device=local_rank, distributed=False).result()
                 t_stream = time.perf_counter() - t0
             same = bool(np.array_equal(np.asarray(r_a.hist), np.asarray(r_b.hist)) and r_a.data.equals(r_b.data))
             ok_t = None
@@ -397,14 +398,14 @@ def realistic_cells(device, local_rank, ctx, head, do_verify=True, frames=400):
         torch.cuda.synchronize()
         best = None
         for rep in range(3):
-            r = Rdf.from_trajectory(ref, device=local_rank, distributed=False)
-            k = ctx.last_kernel_seconds(dominant=True)
+            r = Rdf.from_trajectory(ref, device=local_rank, distributed=False).result()
+            k = r._stats["kernel_s_dominant"]
             best = k if best is None or k < best else best
         lz = float(np.max(ref.cell_lengths()))
         vis = min(1.0, 2.0 * r.rmax / lz + 3.0 / 256.0) if 2.0 * r.rmax * 1.05 < lz else 1.0
         same_cost = best / (frames * ref.n_atoms * (ref.n_atoms - 1) / 2.0 * vis)
         out["diagonal_reference"] = {"workload": "the headline system (diagonal cell) over the legs' %d frames" % frames,
-                                     "path": ctx.last_path(), "kernel_ms_per_frame": 1e3 * best / frames,
+                                     "path": r._stats["path"], "kernel_ms_per_frame": 1e3 * best / frames,
                                      "visited_fraction_geometric": vis}
         del ref, r
     except Exception as exc:
@@ -427,14 +428,20 @@ def realistic_cells(device, local_rank, ctx, head, do_verify=True, frames=400):
         try:
             tr = H.device_walk_cell(device, frame0, cells, frames, 0.05, seed)
             torch.cuda.synchronize()
-            best, path = None, None
-            for rep in range(3):
+            # one COLD call (first use of this cell's kernel variant in the process: code-object load, scratch growth), then
+            # three warm ones; kernel and wall time are the minima over the WARM calls, each taken on its own
+            reps = []
+            for rep in range(4):
+                torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                r = Rdf.from_trajectory(tr, device=local_rank, distributed=False)
-                wall = time.perf_counter() - t0
-                k = ctx.last_kernel_seconds(dominant=True)
-                if best is None or k < best:
-                    best, k_all, path, wall_best = k, ctx.last_kernel_seconds(dominant=False), ctx.last_path(), wall
+                r = Rdf.from_trajectory(tr, device=local_rank, distributed=False).result()
+                reps.append((time.perf_counter() - t0, r._stats["kernel_s_dominant"], r._stats["kernel_s_all"], r._stats["path"]))
+            first_call = reps[0][0]
+            warm = reps[1:]
+            wall_best = min(w for w, _, _, _ in warm)
+            best = min(k for _, k, _, _ in warm)
+            span = min(a for _, _, a, _ in warm)
+            path = warm[-1][3]
             N = tr.n_atoms
             lengths = tr.cell_lengths()
             rmax = r.rmax
@@ -444,7 +451,8 @@ def realistic_cells(device, local_rank, ctx, head, do_verify=True, frames=400):
             leg = {"workload": "%s; %d atoms x %d frames, Rdf(dr=0.01, rmax=half shortest length = %.4f A -> %d bins)"
                                % (what, N, frames, rmax, len(r.data)),
                    "path": path, "kernel_ms_per_frame": 1e3 * best / frames, "wall_ms_per_frame": 1e3 * wall_best / frames,
-                   "frames_per_s": frames / wall_best, "kernel_s_all": k_all,
+                   "frames_per_s": frames / wall_best, "first_call_s": first_call, "warm_call_s": wall_best,
+                   "stream_span_s": span,        # first to last kernel of the call on its stream (quantize + tile kernel + gaps)
                    "pair_evals_per_s": pairs / best, "visited_fraction_geometric": visited,
                    "vs_headline_per_pair": (best / pairs) / (head_cost * vis_head),
                    "vs_headline_per_visited_pair": (best / (pairs * visited)) / head_cost,
@@ -550,24 +558,30 @@ def main():
     mode = False if (world == 1 and not forced) else (None if strong else 'local')
 
     def step(with_bad, rec):
+        # the constructors enqueue (amof_amd/_lazy.py: RDF on the device's first lane, the memory-bound analyses on the
+        # second, a high-priority stream) and return; looking at `.data` waits -- EVERY result is looked at inside the
+        # timed region, so nothing is left running when the clock stops
         t0 = time.perf_counter()
         rdf = Rdf.from_trajectory(packed, device=local_rank, distributed=mode)
-        t1 = time.perf_counter()
-        rec["rdf_dom"].append(ctx.last_kernel_seconds(dominant=True))
-        rec["rdf_all"].append(ctx.last_kernel_seconds(dominant=False))
-        t2 = time.perf_counter()
         msd = WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=local_rank, distributed=mode)
+        bad = Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=local_rank, distributed=mode) if with_bad else None
+        t1 = time.perf_counter()
+        n_rdf = len(rdf.data)
+        t2 = time.perf_counter()
+        n_msd = len(msd.data)
         t3 = time.perf_counter()
-        rec["msd_dom"].append(ctx.last_kernel_seconds(dominant=True))
-        rec["msd_all"].append(ctx.last_kernel_seconds(dominant=False))
-        rec["rdf_wall"].append(t1 - t0)
-        rec["msd_wall"].append(t3 - t2)
-        bad = None
         if with_bad:
-            t4 = time.perf_counter()
-            bad = Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=local_rank, distributed=mode)
-            rec["bad_wall"].append(time.perf_counter() - t4)
-            rec["bad_all"].append(ctx.last_kernel_seconds(dominant=False))
+            n_bad = len(bad.data)
+            rec["bad_wall"].append(time.perf_counter() - t3)      # what BAD adds after RDF and MSD are there
+            rec["bad_all"].append(bad._stats["kernel_s_all"])
+        assert n_rdf > 0 and n_msd > 0
+        rec["submit_wall"].append(t1 - t0)
+        rec["rdf_wall"].append(t2 - t0)                            # constructor call -> RDF DataFrame in hand
+        rec["msd_wall"].append(t3 - t2)                            # what MSD adds after that (0 when it ran beside the RDF launch)
+        rec["rdf_dom"].append(rdf._stats["kernel_s_dominant"])
+        rec["rdf_all"].append(rdf._stats["kernel_s_all"])
+        rec["msd_dom"].append(msd._stats["kernel_s_dominant"])
+        rec["msd_all"].append(msd._stats["kernel_s_all"])
         return rdf, msd, bad
 
     def fence():
@@ -577,7 +591,7 @@ def main():
         torch.cuda.synchronize()
 
     def timed(with_bad):
-        keys = ("rdf_dom", "rdf_all", "msd_dom", "msd_all", "rdf_wall", "msd_wall", "bad_wall", "bad_all")
+        keys = ("rdf_dom", "rdf_all", "msd_dom", "msd_all", "rdf_wall", "msd_wall", "bad_wall", "bad_all", "submit_wall")
         rec = {k: [] for k in keys}
         for _ in range(args.warmup):
             step(with_bad, rec)
@@ -601,6 +615,23 @@ def main():
         (rdf3, msd3, bad3), elapsed3, mean3 = timed(True)
         cfg3 = (bad3, elapsed3, mean3)
         assert "N-Zn-N" in bad3.data.columns
+
+    # the MSD pipeline ALONE (nothing else on the GPU): what roofline_msd prices.  Inside the steps above its kernels
+    # share the chip with the RDF launch, and their in-step durations say how well the two overlap, not how fast they are.
+    seq = {"all": [], "dom": [], "wall": []}
+    fence()
+    for rep in range(args.warmup + args.steps):
+        t0 = time.perf_counter()
+        m = WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=local_rank, distributed=mode)
+        m.result()
+        if rep >= args.warmup:
+            seq["wall"].append(time.perf_counter() - t0)
+            seq["all"].append(m._stats["kernel_s_all"])
+            seq["dom"].append(m._stats["kernel_s_dominant"])
+    msd_path = m._stats["path"]
+    seq = {k: float(np.mean(v)) for k, v in seq.items()}
+    del m
+    fence()
 
     per_rank = {"rank": rank, "device": local_rank, "rdf_frames": list(_rdf_range(F, rank, world, strong)),
                 "kernel_s": {k: mean[k] for k in ("rdf_dom", "rdf_all", "msd_all")},
@@ -706,14 +737,22 @@ def main():
             "roofline_msd": {"kernel": "msd pipeline, 2-pass form (delta_transpose with the tile sums of m p | com_finish | msd_stream | reduce)"
                                        if world == 1 else "msd pipeline (com share + all-reduce | delta_transpose | msd_stream | reduce)",
                              "bound": "hbm",
-                             "achieved": msd_bytes / mean["msd_all"] / 1e9, "peak": HBM_PEAK_GBPS,
-                             "unit": "GB/s", "frac": msd_bytes / mean["msd_all"] / 1e9 / HBM_PEAK_GBPS,
-                             "traffic": traffic.get("msd_pipeline"), "pipeline_seconds": mean["msd_all"],
-                             "msd_window_kernel_seconds": mean["msd_dom"], "algorithmic_bytes": msd_bytes},
+                             "achieved": msd_bytes / seq["all"] / 1e9, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": msd_bytes / seq["all"] / 1e9 / HBM_PEAK_GBPS,
+                             "traffic": traffic.get("msd_pipeline"), "pipeline_seconds": seq["all"],
+                             "msd_window_kernel_seconds": seq["dom"], "call_wall_seconds": seq["wall"], "path": msd_path,
+                             "algorithmic_bytes": msd_bytes,
+                             "measured": "the MSD class alone, %d calls back to back after the timed steps (in the steps its "
+                                         "kernels run BESIDE the RDF launch on the second lane: in_step_seconds)" % args.steps,
+                             "in_step_seconds": mean["msd_all"]},
             "kernel_seconds_per_step": {"rdf_tile": t_rdf, "rdf_all_incl_quantize": mean["rdf_all"],
                                         "msd_all": mean["msd_all"]},
-            "host_seconds_per_step": {"rdf_wall_minus_kernels": mean["rdf_wall"] - mean["rdf_all"],
-                                      "msd_wall_minus_kernels": mean["msd_wall"] - mean["msd_all"]},
+            "wall_seconds_per_step": {"constructors_return_after": mean["submit_wall"], "rdf_data_after": mean["rdf_wall"],
+                                      "msd_data_adds": mean["msd_wall"],
+                                      "note": "asynchronous constructors (amof_amd/_lazy.py): every .data is read inside the "
+                                              "timed region; msd_data_adds = wait for the MSD result once the RDF result is there"},
+            "host_seconds_per_step": {"rdf_wall_minus_kernels": mean["rdf_wall"] - mean["rdf_all"]},
+            "async": os.environ.get("AMOF_ASYNC", "1") != "0",
             "per_rank": ranks,
         }
         if cfg3:
@@ -753,8 +792,9 @@ def main():
             host = PackedTrajectory(packed.pos.cpu().numpy(), packed.cell, packed.numbers)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            Rdf.from_trajectory(host, device=local_rank, distributed=False)
-            WindowMsd.from_trajectory(host, delta_time=100, timestep=1, device=local_rank, distributed=False)
+            a_ = Rdf.from_trajectory(host, device=local_rank, distributed=False)
+            b_ = WindowMsd.from_trajectory(host, delta_time=100, timestep=1, device=local_rank, distributed=False)
+            a_.result(), b_.result()
             torch.cuda.synchronize()
             out["host_resident_frames_per_s"] = F / (time.perf_counter() - t0)
             # supplementary: packing a list of ase.Atoms-like frames into the arrays above (pure Python + memcpy,
@@ -775,14 +815,14 @@ def main():
                 for rep in range(args.warmup + 3):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    cnh = CoordinationNumber.from_trajectory(packed, {'Zn-N': 2.5}, device=local_rank, distributed=False)
+                    cnh = CoordinationNumber.from_trajectory(packed, {'Zn-N': 2.5}, device=local_rank, distributed=False).result()
                     w = time.perf_counter() - t0
-                    k = ctx.last_kernel_seconds(dominant=False)
+                    k = cnh._stats["kernel_s_all"]
                     if best_k is None or k < best_k:
                         best_k, best_w = k, w
                 out["cn_headline"] = {
                     "workload": "CoordinationNumber({'Zn-N': 2.5}) on the headline trajectory (%d atoms x %d frames)" % (N, F),
-                    "path": ctx.last_path(), "frames_per_s": F / best_w, "wall_s": best_w, "kernel_s": best_k,
+                    "path": cnh._stats["path"], "frames_per_s": F / best_w, "wall_s": best_w, "kernel_s": best_k,
                     "roofline_cn": {"kernel": "cn_frame_kernel (whole frame of the species pair in LDS)", "bound": "hbm",
                                     "achieved": F * (24 * N + 72) / best_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": F * (24 * N + 72) / best_k / 1e9 / HBM_PEAK_GBPS,

@@ -40,7 +40,7 @@ extern "C" {
 #define AMOF_ECAPACITY (-6)  /* a documented kernel capacity was exceeded */
 #define AMOF_ENODEVICE (-7)  /* no usable GPU */
 
-#define AMOF_ABI_VERSION 3
+#define AMOF_ABI_VERSION 4
 
 /* capacities */
 #define AMOF_MAX_LDS_BINS 36864     /* histogram bins held in LDS per workgroup (u32); more bins: global-memory kernels */
@@ -75,6 +75,13 @@ int amof_abi_version(void);
 int amof_device_count(void);
 
 int amof_ctx_create(int device, amof_ctx **out);
+/* The same with flags.  AMOF_CTX_HIGH_PRIORITY: the context's stream is created at the device's highest stream
+ * priority -- the second context of a device, on which the memory-bound analyses (MSD, BAD, CN) run beside the
+ * pair-evaluation-bound RDF launch of the first (the reference runs its analyses as independent calls,
+ * examples/Compute structural properties.py:58-118, and parallelises inside them with joblib, amof/msd.py:252-256);
+ * their workgroups are dispatched ahead of the RDF kernel's whenever a CU has room. */
+#define AMOF_CTX_HIGH_PRIORITY 1
+int amof_ctx_create2(int device, int flags, amof_ctx **out);
 void amof_ctx_destroy(amof_ctx *ctx);
 const char *amof_last_error(const amof_ctx *ctx);
 

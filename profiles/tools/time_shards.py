@@ -73,18 +73,40 @@ from amof_amd.bad import Bad                                # noqa: E402
 torch.cuda.set_device(0)
 tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 real_world = adist.world
-print("classes as rank 0 of N (one-rank RCCL group): wall ms per call, best of 5")
-print("N_gpus  Rdf_wall  Msd_wall  Bad_wall | rdf+msd   speedup_vs_1 | rdf+msd+bad  speedup_vs_1")
+def best_wall(fn, reps=5):
+    fn()
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def step(with_bad):
+    # what bench.py times: the constructors enqueue (RDF on the first lane, MSD / BAD on the second, a high-priority
+    # stream), every result is looked at before the clock stops
+    a = Rdf.from_trajectory(packed, device=0, distributed=None)
+    b = WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=0, distributed=None)
+    c = Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=0, distributed=None) if with_bad else None
+    n = len(a.data) + len(b.data) + (len(c.data) if with_bad else 0)
+    return n
+
+
+print("classes as rank 0 of N (one-rank RCCL group): wall ms, best of 5.  'each' = the class alone (constructor + .data);")
+print("'step' = the constructors back to back, then every .data (AMOF_ASYNC=%s)" % os.environ.get("AMOF_ASYNC", "1"))
+print("N_gpus  Rdf_each  Msd_each  Bad_each | step rdf+msd  speedup_vs_1 | step rdf+msd+bad  speedup_vs_1")
 base2 = base3 = None
 for n in (1, 2, 4, 8):
     adist.world = (lambda group=None, n=n: (0, n)) if n > 1 else real_world
-    r = timed(lambda: Rdf.from_trajectory(packed, device=0, distributed=None), reps=5)
-    m = timed(lambda: WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=0, distributed=None), reps=5)
-    b = timed(lambda: Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=0, distributed=None), reps=5)
-    t2, t3 = r[0] + m[0], r[0] + m[0] + b[0]
+    r = best_wall(lambda: Rdf.from_trajectory(packed, device=0, distributed=None).result())
+    m = best_wall(lambda: WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=0, distributed=None).result())
+    b = best_wall(lambda: Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=0, distributed=None).result())
+    t2, t3 = best_wall(lambda: step(False)), best_wall(lambda: step(True))
     base2, base3 = base2 or t2, base3 or t3
-    print("%6d  %8.3f  %8.3f  %8.3f | %8.3f   %.2fx        | %8.3f     %.2fx" %
-          (n, 1e3 * r[0], 1e3 * m[0], 1e3 * b[0], 1e3 * t2, base2 / t2, 1e3 * t3, base3 / t3))
+    print("%6d  %8.3f  %8.3f  %8.3f | %12.3f   %.2fx        | %16.3f     %.2fx" %
+          (n, 1e3 * r, 1e3 * m, 1e3 * b, 1e3 * t2, base2 / t2, 1e3 * t3, base3 / t3))
 adist.world = real_world
 tdist.destroy_process_group()
 os.environ.pop("AMOF_DIST_FORCE_MERGE")
@@ -97,5 +119,10 @@ for name, fn in (("Rdf", lambda: Rdf.from_trajectory(packed, device=0, distribut
                  ("Bad", lambda: Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=0, distributed=False)),
                  ("WindowMsd", lambda: WindowMsd.from_trajectory(packed, delta_time=100, timestep=1, device=0,
                                                                  distributed=False))):
-    w, k = timed(fn)
+    best = (1e9, 0.0)
+    for _ in range(4):
+        t0 = time.perf_counter()
+        o = fn().result()
+        best = min(best, (time.perf_counter() - t0, o._stats["kernel_s_all"]))
+    w, k = best
     print("class %-10s wall %.3f ms, kernels %.3f ms, host %.3f ms" % (name, 1e3 * w, 1e3 * k, 1e3 * (w - k)))

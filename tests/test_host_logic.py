@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.amof_abi_version() == 3
+    assert lib.amof_abi_version() == _hip.ABI_VERSION == 4
 
 
 def test_struct_layout_matches_header():
