@@ -24,6 +24,7 @@ AMOF_ENOMEM = -4
 AMOF_EHIP = -5
 AMOF_ECAPACITY = -6
 AMOF_ENODEVICE = -7
+AMOF_EUNSUPPORTED = -8
 ABI_VERSION = 4
 
 EXPORTS = [
@@ -32,7 +33,7 @@ EXPORTS = [
     "amof_last_path",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_bad_hist_by_cn",
-    "amof_msd_window", "amof_msd_window_dev", "amof_msd_com_dev", "amof_msd_direct",
+    "amof_msd_window", "amof_msd_window_dev", "amof_msd_com_dev", "amof_msd_shard_begin", "amof_msd_shard_finish", "amof_msd_direct",
     "amof_xyz_scan", "amof_xyz_read", "amof_xyz_open", "amof_xyz_read_frames", "amof_xyz_close", "amof_cp2k_cell_read", "amof_ingest_last_error",
 ]
 
@@ -41,6 +42,10 @@ class AmofError(RuntimeError):
     def __init__(self, code, message):
         RuntimeError.__init__(self, "libamofhip error %d: %s" % (code, message))
         self.code = code
+
+
+class Unsupported(AmofError):
+    """AMOF_EUNSUPPORTED: a specialised entry point does not take the arguments; the caller uses the general one"""
 
 
 class AmofTraj(ctypes.Structure):
@@ -114,6 +119,8 @@ def load_library():
         lib.amof_msd_window_dev.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.c_int64, ctypes.c_int64, P, P]
         lib.amof_msd_com_dev.argtypes = [P, TP, ctypes.c_int64, ctypes.c_int64, P]
+        lib.amof_msd_shard_begin.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, P]
+        lib.amof_msd_shard_finish.argtypes = [P, TP, P, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, P, P]
         lib.amof_msd_direct.argtypes = [P, TP, P]
         lib.amof_xyz_scan.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         lib.amof_xyz_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -321,6 +328,8 @@ class Context(Lane):
             raise ZeroDivisionError("Undefined angle")  # what ASE raises (reference amof/bad.py:100)
         if rc == AMOF_EINVAL:
             raise ValueError(msg)
+        if rc == AMOF_EUNSUPPORTED:
+            raise Unsupported(rc, msg)
         raise AmofError(rc, msg)
 
     @_locked
@@ -526,6 +535,35 @@ class Context(Lane):
         self._check(rc)
         return out, th.kinds
 
+
+    @_locked
+    def msd_shard_begin(self, packed, windows, atom_range, csum):
+        """first half of an atom-sharded window MSD (``amof_msd_shard_begin``): ``csum`` (torch CUDA f64 ``[F][3]``) receives
+        the mass-weighted coordinate sums of the atoms ``[a0, a1)`` per frame -- the caller all-reduces it over the ranks.
+        Raises :class:`Unsupported` where the fused form does not apply (the caller then takes ``msd_com`` + ``msd_window``)."""
+        th = self._traj(packed)
+        windows = np.ascontiguousarray(windows, dtype=np.int32)
+        assert csum.is_cuda and csum.is_contiguous() and csum.numel() == 3 * th.n_frames and csum.element_size() == 8
+        assert csum.device.index == self.device
+        self._order_after_torch()
+        self._check(self._lib.amof_msd_shard_begin(self._h, ctypes.byref(th.c), ctypes.c_void_p(windows.ctypes.data), len(windows),
+                                                   int(atom_range[0]), int(atom_range[1]), ctypes.c_void_p(csum.data_ptr())))
+        return csum
+
+    @_locked
+    def msd_shard_finish(self, packed, windows, atom_range, csum, out):
+        """second half (``amof_msd_shard_finish``, the next call on this context after its begin): adds the sums of the
+        atoms ``[a0, a1)`` into ``out`` (torch CUDA f64 ``[S][W]``); ``csum`` = the table summed over the ranks"""
+        th = self._traj(packed)
+        windows = np.ascontiguousarray(windows, dtype=np.int32)
+        assert csum.is_cuda and csum.is_contiguous() and csum.numel() == 3 * th.n_frames and csum.element_size() == 8
+        assert out.is_cuda and out.is_contiguous() and out.numel() == th.S * len(windows) and out.element_size() == 8
+        assert csum.device.index == self.device and out.device.index == self.device
+        self._order_after_torch()
+        self._check(self._lib.amof_msd_shard_finish(self._h, ctypes.byref(th.c), ctypes.c_void_p(windows.ctypes.data), len(windows),
+                                                    int(atom_range[0]), int(atom_range[1]), ctypes.c_void_p(csum.data_ptr()),
+                                                    ctypes.c_void_p(out.data_ptr())))
+        return out, th.kinds
 
     @_locked
     def msd_direct(self, packed):

@@ -68,6 +68,10 @@ struct amof_ctx {
     // synchronisation still reads it.
     unsigned char *pin = nullptr;
     size_t pin_cap = 0, pin_off = 0;
+    // amof_msd_shard_begin leaves scratch for amof_msd_shard_finish: valid while no other call ran on the context
+    int64_t calls = 0;            // entry points that started device work (timing_begin)
+    int64_t shard_ticket = 0;     // `calls` right after a begin; 0 = none pending
+    int64_t shard_key[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace amof {

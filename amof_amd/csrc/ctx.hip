@@ -143,6 +143,7 @@ void timing_begin(amof_ctx *ctx)
 {
     ctx->ev_valid = false;
     ctx->dom_launches = 0;
+    ctx->calls++;
     (void)hipEventRecord(ctx->ev_all0, ctx->stream);
 }
 void timing_end(amof_ctx *ctx)

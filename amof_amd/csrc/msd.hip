@@ -30,6 +30,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "amof_internal.h"
@@ -151,6 +152,27 @@ __device__ __forceinline__ double wave_sum_dpp(double x)
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
     };
     return ((lane(15) + lane(31)) + lane(47)) + x;      // (lane 63 holds the last row's total)
+}
+
+// The same sum with the four row totals combined by DPP row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into
+// rows 2 and 3) instead of readlanes: no scalar round trip (a v_readlane of a value a vector instruction has just written
+// waits, and three double sums per frame are the inner loop of msd_seg_kernel).  Valid in lane 63; fixed order.
+__device__ __forceinline__ double wave_sum_bcast(double x)
+{
+#define AMOF_DPP_STEP2(CTRL, ROWMASK)                                                                                  \
+    {                                                                                                                   \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWMASK, 0xf, false);                     \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWMASK, 0xf, false);                     \
+        x += __hiloint2double(hi, lo);                                                                                   \
+    }
+    AMOF_DPP_STEP2(0x111, 0xf)    // row_shr:1
+    AMOF_DPP_STEP2(0x112, 0xf)    // row_shr:2
+    AMOF_DPP_STEP2(0x114, 0xf)    // row_shr:4
+    AMOF_DPP_STEP2(0x118, 0xf)    // row_shr:8   (lane 15 of every row: the row's total)
+    AMOF_DPP_STEP2(0x142, 0xa)    // row_bcast:15 -> rows 1 and 3 add the total of the row before
+    AMOF_DPP_STEP2(0x143, 0xc)    // row_bcast:31 -> rows 2 and 3 add lane 31 (rows 0 + 1)
+#undef AMOF_DPP_STEP2
+    return x;
 }
 
 // 2-pass form: what a window kernel needs to finish a column of raw wrapped differences (dcT == nullptr: nothing to do)
@@ -981,6 +1003,446 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_reduce_kernel(const double *_
     if (threadIdx.x == 0) sumsq[blockIdx.x] = acc;
 }
 
+// ---- fused form (round 5): no transposed copy of the trajectory --------------------------------------------------
+// The transposed forms above write D_T (1.18 GB at the headline size) and read it back; their window kernel holds a whole
+// column in LDS, loads / scans / multiplies it one phase after the other, and a workgroup's columns one after the other
+// (profiles/r04/msd_experiments.txt: 24 % of the HBM peak; with the atoms in blocks, 8 x slower per atom --
+// profiles/r05/msd_blocks_experiment.txt).  For windows m_w = w d the pairs (k, k + w d) only couple frames of the same
+// residue r = k mod d, so a column is cut into SEGMENTS of d frames, e = 0 .. nq - 1 (nq = ceil(F / d)), and at "step" r
+// every segment contributes one comb entry  x_e(r) = U[e d + r]  (U = the running position):
+//   pass 1  msd_seg_kernel    one thread per (atom, segment): the segment's sum of wrapped raw differences RS[e][col] and,
+//                             per (64-atom tile, frame), the mass-weighted coordinate sums (cpart) -- pos read ONCE, 12 MB written
+//           com_tiles / com_steps (centre of mass, its steps dc, max |dc|), seg_scan (RS -> exclusive prefix P over e)
+//   pass 2  msd_fused_kernel  a workgroup = 24 columns (8 atoms) x all segments; a thread owns 5 consecutive segments of one
+//                             column and walks r = 0 .. d-1: one coalesced load per segment and step (pos read a SECOND time,
+//                             192 contiguous bytes per frame row and workgroup), x_e(r) = P_e + sum of raw differences
+//                             - c_k, published through LDS; every pair (e, e - w), w = 1 .. L, is formed from registers
+//                             (own entries) or ONE LDS read per partner entry (28 reads for 120 products)
+//           msd_colreduce     per-column sums -> sumsq[S][W] in species order (fixed order: deterministic)
+// HBM traffic 2 x pos + ~30 MB (3.64 GB before), no LDS-resident column (any F), all loads coalesced along the atoms.
+// The centre of mass enters as in the 2-pass form: wrap(raw - dc) = raw - dc unless |raw| comes within max|dc| of half the
+// cell; pass 2 checks every raw difference and raises a flag, and the call is then answered by the transposed forms.
+// Shape of pass 2's workgroups (256 threads, <= 128 VGPRs, 10 kB of LDS): what ONE retiring workgroup of the RDF tile
+// kernel frees on a CU, so that they are placed beside a running RDF launch (second lane: amof_amd/_lazy.py).
+constexpr int FU_EB = 5;          // comb entries (segments) per thread
+constexpr int FU_CPW = 24;        // columns (= 8 atoms) per workgroup; 32 (whole 128-byte lines, 5-wave workgroups) measured slower: 0.64 vs 0.47 ms
+constexpr int FU_MAX_TPC = 21;    // threads per column: nq <= 105 (workgroups of <= 512 threads: 168 registers per lane)
+
+// TPL atoms per lane (atoms a, a + 64, ...: a "tile" of cpart is 64 TPL atoms): their m p are added in the lane before the
+// wave sum -- the three double sums over the 64 lanes are ~60 of the ~130 instructions of a frame at TPL = 1.
+template <int TPL, int U>
+__global__ __launch_bounds__(256) void msd_seg_kernel(const double *__restrict__ pos, const double *__restrict__ geom, int n_cells,
+                                                      int64_t N, int F, int d, int nq, int64_t a_begin, int64_t a_end,
+                                                      const double *__restrict__ masses, double *__restrict__ RS,
+                                                      int64_t rs_stride, double *__restrict__ cpart)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = blockIdx.y * 4 + wv;
+    if (e >= nq) return;                     // (a whole wave; the kernel has no barrier)
+    const int k0 = e * d, k1 = min(k0 + d, F);
+    const size_t N3 = (size_t)N * 3;
+    bool ok[TPL];
+    double m[TPL], px[TPL], py[TPL], pz[TPL], rx[TPL], ry[TPL], rz[TPL];
+    const double *__restrict__ p[TPL];
+#pragma unroll
+    for (int t = 0; t < TPL; t++) {
+        const int64_t a = a_begin + ((int64_t)blockIdx.x * TPL + t) * 64 + lane;
+        ok[t] = a < a_end;
+        const int64_t aa = ok[t] ? a : a_begin;     // (idle lanes read an atom that exists and keep nothing)
+        m[t] = ok[t] ? masses[a] : 0.0;
+        p[t] = pos + (size_t)k0 * N3 + (size_t)aa * 3;
+        px[t] = py[t] = pz[t] = rx[t] = ry[t] = rz[t] = 0.0;
+        if (k0 >= 1) {
+            px[t] = p[t][-(ptrdiff_t)N3]; py[t] = p[t][1 - (ptrdiff_t)N3]; pz[t] = p[t][2 - (ptrdiff_t)N3];
+        }
+    }
+    // U frames per round, the next round's loads issued before this round's arithmetic
+    double qx[U][TPL], qy[U][TPL], qz[U][TPL], nx[U][TPL], ny[U][TPL], nz[U][TPL];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+        const size_t off = (size_t)(min(k0 + j, k1 - 1) - k0) * N3;
+#pragma unroll
+        for (int t = 0; t < TPL; t++) { qx[j][t] = p[t][off]; qy[j][t] = p[t][off + 1]; qz[j][t] = p[t][off + 2]; }
+    }
+    for (int kb = k0; kb < k1; kb += U) {
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const size_t off = (size_t)(min(kb + U + j, k1 - 1) - k0) * N3;
+#pragma unroll
+            for (int t = 0; t < TPL; t++) { nx[j][t] = p[t][off]; ny[j][t] = p[t][off + 1]; nz[j][t] = p[t][off + 2]; }
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const int k = kb + j;
+            if (k < k1) {
+                double mx = 0.0, my = 0.0, mz = 0.0;
+#pragma unroll
+                for (int t = 0; t < TPL; t++) {
+                    if (k >= 1) {
+                        const double *g = geom + (size_t)(n_cells == 1 ? 0 : k - 1) * MSD_GEOM;
+                        double dx, dy, dz;
+                        wrap_delta_t<true>(g, qx[j][t] - px[t], qy[j][t] - py[t], qz[j][t] - pz[t], dx, dy, dz);
+                        rx[t] += dx; ry[t] += dy; rz[t] += dz;
+                    }
+                    mx += m[t] * qx[j][t]; my += m[t] * qy[j][t]; mz += m[t] * qz[j][t];
+                    px[t] = qx[j][t]; py[t] = qy[j][t]; pz[t] = qz[j][t];
+                }
+                const double sx = wave_sum_bcast(mx), sy = wave_sum_bcast(my), sz = wave_sum_bcast(mz);
+                if (lane == 63) {
+                    double *o = cpart + ((size_t)blockIdx.x * (size_t)F + (size_t)k) * 3;
+                    o[0] = sx; o[1] = sy; o[2] = sz;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+#pragma unroll
+            for (int t = 0; t < TPL; t++) { qx[j][t] = nx[j][t]; qy[j][t] = ny[j][t]; qz[j][t] = nz[j][t]; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPL; t++) {
+        if (ok[t]) {
+            const int64_t a = a_begin + ((int64_t)blockIdx.x * TPL + t) * 64 + lane;
+            double *o = RS + (size_t)e * rs_stride + 3 * (a - a_begin);
+            o[0] = rx[t]; o[1] = ry[t]; o[2] = rz[t];
+        }
+    }
+}
+
+// csum[k][c] = sum over this call's atom tiles of cpart[t][k][c], in tile order (four thread groups share the tiles, their
+// partial sums are added in group order: deterministic)
+__global__ __launch_bounds__(MSD_THREADS) void com_tiles_kernel(const double *__restrict__ cpart, int ntiles, int F,
+                                                                double *__restrict__ csum)
+{
+    __shared__ double part[COMF_GROUPS][COMF_FRAMES][3];
+    const int k = blockIdx.x * COMF_FRAMES + threadIdx.x % COMF_FRAMES, g = threadIdx.x / COMF_FRAMES;
+    const int per = (ntiles + COMF_GROUPS - 1) / COMF_GROUPS, t0 = min(g * per, ntiles), t1 = min(t0 + per, ntiles);
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    if (k < F) {
+        for (int t = t0; t < t1; t += 8) {
+            double v[8][3];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const double *__restrict__ c = cpart + ((size_t)min(t + e, t1 - 1) * (size_t)F + (size_t)k) * 3;
+                v[e][0] = c[0]; v[e][1] = c[1]; v[e][2] = c[2];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (t + e < t1) { sx += v[e][0]; sy += v[e][1]; sz += v[e][2]; }
+        }
+    }
+    part[g][threadIdx.x % COMF_FRAMES][0] = sx; part[g][threadIdx.x % COMF_FRAMES][1] = sy; part[g][threadIdx.x % COMF_FRAMES][2] = sz;
+    __syncthreads();
+    for (int q = threadIdx.x; q < COMF_FRAMES * 3; q += MSD_THREADS) {
+        const int f = q / 3, c = q % 3, kk = blockIdx.x * COMF_FRAMES + f;
+        double sum = 0.0;
+        for (int gg = 0; gg < COMF_GROUPS; gg++) sum += part[gg][f][c];
+        if (kk < F) csum[(size_t)kk * 3 + c] = sum;
+    }
+}
+
+// c_k = csum_k / M (csum complete over ALL atoms: after the ranks' all-reduce in an atom-sharded run);
+// dcT[c][k] = c_k - c_k-1 (0 at k = 0), CT[c][k] = c_k, CT[3][k] = 0, dcmax[c] = max_k |dc| (bits)
+__global__ __launch_bounds__(MSD_THREADS) void com_steps_kernel(const double *__restrict__ csum, int F, int64_t Fp, double total_mass,
+                                                                double *__restrict__ dcT, double *__restrict__ CT,
+                                                                unsigned long long *__restrict__ dcmax)
+{
+    const int k = blockIdx.x * MSD_THREADS + threadIdx.x;
+    double mx[3] = {0.0, 0.0, 0.0};
+    if (k < F) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double ck = csum[(size_t)k * 3 + c] / total_mass;
+            const double dd = k == 0 ? 0.0 : ck - csum[(size_t)(k - 1) * 3 + c] / total_mass;
+            dcT[(size_t)c * Fp + k] = dd;
+            CT[(size_t)c * Fp + k] = ck;
+            mx[c] = fabs(dd);
+        }
+        CT[(size_t)3 * Fp + k] = 0.0;
+    }
+    // one atomic per wave and coordinate (15 000 atomics on three words took 13 us)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double v = mx[c];
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&dcmax[c], (unsigned long long)__double_as_longlong(v));      // (non-negative doubles order as integers)
+    }
+}
+
+// RS[e][col] -> exclusive prefix over e (the running raw position at the last frame before segment e)
+__global__ __launch_bounds__(256) void seg_scan_kernel(double *__restrict__ RS, int nq, int64_t ncols, int64_t stride)
+{
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols) return;
+    double run = 0.0;
+    constexpr int B = 10;                  // loads of a batch in flight together (a chain of nq dependent round trips otherwise)
+    for (int e0 = 0; e0 < nq; e0 += B) {
+        double v[B];
+#pragma unroll
+        for (int j = 0; j < B; j++) v[j] = e0 + j < nq ? RS[(size_t)(e0 + j) * stride + col] : 0.0;
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            if (e0 + j < nq) RS[(size_t)(e0 + j) * stride + col] = run;
+            run += v[j];
+        }
+    }
+}
+
+// Pair products of one step.  Own entries x[0 .. EB) are the comb entries e0 + i; their partners e0 - L .. e0 + EB - 2 (index
+// j = 0 .. L + EB - 2) come from LDS (j < L: rows of the step buffer, which starts with L GHOST rows of zeros for the entries
+// "before" the first segment) or are own entries (j >= L).
+// fused_products_fast: no predicate at all -- what a pair with a ghost row adds, x_hi^2, is taken back at the end of the
+// kernel (the caller keeps  s[i] = sum over the fast steps of x[i]^2).
+// fused_products_exact: every exception by predicate -- jmin: first partner that exists; jskip: the partner that is the
+// time origin (entry 0 at step 0: the reference never evaluates k = 0, amof/msd.py:200) or -1; nv: own entries that exist at
+// this step (the last segment may be short, the last thread's entries may lie beyond the trajectory).
+template <int L>
+__device__ __forceinline__ void fused_products_fast(const double (&x)[FU_EB], const double *__restrict__ xrow, double (&acc)[L + 1])
+{
+#pragma unroll
+    for (int j = 0; j < L + FU_EB - 1; j++) {
+        const double v = j >= L ? x[j >= L ? j - L : 0] : xrow[j * FU_CPW];
+#pragma unroll
+        for (int i = 0; i < FU_EB; i++) {
+            const int w = L + i - j;                           // (compile time)
+            if (w >= 1 && w <= L) {
+                const double dd = x[i] - v;
+                acc[w] = fma(dd, dd, acc[w]);
+            }
+        }
+    }
+}
+
+template <int L>
+__device__ __forceinline__ void fused_products_exact(const double (&x)[FU_EB], const double *__restrict__ xrow, int jmin, int jskip,
+                                                  int nv, double (&acc)[L + 1])
+{
+#pragma unroll
+    for (int j = 0; j < L + FU_EB - 1; j++) {
+        if (j >= jmin && j != jskip) {
+            const double v = j >= L ? x[j >= L ? j - L : 0] : xrow[j * FU_CPW];
+#pragma unroll
+            for (int i = 0; i < FU_EB; i++) {
+                const int w = L + i - j;                           // (compile time)
+                if (w >= 1 && w <= L && i < nv) {
+                    const double dd = x[i] - v;
+                    acc[w] = fma(dd, dd, acc[w]);
+                }
+            }
+        }
+    }
+}
+
+// GENERAL = false: every thread owns EB whole segments (nq a multiple of EB, F a multiple of d): only the predicate-free
+// step exists in the kernel (the exact step's predicates cost 100 registers more per lane).  CONSTCELL: one cell for all frames.
+template <int L, bool GENERAL, bool CONSTCELL, int PF>
+__device__ __forceinline__ void msd_fused_body(const double *__restrict__ pos, const double *__restrict__ P, int64_t p_stride,
+                                               const double *__restrict__ geom, int n_cells, const Dcom &dc, int64_t N, int F,
+                                               int d, int nq, int TPC, int64_t a_begin, int64_t ncols,
+                                               double *__restrict__ colpart, int64_t cp_stride, int W,
+                                               int32_t *__restrict__ flag)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double *xs = reinterpret_cast<double *>(lds_raw);            // [2][L + TPC * EB][CPW]: L ghost rows of zeros, then the entries
+    const int nrow = L + TPC * FU_EB;
+    const int tid = threadIdx.x, cl = tid % FU_CPW, eb = tid / FU_CPW;
+    // (measured and rejected: consecutive column blocks dealt to ONE XCD, so that the 128-byte lines two neighbouring blocks
+    //  share -- a block's row is 192 bytes -- come from that XCD's L2 the second time: 0.473 vs 0.467 ms, no gain)
+    const int64_t lc = (int64_t)blockIdx.x * FU_CPW + cl;        // column of this call's atom range
+    const bool on = eb < TPC && lc < ncols;
+    const int64_t col = 3 * a_begin + (lc < ncols ? lc : 0);     // column of the frame rows: 3 a + c (idle lanes: one that exists)
+    const int c = (int)(col % 3);
+    const int e0 = (eb < TPC ? eb : 0) * FU_EB;                  // (idle lanes look at rows that exist)
+    const size_t N3 = (size_t)N * 3;
+    const double thr = dcom_thr(dc, c);
+    const double *__restrict__ dcrow = dc.dcT + (size_t)c * dc.Fp;
+    // a constant cell: the three numbers of this coordinate's wrap (wrap_delta_t<true>) stay in registers
+    const double ginv = geom[9 + 4 * c], gper = geom[18 + c], glen = geom[4 * c];
+    // entry i (segment e0 + i) exists at step r while  i d + r < rem
+    const int rem = on ? max(0, min(F - e0 * d, (nq - e0) * d)) : 0;
+    // steps r < r_fast need no exception in a wave whose threads own EB whole segments each: the last segment is complete
+    // there (r_fast = its length); the pairs with the time origin that step 0 forms are taken back right after it
+    const int r_fast = GENERAL ? F - (nq - 1) * d : d;
+    bool clean = true;
+    if (GENERAL) {
+        const bool whole = !on || rem >= FU_EB * d || (rem > (FU_EB - 1) * d && e0 + FU_EB == nq);
+        clean = __all(whole) != 0;                               // (wave-uniform)
+    }
+    for (int q = tid; q < 2 * L * FU_CPW; q += blockDim.x) xs[(size_t)(q / (L * FU_CPW)) * nrow * FU_CPW + q % (L * FU_CPW)] = 0.0;
+    // x[i] = U_raw[k] - (c_k - c_0) at the thread's current frame of segment e0 + i (a constant per column cancels in every
+    // pair; this one keeps x small): x(k) = x(k - 1) + raw_k - dc_k, started from the segment's prefix
+    // (measured and rejected, profiles/r05/msd_fused_experiments.txt: positions loaded two and three steps ahead through a
+    //  register ring -- 1.35 / 2.07 ms instead of 0.47: the ring's registers cost the third wave per SIMD and more)
+    double x[FU_EB], prev[FU_EB], cur[PF][FU_EB], dcv[PF][FU_EB], sq[FU_EB], acc[L + 1];
+    const double *pp[FU_EB], *dp[FU_EB];                          // this thread's next loads (frame rows advance by N3 per step)
+#pragma unroll
+    for (int w = 0; w <= L; w++) acc[w] = 0.0;
+    const double c0 = dc.CT[(size_t)c * dc.Fp];
+#pragma unroll
+    for (int i = 0; i < FU_EB; i++) {
+        const int e = e0 + i;
+        x[i] = prev[i] = sq[i] = 0.0;
+        const bool have = GENERAL ? i * d < rem : true;           // (!GENERAL: idle lanes read rows that exist and drop the result)
+        const size_t k = (size_t)(have ? e : 0) * d;
+        pp[i] = pos + k * N3 + col;
+        dp[i] = dcrow + k;
+        if (have) {
+            x[i] = P[(size_t)e * p_stride + (lc < ncols ? lc : 0)] - (dc.CT[(size_t)c * dc.Fp + (k >= 1 ? k - 1 : 0)] - c0);
+            if (k >= 1) prev[i] = *(pp[i] - N3);
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            cur[u][i] = dcv[u][i] = 0.0;
+            if (have && (GENERAL ? i * d + u < rem && u < d : u < d)) {
+                cur[u][i] = pp[i][(size_t)u * N3];
+                dcv[u][i] = dp[i][u];
+            }
+        }
+    }
+    const int jmin = max(0, L - e0);
+    bool evt = false;
+    // one step: this thread's EB new comb entries (the wrapped raw difference of the frame, minus the centre-of-mass step),
+    // published through LDS; then the products.  FAST: no predicate (see fused_products_fast).
+    auto step = [&](int r, auto fast_tag, auto slot_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int SL = decltype(slot_tag)::value;
+        int nv = FAST ? FU_EB : 0;
+#pragma unroll
+        for (int i = 0; i < FU_EB; i++) {
+            if (FAST || i * d + r < rem) {
+                if (!FAST) nv = i + 1;
+                const int k = (e0 + i) * d + r;
+                double fr, per = gper, len = glen;
+                if (CONSTCELL) {
+                    fr = (cur[SL][i] - prev[i]) * ginv;
+                } else {
+                    const double *g = geom + (size_t)max(k - 1, 0) * MSD_GEOM;
+                    fr = (cur[SL][i] - prev[i]) * g[9 + 4 * c];
+                    per = g[18 + c];
+                    len = g[4 * c];
+                }
+                if (per != 0.0) {
+                    const double shift = 0.0 - 0.5 - 1e-7;
+                    double t = fr - shift;
+                    t = t - floor(t);
+                    fr = t + shift;
+                }
+                const double raw = k >= 1 ? fr * len : 0.0;       // (frame 0 has no predecessor)
+                evt |= fabs(raw) > thr;
+                x[i] += raw - dcv[SL][i];
+                prev[i] = cur[SL][i];
+            }
+        }
+        // the next step's loads: in flight behind the barrier and this step's products
+#pragma unroll
+        for (int i = 0; i < FU_EB; i++) {
+            if (FAST ? r + 1 < d : (i * d + r + 1 < rem && r + 1 < d)) {
+                pp[i] += N3;
+                dp[i] += 1;
+                cur[SL][i] = *pp[i];
+                dcv[SL][i] = *dp[i];
+            }
+        }
+        double *xb = xs + (size_t)(r & 1) * nrow * FU_CPW;
+        if (eb < TPC) {
+#pragma unroll
+            for (int i = 0; i < FU_EB; i++) xb[(L + e0 + i) * FU_CPW + cl] = x[i];
+        }
+        __syncthreads();       // (one barrier per step: the other buffer is rewritten only after everybody has passed this one)
+        const double *xrow = xb + (size_t)e0 * FU_CPW + cl;      // partner j = 0: entry e0 - L = row e0 behind the ghosts
+        if (FAST) {
+            fused_products_fast<L>(x, xrow, acc);
+#pragma unroll
+            for (int i = 0; i < FU_EB; i++) sq[i] = fma(x[i], x[i], sq[i]);
+            if (r == 0) {
+                // the reference never evaluates the time origin k = 0 (amof/msd.py:200): the pairs (entry w, entry 0) of this
+                // step, w = 1 .. L, go out again (every accumulator updated unconditionally, with a selected operand: a
+                // conditional update of ONE of them would turn the register array into memory)
+                const double x00 = xb[L * FU_CPW + cl];
+#pragma unroll
+                for (int i = 0; i < FU_EB; i++) {
+                    const double dd = x[i] - x00, d2 = dd * dd;
+#pragma unroll
+                    for (int w = 1; w <= L; w++) acc[w] -= e0 + i == w ? d2 : 0.0;
+                }
+            }
+        } else if (nv > 0) {
+            fused_products_exact<L>(x, xrow, jmin, (r == 0 && e0 <= L) ? L - e0 : -1, nv, acc);
+        }
+    };
+    auto run = [&](int ra, int rb, auto fast_tag) {
+        for (int r = ra; r < rb; r++) step(r, fast_tag, std::integral_constant<int, 0>());
+    };
+    if (!GENERAL) {
+        run(0, d, std::true_type());
+    } else {
+        // steps 0 .. r_fast - 1 | r_fast .. d - 1: the first range without predicates where the whole wave allows it
+        if (clean) run(0, r_fast, std::true_type());
+        else run(0, r_fast, std::false_type());
+        run(r_fast, d, std::false_type());
+    }
+    if (evt && on) atomicOr(flag, 1);
+    // what the fast steps added for partners before the first segment (ghost rows: x_hi^2 at every lag w > e_hi)
+#pragma unroll
+    for (int w = 1; w <= L; w++) {
+#pragma unroll
+        for (int i = 0; i < FU_EB; i++) acc[w] -= e0 + i < w ? sq[i] : 0.0;
+    }
+    // per column: the threads of its segments in fixed order (eb = 0, 1, ...)
+    double *red = xs;                                            // [2][TPC][CPW] (<= the step buffers)
+    __syncthreads();
+#pragma unroll
+    for (int w = 1; w <= L; w++) {
+        double *rb = red + (size_t)(w & 1) * TPC * FU_CPW;
+        if (eb < TPC) rb[eb * FU_CPW + cl] = acc[w];
+        __syncthreads();
+        if (eb == 0 && on && w < W) {
+            double tot = 0.0;
+            for (int q = 0; q < TPC; q++) tot += rb[q * FU_CPW + cl];
+            colpart[(size_t)w * cp_stride + lc] = tot;
+        }
+    }
+    if (eb == 0 && on) colpart[lc] = 0.0;                        // lag 0
+}
+
+// the lean kernel at three waves per SIMD (<= 168 registers); the general one takes what it needs (its exact step is rare)
+template <int L, int MAXT, bool CONSTCELL, int PF>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(3))) void msd_fused_kernel(
+    const double *__restrict__ pos, const double *__restrict__ P, int64_t p_stride, const double *__restrict__ geom, int n_cells, Dcom dc,
+    int64_t N, int F, int d, int nq, int TPC, int64_t a_begin, int64_t ncols, double *__restrict__ colpart, int64_t cp_stride, int W,
+    int32_t *__restrict__ flag)
+{
+    msd_fused_body<L, false, CONSTCELL, PF>(pos, P, p_stride, geom, n_cells, dc, N, F, d, nq, TPC, a_begin, ncols, colpart, cp_stride, W, flag);
+}
+
+template <int L, int MAXT, bool CONSTCELL>
+__global__ __launch_bounds__(MAXT) void msd_fused_general_kernel(
+    const double *__restrict__ pos, const double *__restrict__ P, int64_t p_stride, const double *__restrict__ geom, int n_cells, Dcom dc,
+    int64_t N, int F, int d, int nq, int TPC, int64_t a_begin, int64_t ncols, double *__restrict__ colpart, int64_t cp_stride, int W,
+    int32_t *__restrict__ flag)
+{
+    msd_fused_body<L, true, CONSTCELL, 1>(pos, P, p_stride, geom, n_cells, dc, N, F, d, nq, TPC, a_begin, ncols, colpart, cp_stride, W, flag);
+}
+
+// sumsq[s][w] = sum over the atoms of species s (perm order) of their three columns: one workgroup per (s, w)
+__global__ __launch_bounds__(MSD_THREADS) void msd_colreduce_kernel(const double *__restrict__ colpart, int64_t cp_stride,
+                                                                    const int32_t *__restrict__ perm,
+                                                                    const int32_t *__restrict__ sp_first, int64_t a_begin, int W,
+                                                                    double *__restrict__ sumsq)
+{
+    __shared__ double red[2 * (MSD_THREADS / 64)];
+    const int s = blockIdx.x / W, w = blockIdx.x % W;
+    const double *__restrict__ row = colpart + (size_t)w * cp_stride;
+    double acc = 0.0;
+    for (int q = sp_first[s] + threadIdx.x; q < sp_first[s + 1]; q += MSD_THREADS) {
+        const int64_t lc = 3 * ((int64_t)perm[q] - a_begin);
+        acc += (row[lc] + row[lc + 1]) + row[lc + 2];
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) sumsq[blockIdx.x] = acc;
+}
+
 // ---- unwrap path (amof/msd.py:222-230) in atom-major layout ----
 // OUT[col][k] = x0[col] + sum_{j<=k} IN[col][j]   (x0 == nullptr: plain prefix sum; IN may alias OUT).
 // Any F: the column is scanned in LDS segments with a running carry.
@@ -1147,6 +1609,121 @@ __global__ void add_f64_kernel(double *dst, const double *src, int n)
     if (i < n) dst[i] += src[i];
 }
 
+
+// ---- host side of the fused form ----
+namespace {
+
+struct FusedDims {
+    int d = 0, nq = 0, TPC = 0, L = 0;
+    int64_t ncols = 0, stride = 0;      // columns of the atom range; row stride of RS / colpart (columns padded to 32)
+    size_t lds = 0;
+    unsigned threads = 0;
+};
+
+// does the fused form take windows m_w = w * comb_d, w = 0 .. W-1, over F frames?
+bool fused_dims(int64_t F, int W, int comb_d, int64_t a0, int64_t a1, FusedDims &fd)
+{
+    if (comb_d < 16 || W < 2 || W > 32 || F < 64 || a1 <= a0) return false;
+    fd.d = comb_d;
+    fd.nq = (int)((F + comb_d - 1) / comb_d);
+    fd.TPC = (fd.nq + FU_EB - 1) / FU_EB;
+    if (fd.TPC > FU_MAX_TPC) return false;
+    fd.L = W <= 8 ? 7 : W <= 16 ? 15 : W <= 25 ? 24 : 31;
+    fd.ncols = 3 * (a1 - a0);
+    fd.stride = (fd.ncols + 31) / 32 * 32;
+    fd.threads = (unsigned)((fd.TPC * FU_CPW + 63) / 64 * 64);
+    fd.lds = (size_t)2 * (fd.L + fd.TPC * FU_EB) * FU_CPW * sizeof(double);
+    return true;
+}
+
+// pass 1 over the atoms [a0, a1): RS (SLOT_AUX7) and the tile sums, added up into csum[F][3] (device, overwritten)
+int fused_pass1(amof_ctx *ctx, const amof_traj *t, const double *pos_dev, const double *d_geom, const double *d_mass, int64_t a0,
+                int64_t a1, const FusedDims &fd, double *d_csum, double **d_RS_out)
+{
+    const int64_t N = t->n_atoms, F = t->n_frames;
+    // four atoms per lane where that still gives every SIMD a wave, else one
+    int tpl = (a1 - a0) * (int64_t)fd.nq >= (int64_t)4 * 64 * 1024 ? 4 : 1, useg = 4;
+    // (atoms per lane x frames per round 1 x 4, 1 x 8, 2 x 4, 4 x 2 all take 0.35 - 0.37 ms at the headline size: the kernel is
+    //  not bound by its instruction count or by its loads in flight -- profiles/r05/msd_fused_experiments.txt)
+    const int ntiles = (int)((a1 - a0 + 64 * tpl - 1) / (64 * tpl));
+    void *d_RS, *d_cpart;
+    AMOF_TRY(ensure(ctx, SLOT_AUX7, (size_t)fd.nq * (size_t)fd.stride * sizeof(double), &d_RS));
+    AMOF_TRY(ensure(ctx, SLOT_AUX6, (size_t)ntiles * (size_t)F * 3 * sizeof(double), &d_cpart));
+    const dim3 grid((unsigned)ntiles, (unsigned)((fd.nq + 3) / 4));
+#define AMOF_SEG(T, UU)                                                                                                     \
+    hipLaunchKernelGGL((msd_seg_kernel<T, UU>), grid, dim3(256), 0, ctx->stream, pos_dev, d_geom, (int)t->n_cells, N, (int)F, fd.d, \
+                       fd.nq, a0, a1, d_mass, (double *)d_RS, fd.stride, (double *)d_cpart)
+    if (tpl == 4) AMOF_SEG(4, 2);
+    else if (tpl == 2) AMOF_SEG(2, 4);
+    else if (useg == 8) AMOF_SEG(1, 8);
+    else AMOF_SEG(1, 4);
+#undef AMOF_SEG
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(com_tiles_kernel, dim3((unsigned)((F + COMF_FRAMES - 1) / COMF_FRAMES)), dim3(MSD_THREADS), 0, ctx->stream,
+                       (const double *)d_cpart, ntiles, (int)F, d_csum);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    *d_RS_out = (double *)d_RS;
+    return AMOF_OK;
+}
+
+// centre of mass from the complete csum, prefix of RS, pass 2, column sums -> d_out[S][W]; *d_flag_out: device word that is
+// non-zero when a raw difference could wrap again under the centre-of-mass step (the caller reads it back and then answers
+// the call with the transposed forms)
+int fused_pass2(amof_ctx *ctx, const amof_traj *t, const double *pos_dev, const double *d_geom, int64_t a0, const FusedDims &fd,
+                int W, const double *d_csum, double total_mass, double *d_RS, const int32_t *d_perm, const int32_t *d_spfirst,
+                double *d_out, int32_t **d_flag_out)
+{
+    const int64_t N = t->n_atoms, F = t->n_frames;
+    const int S = t->n_species;
+    const int64_t Fp = (F + 31) / 32 * 32;
+    void *d_dcT, *d_colpart, *d_flag;
+    AMOF_TRY(ensure(ctx, SLOT_AUX4, (size_t)7 * Fp * sizeof(double) + 64, &d_dcT));
+    AMOF_TRY(ensure(ctx, SLOT_AUX8, (size_t)(fd.L + 1) * (size_t)fd.stride * sizeof(double), &d_colpart));
+    double *d_CT = (double *)d_dcT + (size_t)3 * Fp;
+    unsigned long long *d_dcmax = (unsigned long long *)(d_CT + (size_t)4 * Fp);
+    d_flag = d_dcmax + 3;
+    // (dcmax and the flag word sit next to each other behind C: one fill)
+    AMOF_HIP_TRY(ctx, hipMemsetAsync(d_dcmax, 0, 3 * sizeof(unsigned long long) + 4 * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(com_steps_kernel, dim3((unsigned)((F + MSD_THREADS - 1) / MSD_THREADS)), dim3(MSD_THREADS), 0, ctx->stream,
+                       d_csum, (int)F, Fp, total_mass, (double *)d_dcT, d_CT, d_dcmax);
+    hipLaunchKernelGGL(seg_scan_kernel, dim3((unsigned)((fd.ncols + 255) / 256)), dim3(256), 0, ctx->stream, d_RS, fd.nq, fd.ncols,
+                       fd.stride);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    Dcom dc = {(const double *)d_dcT, d_CT, d_dcmax, d_geom, {0.0, 0.0, 0.0}, Fp, (int32_t)t->n_cells, 0};
+    for (int c = 0; c < 3; c++) {
+        double lmin = 1e300;
+        for (int64_t k = 0; k < t->n_cells; k++) lmin = std::min(lmin, fabs(t->cell[9 * k + 4 * c]));
+        dc.lhalf[c] = t->pbc[c] ? lmin * (0.5 - 1e-6) : 1e300;       // (a non-periodic axis never wraps)
+    }
+    timing_dom_begin(ctx, "msd_fused");
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = allow_max_lds((const void *)kern);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((fd.ncols + FU_CPW - 1) / FU_CPW)), dim3(fd.threads), fd.lds, ctx->stream, pos_dev,
+                           (const double *)d_RS, fd.stride, d_geom, (int)t->n_cells, dc, N, (int)F, fd.d, fd.nq, fd.TPC, a0, fd.ncols,
+                           (double *)d_colpart, fd.stride, W, (int32_t *)d_flag);
+        return hipGetLastError();
+    };
+    // lean kernel: every thread owns EB whole segments
+    const bool general = fd.nq % FU_EB != 0 || F % fd.d != 0 || getenv("AMOF_MSD_FUSED_GENERAL");
+    const bool constcell = t->n_cells == 1;
+    hipError_t e;
+#define AMOF_FUSED_L(LL)                                                                                                        \
+    (general ? (constcell ? go(msd_fused_general_kernel<LL, 512, true>) : go(msd_fused_general_kernel<LL, 512, false>))         \
+             : (constcell ? go(msd_fused_kernel<LL, 512, true, 1>) : go(msd_fused_kernel<LL, 512, false, 1>)))
+    e = fd.L == 7 ? AMOF_FUSED_L(7) : fd.L == 15 ? AMOF_FUSED_L(15) : fd.L == 24 ? AMOF_FUSED_L(24) : AMOF_FUSED_L(31);
+#undef AMOF_FUSED_L
+    AMOF_HIP_TRY(ctx, e);
+    timing_dom_end(ctx, 1);
+    hipLaunchKernelGGL(msd_colreduce_kernel, dim3((unsigned)(S * W)), dim3(MSD_THREADS), 0, ctx->stream, (const double *)d_colpart,
+                       fd.stride, d_perm, d_spfirst, a0, W, d_out);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    *d_flag_out = (int32_t *)d_flag;
+    return AMOF_OK;
+}
+
+}  // namespace
+
 // sumsq (host, overwritten) or sumsq_dev (device, accumulated into) receives the [S][W] sums; com_ext: optional
 // precomputed centre of mass of every frame (device [F][3]; frame-sharded ranks compute their rows with
 // amof_msd_com_dev and all-reduce them), not with unwrap (the unwrapped centre of mass is a different quantity)
@@ -1197,6 +1774,9 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
         }
     }
     sp_group_first[S] = (int32_t)groups.size();
+    std::vector<int32_t> sp_first_atom(S + 1, 0);       // species s owns perm[sp_first_atom[s] .. sp_first_atom[s + 1])
+    for (int s = 0; s < S; s++) sp_first_atom[s] = sp_group_first[s] < (int32_t)groups.size() ? groups[sp_group_first[s]].start : (int32_t)perm.size();
+    sp_first_atom[S] = (int32_t)perm.size();
     double total_mass = 0.0;
     if (remove_com)
         for (int64_t i = 0; i < N; i++) total_mass += t->masses[i];
@@ -1207,8 +1787,8 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
     AMOF_TRY(stage_positions(ctx, t, &pos_dev));
     const int64_t Fp = (F + 31) / 32 * 32;
     const size_t dt_bytes = (size_t)3 * N * Fp * sizeof(double);
-    const void *d_geom, *d_perm, *d_groups, *d_win, *d_mass = nullptr, *d_sgf;
-    void *d_com = nullptr, *d_DT, *d_UT = nullptr, *d_part, *d_out;
+    const void *d_geom, *d_perm, *d_groups, *d_win, *d_mass = nullptr, *d_sgf, *d_sfa;
+    void *d_com = nullptr, *d_DT = nullptr, *d_UT = nullptr, *d_part = nullptr, *d_out;
     // the call's small tables travel in ONE copy (a copy costs ~5 us of queue time however small: six of them were a tenth
     // of the pipeline)
     UploadPack pk;
@@ -1217,17 +1797,42 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
     const int i_groups = pk.add(groups.data(), groups.size() * sizeof(MsdGroup));
     const int i_win = pk.add(windows, (size_t)W * sizeof(int32_t));
     const int i_sgf = pk.add(sp_group_first.data(), sp_group_first.size() * sizeof(int32_t));
+    const int i_sfa = pk.add(sp_first_atom.data(), sp_first_atom.size() * sizeof(int32_t));
     const int i_mass = remove_com ? pk.add(t->masses, (size_t)N * sizeof(double)) : -1;
     AMOF_TRY(upload_pack(ctx, SLOT_GEOM, pk));
     d_geom = pk.ptr<double>(i_geom); d_perm = pk.ptr<int32_t>(i_perm); d_groups = pk.ptr<MsdGroup>(i_groups);
-    d_win = pk.ptr<int32_t>(i_win); d_sgf = pk.ptr<int32_t>(i_sgf);
+    d_win = pk.ptr<int32_t>(i_win); d_sgf = pk.ptr<int32_t>(i_sgf); d_sfa = pk.ptr<int32_t>(i_sfa);
     if (remove_com) {
         d_mass = pk.ptr<double>(i_mass);
         AMOF_TRY(ensure(ctx, SLOT_AUX2, (size_t)F * 3 * sizeof(double), &d_com));
     }
+    AMOF_TRY(ensure(ctx, SLOT_OUT0, (size_t)S * W * sizeof(double), &d_out));
+    // windows in arithmetic progression from 0 (the only thing WindowMsd produces): comb kernels
+    int comb_d = 0;
+    if (W >= 2 && W <= (lds_resident ? 128 : 256) && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
+        comb_d = windows[1];
+        for (int w = 0; w < W; w++)
+            if ((int64_t)windows[w] != (int64_t)w * comb_d) comb_d = 0;
+    }
+    // fused form (no transposed copy: see msd_seg_kernel): diagonal cells, the whole system in one call (the centre of
+    // mass needs every atom; atom-sharded ranks go through amof_msd_shard_begin / _finish), centre of mass removed, no unwrap
+    FusedDims fd;
+    bool done = false;
+    if (!unwrap && remove_com && !com_ext && hg.all_ortho && atom_begin == 0 && atom_end == N && !getenv("AMOF_MSD_NOFUSED") &&
+        fused_dims(F, W, comb_d, atom_begin, atom_end, fd)) {
+        double *d_RS = nullptr;
+        int32_t *d_flag = nullptr, evt = 0;
+        AMOF_TRY(fused_pass1(ctx, t, pos_dev, (const double *)d_geom, (const double *)d_mass, atom_begin, atom_end, fd,
+                             (double *)d_com, &d_RS));
+        AMOF_TRY(fused_pass2(ctx, t, pos_dev, (const double *)d_geom, atom_begin, fd, (int)W, (const double *)d_com, total_mass, d_RS,
+                             (const int32_t *)d_perm, (const int32_t *)d_sfa, (double *)d_out, &d_flag));
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(&evt, d_flag, sizeof evt, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (not sync_stream: the staged tables stay where they are)
+        done = evt == 0;       // else: an entry could wrap again under the centre-of-mass step -- the transposed forms answer
+    }
+    if (!done) {
     AMOF_TRY(ensure(ctx, SLOT_AUX3, dt_bytes, &d_DT));
     AMOF_TRY(ensure(ctx, SLOT_AUX5, groups.size() * (size_t)W * sizeof(double), &d_part));
-    AMOF_TRY(ensure(ctx, SLOT_OUT0, (size_t)S * W * sizeof(double), &d_out));
 
     // transposition tile: 32 frames x 64 atoms, 1024 threads (two consecutive frames per thread).  Measured on the
     // MI355X for the headline shape (profiles/r02/msd_transpose_shapes.txt): 0.52 ms = 4.5 TB/s of read + write; a
@@ -1246,13 +1851,6 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
         };
         return hg.all_ortho ? go(delta_transpose_kernel<TF, TA, TH, true>) : go(delta_transpose_kernel<TF, TA, TH, false>);
     };
-    // windows in arithmetic progression from 0 (the only thing WindowMsd produces): comb kernels
-    int comb_d = 0;
-    if (W >= 2 && W <= (lds_resident ? 128 : 256) && windows[0] == 0 && windows[1] > 0 && !getenv("AMOF_MSD_NOCOMB")) {
-        comb_d = windows[1];
-        for (int w = 0; w < W; w++)
-            if ((int64_t)windows[w] != (int64_t)w * comb_d) comb_d = 0;
-    }
     // 2-pass form (see the header): diagonal cells, the whole system in one call, the series LDS-resident
     Dcom dcom = {nullptr, nullptr, nullptr, (const double *)d_geom, {0.0, 0.0, 0.0}, Fp, (int32_t)t->n_cells, 0};
     // (the streaming window kernel subtracts C in its register scan: chunks of at most STREAM_CH entries per thread)
@@ -1274,6 +1872,7 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
         AMOF_HIP_TRY(ctx, transpose((const double *)nullptr, 0, N, (double *)d_cpart));
         hipLaunchKernelGGL(com_finish_kernel, dim3((unsigned)((F + COMF_FRAMES - 1) / COMF_FRAMES)), dim3(MSD_THREADS), 0,
                            ctx->stream, (const double *)d_cpart, ntiles, (int)F, Fp, total_mass, (double *)d_dcT, d_CT, d_dcmax);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
         dcom.dcT = (const double *)d_dcT;
         dcom.CT = d_CT;
         dcom.dcmax = d_dcmax;
@@ -1419,6 +2018,7 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
     hipLaunchKernelGGL(msd_reduce_kernel, dim3((unsigned)(S * W)), dim3(MSD_THREADS), 0, ctx->stream,
                        (const double *)d_part, (const int32_t *)d_sgf, (int)W, (double *)d_out);
     AMOF_HIP_TRY(ctx, hipGetLastError());
+    }   // (!done: the transposed forms)
     if (sumsq_dev) {
         hipLaunchKernelGGL(add_f64_kernel, dim3((unsigned)((S * W + 255) / 256)), dim3(256), 0, ctx->stream, sumsq_dev,
                            (const double *)d_out, S * (int)W);
@@ -1447,6 +2047,161 @@ extern "C" int amof_msd_window_dev(amof_ctx *ctx, const amof_traj *t, const int3
     if (!ctx) return AMOF_EINVAL;
     if (!sumsq_dev) return fail(ctx, AMOF_EINVAL, "NULL argument");
     return msd_window_run(ctx, t, windows, W, unwrap, remove_com, atom_begin, atom_end, com_dev, nullptr, sumsq_dev);
+}
+
+// ---- atom-sharded window MSD around ONE all-reduce: the fused form under atom sharding --------------------------------
+namespace {
+
+__global__ void com_from_csum_kernel(const double *__restrict__ csum, int n, double total_mass, double *__restrict__ com)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) com[i] = csum[i] / total_mass;
+}
+
+struct ShardTables {
+    std::vector<double> grec;
+    std::vector<int32_t> perm, sp_first;
+    const double *d_geom = nullptr, *d_mass = nullptr;
+    const int32_t *d_perm = nullptr, *d_sp_first = nullptr;
+    double total_mass = 0.0;
+    int comb_d = 0;
+    bool ortho = true;
+};
+
+// what both halves of a sharded call need on the device: geometry records, the species-sorted atoms of the range, masses
+int shard_tables(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W, int64_t a0, int64_t a1, ShardTables &st)
+{
+    const int S = t->n_species;
+    const int64_t N = t->n_atoms;
+    HostGeom hg;
+    AMOF_TRY(build_geometry(ctx, t, hg));
+    st.ortho = hg.all_ortho;
+    st.grec.assign((size_t)t->n_cells * MSD_GEOM, 0.0);
+    for (int64_t k = 0; k < t->n_cells; k++) {
+        for (int q = 0; q < 9; q++) st.grec[(size_t)k * MSD_GEOM + q] = t->cell[9 * k + q];
+        for (int q = 0; q < 9; q++) st.grec[(size_t)k * MSD_GEOM + 9 + q] = hg.invfull[(size_t)k * 9 + q];
+        for (int q = 0; q < 3; q++) st.grec[(size_t)k * MSD_GEOM + 18 + q] = t->pbc[q] ? 1.0 : 0.0;
+    }
+    st.sp_first.assign(S + 1, 0);
+    for (int s = 0; s < S; s++) {
+        st.sp_first[s] = (int32_t)st.perm.size();
+        for (int64_t i = a0; i < a1; i++)
+            if (t->species[i] == s) st.perm.push_back((int32_t)i);
+    }
+    st.sp_first[S] = (int32_t)st.perm.size();
+    st.total_mass = 0.0;
+    for (int64_t i = 0; i < N; i++) st.total_mass += t->masses[i];
+    st.comb_d = 0;
+    if (W >= 2 && windows[0] == 0 && windows[1] > 0) {
+        st.comb_d = windows[1];
+        for (int w = 0; w < W; w++)
+            if ((int64_t)windows[w] != (int64_t)w * st.comb_d) st.comb_d = 0;
+    }
+    UploadPack pk;
+    const int i_geom = pk.add(st.grec.data(), st.grec.size() * sizeof(double));
+    const int i_perm = pk.add(st.perm.data(), st.perm.size() * sizeof(int32_t));
+    const int i_spf = pk.add(st.sp_first.data(), st.sp_first.size() * sizeof(int32_t));
+    const int i_mass = pk.add(t->masses, (size_t)N * sizeof(double));
+    AMOF_TRY(upload_pack(ctx, SLOT_GEOM, pk));
+    st.d_geom = pk.ptr<double>(i_geom);
+    st.d_perm = pk.ptr<int32_t>(i_perm);
+    st.d_sp_first = pk.ptr<int32_t>(i_spf);
+    st.d_mass = pk.ptr<double>(i_mass);
+    return AMOF_OK;
+}
+
+int shard_check(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W, int64_t a0, int64_t a1)
+{
+    AMOF_TRY(validate_traj(ctx, t, true));
+    const int64_t N = t->n_atoms, F = t->n_frames;
+    if (W < 0 || (W > 0 && !windows)) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    if (a0 < 0 || a1 > N || a0 > a1) return fail(ctx, AMOF_EINVAL, "bad atom range");
+    if (!t->pos_on_device) return fail(ctx, AMOF_EUNSUPPORTED, "the sharded form reads device-resident positions");
+    if (F > 0x7fffffffLL) return fail(ctx, AMOF_EINVAL, "too many frames");
+    for (int w = 0; w < W; w++)
+        if (windows[w] < 0 || (F > 0 && windows[w] >= F)) return fail(ctx, AMOF_EINVAL, "window %d out of range", windows[w]);
+    return AMOF_OK;
+}
+
+}  // namespace
+
+extern "C" int amof_msd_shard_begin(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W, int64_t a0, int64_t a1,
+                                    double *csum_dev)
+{
+    if (!ctx) return AMOF_EINVAL;
+    if (!csum_dev) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    AMOF_TRY(shard_check(ctx, t, windows, W, a0, a1));
+    const int64_t F = t->n_frames;
+    ctx->shard_ticket = 0;
+    ShardTables st;
+    FusedDims fd;
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    AMOF_TRY(shard_tables(ctx, t, windows, W, a0, a1, st));
+    if (!st.ortho || getenv("AMOF_MSD_NOFUSED") || !fused_dims(F, W, st.comb_d, a0, std::max(a1, a0 + 1), fd))
+        return fail(ctx, AMOF_EUNSUPPORTED, "the fused window-MSD form does not take this call (general cell, or windows that are "
+                                            "not w * d with 16 <= d, W <= 32, ceil(F / d) <= %d)", FU_MAX_TPC * FU_EB);
+    timing_begin(ctx);
+    timing_dom_begin(ctx, "msd_fused");
+    if (a1 > a0) {
+        double *d_RS = nullptr;
+        AMOF_TRY(fused_dims(F, W, st.comb_d, a0, a1, fd) ? AMOF_OK : AMOF_EINVAL);
+        AMOF_TRY(fused_pass1(ctx, t, t->pos, st.d_geom, st.d_mass, a0, a1, fd, csum_dev, &d_RS));
+    } else {
+        AMOF_HIP_TRY(ctx, hipMemsetAsync(csum_dev, 0, (size_t)F * 3 * sizeof(double), ctx->stream));
+    }
+    timing_dom_end(ctx, 1);
+    timing_end(ctx);
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
+    ctx->shard_ticket = ctx->calls;       // (timing_begin counts the calls: a finish must be the NEXT call on this context)
+    ctx->shard_key[0] = (int64_t)(intptr_t)t->pos; ctx->shard_key[1] = F; ctx->shard_key[2] = t->n_atoms;
+    ctx->shard_key[3] = a0; ctx->shard_key[4] = a1; ctx->shard_key[5] = st.comb_d; ctx->shard_key[6] = W;
+    return AMOF_OK;
+}
+
+extern "C" int amof_msd_shard_finish(amof_ctx *ctx, const amof_traj *t, const int32_t *windows, int32_t W, int64_t a0, int64_t a1,
+                                     const double *csum_dev, double *sumsq_dev)
+{
+    if (!ctx) return AMOF_EINVAL;
+    if (!csum_dev || !sumsq_dev) return fail(ctx, AMOF_EINVAL, "NULL argument");
+    AMOF_TRY(shard_check(ctx, t, windows, W, a0, a1));
+    const int S = t->n_species;
+    const int64_t F = t->n_frames;
+    ShardTables st;
+    FusedDims fd;
+    AMOF_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    AMOF_TRY(shard_tables(ctx, t, windows, W, a0, a1, st));
+    const int64_t key[7] = {(int64_t)(intptr_t)t->pos, F, t->n_atoms, a0, a1, st.comb_d, W};
+    bool same = ctx->shard_ticket != 0 && ctx->shard_ticket == ctx->calls;
+    for (int q = 0; q < 7; q++) same = same && key[q] == ctx->shard_key[q];
+    ctx->shard_ticket = 0;
+    if (!same) return fail(ctx, AMOF_EINVAL, "amof_msd_shard_finish must follow amof_msd_shard_begin of the same arguments on this context");
+    if (a1 == a0 || W == 0) return AMOF_OK;
+    if (!fused_dims(F, W, st.comb_d, a0, a1, fd)) return fail(ctx, AMOF_EINVAL, "window list changed");
+    timing_begin(ctx);
+    void *d_RS, *d_out;
+    AMOF_TRY(ensure(ctx, SLOT_AUX7, (size_t)fd.nq * (size_t)fd.stride * sizeof(double), &d_RS));      // (what begin left there)
+    AMOF_TRY(ensure(ctx, SLOT_OUT0, (size_t)S * W * sizeof(double), &d_out));
+    int32_t *d_flag = nullptr, evt = 0;
+    AMOF_TRY(fused_pass2(ctx, t, t->pos, st.d_geom, a0, fd, (int)W, csum_dev, st.total_mass, (double *)d_RS, st.d_perm, st.d_sp_first,
+                         (double *)d_out, &d_flag));
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(&evt, d_flag, sizeof evt, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (evt) {
+        // an entry could wrap again under the centre-of-mass step: the transposed forms with the completed centre of mass
+        void *d_com;
+        AMOF_TRY(ensure(ctx, SLOT_AUX9, (size_t)F * 3 * sizeof(double), &d_com));
+        hipLaunchKernelGGL(com_from_csum_kernel, dim3((unsigned)((3 * F + 255) / 256)), dim3(256), 0, ctx->stream, csum_dev, (int)(3 * F),
+                           st.total_mass, (double *)d_com);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
+        AMOF_HIP_TRY(ctx, sync_stream(ctx));
+        return msd_window_run(ctx, t, windows, W, 0, 1, a0, a1, (const double *)d_com, nullptr, sumsq_dev);
+    }
+    hipLaunchKernelGGL(add_f64_kernel, dim3((unsigned)((S * W + 255) / 256)), dim3(256), 0, ctx->stream, sumsq_dev, (const double *)d_out,
+                       S * (int)W);
+    AMOF_HIP_TRY(ctx, hipGetLastError());
+    timing_end(ctx);
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
+    return AMOF_OK;
 }
 
 extern "C" int amof_msd_com_dev(amof_ctx *ctx, const amof_traj *t, int64_t frame_begin, int64_t frame_end, double *com_dev)

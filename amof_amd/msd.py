@@ -160,16 +160,26 @@ class WindowMsd(Msd, Deferred):
         ctx = _hip.lane_context(dev, 1)
         sharded = merge and distributed != 'local'
         on_device = sharded and _dist.device_collectives()
-        com = None
+        com = csum = None
         if on_device and unwrap != True and packed.on_device:  # noqa: E712  (the unwrapped centre of mass is another quantity)
-            # atoms are sharded (reference: one joblib worker per element, amof/msd.py:252-256); what every rank would
-            # otherwise repeat -- the centre of mass of EVERY frame from all atoms -- is frame-sharded: each rank fills
-            # its rows of a zeroed [F][3] table, one all-reduce (120 kB at 5000 frames; x + 0 = x, exact) completes it.
-            # (Here, in the calling thread: collectives are issued in program order, never from a lane.)
+            # atoms are sharded (reference: one joblib worker per element, amof/msd.py:252-256).  What couples the ranks is
+            # the centre of mass of every frame, a sum over ALL atoms: each rank reads ITS atoms once and contributes their
+            # mass-weighted coordinate sums per frame, ONE all-reduce of [F][3] (120 kB at 5000 frames) completes them, and
+            # the rank's second pass finishes its atoms (amof_msd_shard_begin / _finish: 1 / world of the trajectory per rank
+            # and pass).  The first half and the all-reduce run here, in the calling thread -- collectives are issued in
+            # program order, never from a lane -- the second half on the lane.
             import torch
-            com = torch.zeros((F, 3), dtype=torch.float64, device=torch.device("cuda", ctx.device))
-            ctx.msd_com(packed, _dist.shard_range(F, rank, world), com)
-            _dist.all_reduce_sum(com)
+            csum = torch.empty((F, 3), dtype=torch.float64, device=torch.device("cuda", ctx.device))
+            try:
+                ctx.msd_shard_begin(packed, window, atom_range, csum)
+                _dist.all_reduce_sum(csum)
+            except _hip.Unsupported:
+                # general cells, irregular windows: the centre of mass frame-sharded into a zeroed table (x + 0 = x, exact),
+                # then the general kernels on the rank's atoms
+                csum = None
+                com = torch.zeros((F, 3), dtype=torch.float64, device=torch.device("cuda", ctx.device))
+                ctx.msd_com(packed, _dist.shard_range(F, rank, world), com)
+                _dist.all_reduce_sum(com)
 
         def local():
             # this rank's kernels (a lane job: amof_amd/_lazy.py)
@@ -178,6 +188,8 @@ class WindowMsd(Msd, Deferred):
                 import torch
                 out = torch.zeros((len(_hip.packed_species(packed)[0]), len(window)), dtype=torch.float64,
                                   device=torch.device("cuda", ctx.device))
+                if csum is not None:
+                    return ctx.msd_shard_finish(packed, window, atom_range, csum, out)
                 return ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712
                                       atom_range=atom_range, com=com, out=out)
             return ctx.msd_window(packed, window, unwrap=(unwrap == True), remove_com=True,  # noqa: E712

@@ -706,7 +706,8 @@ def main():
                     "effective_clock_ghz": clock / 1e9, "cost_table": model.get("cost_table"),
                     "note": "share of the SIMDs' issue cycles the kernel's executed VALU instructions need at their "
                             "measured per-class issue costs; the rest is LDS / scalar / wait time"}
-        msd_bytes = alg_bytes if world == 1 else F * (24 * N + 72)      # every rank reads all frames for the COM
+        # (atom-sharded: a rank reads ITS atoms, twice; the algorithmic bytes of its share)
+        msd_bytes = alg_bytes if world == 1 else F * (24 * ((N + world - 1) // world) + 72)
         out = {
             "metric": "frames/s (RDF+MSD, 10k-atom ZIF-4)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -734,8 +735,9 @@ def main():
                                  "to this kernel -- see valu_issue and pair_evals_per_s"},
             "pair_evals_per_s": pairs / t_rdf, "pairs_in_range_per_s": in_range / t_rdf,
             "roofline_valu": roofline_valu, "valu_issue": valu, "counter_files_match_built_sources": counters_current,
-            "roofline_msd": {"kernel": "msd pipeline, 2-pass form (delta_transpose with the tile sums of m p | com_finish | msd_stream | reduce)"
-                                       if world == 1 else "msd pipeline (com share + all-reduce | delta_transpose | msd_stream | reduce)",
+            "roofline_msd": {"kernel": "msd pipeline, fused form (msd_seg: segment sums + tile sums of m p | com_tiles / com_steps / seg_scan | "
+                                       "msd_fused: second pass over pos, products from registers and LDS | colreduce)"
+                                       if world == 1 else "msd pipeline, atom-sharded fused form (shard_begin | all-reduce of the [F][3] sums | shard_finish)",
                              "bound": "hbm",
                              "achieved": msd_bytes / seq["all"] / 1e9, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": msd_bytes / seq["all"] / 1e9 / HBM_PEAK_GBPS,

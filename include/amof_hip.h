@@ -39,6 +39,7 @@ extern "C" {
 #define AMOF_EHIP (-5)       /* HIP runtime error (message in amof_last_error) */
 #define AMOF_ECAPACITY (-6)  /* a documented kernel capacity was exceeded */
 #define AMOF_ENODEVICE (-7)  /* no usable GPU */
+#define AMOF_EUNSUPPORTED (-8) /* a specialised entry point does not take these arguments: use the general one */
 
 #define AMOF_ABI_VERSION 4
 
@@ -115,7 +116,8 @@ int64_t amof_last_kernel_launches(const amof_ctx *ctx);
  *        "cn_cell", "cn_fast", "cn_exact"
  *   BAD  "bad_frame" (whole frame in LDS), "bad_frame_slabs" (z-slabs of a frame in LDS), "bad_cell", "bad_fast",
  *        "bad_exact", "bad_exact_biglist"
- *   MSD  "msd_stream" (register-ring comb, window spacing 64..256), "msd_comb" (block comb kernels incl. the
+ *   MSD  "msd_fused" (no transposed copy: diagonal cells, evenly spaced windows), "msd_stream" (register-ring comb, window
+ *        spacing 64..256), "msd_comb" (block comb kernels incl. the
  *        double-buffered and > 32-window passes), "msd_group" (arbitrary window lists), "msd_comb_global" /
  *        "msd_global" (series too long for LDS), "msd_direct", "msd_com" (amof_msd_com_dev alone) */
 const char *amof_last_path(const amof_ctx *ctx);
@@ -216,6 +218,25 @@ int amof_msd_window_dev(amof_ctx *ctx, const amof_traj *traj, const int32_t *win
                         const double *com_dev /* device [F][3] or NULL */, double *sumsq_dev /* device [S][W], += */);
 int amof_msd_com_dev(amof_ctx *ctx, const amof_traj *traj, int64_t frame_begin, int64_t frame_end,
                      double *com_dev /* device [F][3] */);
+
+/*
+ * Atom-sharded window MSD around ONE all-reduce (one process per GPU; the element-parallel split this stands in for:
+ * amof/msd.py:252-256).  Every rank holds the whole device-resident trajectory and owns the atoms [atom_begin, atom_end):
+ *   amof_msd_shard_begin  reads ITS atoms once: csum_dev[F][3] (device, overwritten) = sum over its atoms of m_a p_a(k),
+ *                         its share of the centre of mass of every frame (amof/msd.py:235-237), and keeps the segment
+ *                         sums of its atoms' wrapped displacements in the context's scratch;
+ *   the caller sums csum_dev over the ranks (one all-reduce of 24 F bytes);
+ *   amof_msd_shard_finish reads its atoms a second time and ADDS their sums of squared displacements (amof_msd_window's
+ *                         definition) into sumsq_dev[S][W] (device), which the caller all-reduces next.
+ * finish must be the next call on the context after its begin, with the same arguments.  begin returns AMOF_EUNSUPPORTED
+ * (nothing done) where this form does not apply -- general (non-diagonal) cells, host positions, windows that are not
+ * w * d (16 <= d, W <= 32) -- and the caller then uses amof_msd_com_dev + amof_msd_window_dev.
+ */
+int amof_msd_shard_begin(amof_ctx *ctx, const amof_traj *traj, const int32_t *windows, int32_t n_windows,
+                         int64_t atom_begin, int64_t atom_end, double *csum_dev /* device [F][3] */);
+int amof_msd_shard_finish(amof_ctx *ctx, const amof_traj *traj, const int32_t *windows, int32_t n_windows,
+                          int64_t atom_begin, int64_t atom_end, const double *csum_dev /* device [F][3], summed over the ranks */,
+                          double *sumsq_dev /* device [S][W], += */);
 
 /*
  * Direct MSD with running unwrap, orthogonal cells only (deprecated in the reference).
