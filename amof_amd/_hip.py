@@ -35,6 +35,7 @@ EXPORTS = [
     "amof_bad_hist_by_cn",
     "amof_msd_window", "amof_msd_window_dev", "amof_msd_com_dev", "amof_msd_shard_begin", "amof_msd_shard_finish", "amof_msd_direct",
     "amof_xyz_scan", "amof_xyz_read", "amof_xyz_open", "amof_xyz_read_frames", "amof_xyz_close", "amof_cp2k_cell_read", "amof_ingest_last_error",
+    "amof_pack_frames", "amof_frames_checksum",
 ]
 
 
@@ -133,6 +134,8 @@ def load_library():
         lib.amof_xyz_close.restype = None
         lib.amof_cp2k_cell_read.argtypes = [ctypes.c_char_p, ctypes.c_int64, P, ctypes.POINTER(ctypes.c_int64)]
         lib.amof_ingest_last_error.restype = ctypes.c_char_p
+        lib.amof_pack_frames.argtypes = [P, ctypes.c_int64, ctypes.c_int64, P, P, ctypes.c_int32]
+        lib.amof_frames_checksum.argtypes = [P, ctypes.c_int64, ctypes.c_int64, P, ctypes.c_int32]
         if lib.amof_abi_version() != ABI_VERSION:
             raise RuntimeError("libamofhip.so ABI version %d, expected %d" % (lib.amof_abi_version(), ABI_VERSION))
         _lib = lib
@@ -719,6 +722,11 @@ def get_context(device=None, lane=0):
             ctx = Context(device, high_priority=bool(lane))
             _contexts[key] = ctx
         return ctx
+
+
+def default_device():
+    """the GPU an analysis goes to when the caller names none: LOCAL_RANK (one process per GPU) or 0"""
+    return int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def lane_context(device, lane):

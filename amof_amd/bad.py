@@ -25,7 +25,7 @@ from . import atom as amatom
 from . import data as _data
 from . import dist as _dist
 from .files import path as _path
-from .frames import pack_trajectory
+from .frames import pack_trajectory, resident_source
 
 logger = logging.getLogger(__name__)
 
@@ -82,7 +82,7 @@ class Bad(CoreBad, Deferred):
     def compute_bad(self, trajectory, nb_set_and_cutoff, dtheta, normalization='total', parallel=False,
                     device=None, distributed=None):
         """compute bond-angle distributions (reference amof/bad.py:116-160)"""
-        packed = pack_trajectory(trajectory)
+        packed = pack_trajectory(trajectory, device=device if device is not None else _hip.default_device())
         atomic_numbers_unique = packed.unique_numbers()
 
         cutoff_dict = amatom.format_cutoff(nb_set_and_cutoff)
@@ -133,15 +133,20 @@ class Bad(CoreBad, Deferred):
                     cols[aba_str] = n / db / n.sum()      # numpy.histogram(density=True)
             self.data = pd.DataFrame(cols)
 
-        if getattr(packed, "is_stream", False):
+        source = resident_source(packed, ctx.device, allow=not merge and hasattr(ctx, "submit"))
+        if getattr(source, "is_stream", False):
             if merge:
                 raise ValueError("a streamed trajectory is analysed by one process (distributed=False)")
-            hist, nang = np.zeros((len(triples), bins + 1), dtype=np.uint64), np.zeros(len(triples), dtype=np.uint64)
-            for batch in packed.batches():
-                if triples:
-                    h, a = ctx.bad_hist(batch, rcm, triples, theta_bins)
-                    hist, nang = hist + h, nang + a
-            assemble(hist, nang)
+
+            def walk():
+                hist, nang = np.zeros((len(triples), bins + 1), dtype=np.uint64), np.zeros(len(triples), dtype=np.uint64)
+                for batch in source.batches():
+                    if triples:
+                        h, a = ctx.bad_hist(batch, rcm, triples, theta_bins)
+                        hist, nang = hist + h, nang + a
+                return hist, nang
+
+            self._defer(ctx, walk, lambda raw: assemble(raw[0], raw[1]))
             return
         on_device = bool(triples) and merge and _dist.device_collectives()
         T, nb = len(triples), bins + 1

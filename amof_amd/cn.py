@@ -19,7 +19,7 @@ from . import data as _data
 from . import dist as _dist
 from . import trajectory as _trajectory
 from .files import path as _path
-from .frames import pack_trajectory
+from .frames import pack_trajectory, resident_source
 
 logger = logging.getLogger(__name__)
 
@@ -57,7 +57,7 @@ class CoordinationNumber(Deferred):
 
     def compute_cn(self, trajectory, nb_set_and_cutoff, step, parallel=False, device=None, distributed=None):
         """compute coordination numbers (reference amof/cn.py:48-82)"""
-        packed = pack_trajectory(trajectory)
+        packed = pack_trajectory(trajectory, device=device if device is not None else _hip.default_device())
         logger.info("Start computing coordination number for %s frames", len(packed))
         cutoff_dict = amatom.format_cutoff(nb_set_and_cutoff)
         kinds, _ = _hip.packed_species(packed)
@@ -96,12 +96,17 @@ class CoordinationNumber(Deferred):
                 data[name] = col
             self.data = pd.DataFrame(data)
 
-        if getattr(packed, "is_stream", False):
+        source = resident_source(packed, ctx.device, allow=not merge and hasattr(ctx, "submit"))
+        if getattr(source, "is_stream", False):
             if merge:
                 raise ValueError("a streamed trajectory is analysed by one process (distributed=False)")
-            rows = [ctx.cn_count(batch, rcm, live) if live else np.zeros((len(batch), 0), dtype=np.int64)
-                    for batch in packed.batches()]
-            assemble(np.concatenate(rows, axis=0) if rows else np.zeros((0, len(live)), dtype=np.int64))
+
+            def walk():
+                rows = [ctx.cn_count(batch, rcm, live) if live else np.zeros((len(batch), 0), dtype=np.int64)
+                        for batch in source.batches()]
+                return np.concatenate(rows, axis=0) if rows else np.zeros((0, len(live)), dtype=np.int64)
+
+            self._defer(ctx, walk, assemble)
             return
         sharded = merge and distributed != 'local'
 

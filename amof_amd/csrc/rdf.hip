@@ -1581,7 +1581,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 bool ok = true;
                 double slack = 1e300, share = 0.0, l10b = 0.0, c10max = 0.0, tau_max = 0.0;
                 int near = 0;
-                bool twin = false;
+                bool twin = false, xw_wraps = false, twin_wraps = false;
                 std::vector<double> fold((size_t)nc * 2), rec((size_t)nc * 9);
                 for (int64_t k = 0; k < nc && ok; k++) {
                     const double *c = t->cell + 9 * k;
@@ -1599,6 +1599,12 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     if (tau_y > 0.09 || tau_z > 0.0075) { ok = false; break; }
                     if (tau_y > 0.0075) twin = true;
                     tau_max = std::max(tau_max, std::max(tau_y, 0.0));
+                    // The x wrap of XW and of the twin image forms (int)(fy * c10), fy = the y difference in units of 2^-32 of the
+                    // cell: modular arithmetic only while |fy c10| < 2^31 (the conversion saturates beyond).  In range means
+                    // |fy| <= R / L11 cells (the twin: 1/2 + tau_y), so a skewed, non-reduced cell with |L10| >~ L00 cannot take
+                    // these variants: rdf_tile_img / rdf_exact answer it.
+                    if (fabs(L[3]) / L[0] * (R / L[4] + 1e-3) >= 0.5 - 1e-3) xw_wraps = true;
+                    if (fabs(L[3]) / L[0] * (0.5 + std::max(tau_y, 0.0) + 1e-3) >= 0.5 - 1e-3) twin_wraps = true;
                     // A second image along y (z) can only be in range when L11 / 2 < R0 (canonical rmax with rounding slack);
                     // then its in-plane components are below rho = sqrt(R0^2 - (L/2)^2), the evaluated image's differ from them
                     // by at most the lattice offsets, so it lies between L - R0 and sqrt(D2max) from the origin.  When that
@@ -1637,8 +1643,10 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 // (measured: + 8 % per compare, + 24 % for the wrap, profiles/r04/tri_experiments.txt)
                 if (twin) {
                     if (near == 3) ok = false;      // (a common twin along y AND near tests along z: the image-aware / exact kernels)
+                    if (twin_wraps) ok = false;
                     near = 4;
                 }
+                if (!(slack > 0.0) && xw_wraps) ok = false;
                 const int code = near + (slack > 0.0 ? 0 : 5);
                 const double cost = (near == 0 ? 0.0 : near == 1 ? 0.5 : near == 4 ? 6.0 : (double)(near - 1) * 1.5) +
                                     (slack > 0.0 ? 0.0 : 2.5);

@@ -265,15 +265,30 @@ class PackedTrajectory(object):
             except ValueError:          # a truly read-only base (np.memmap mode='r', np.frombuffer): stage through a copy
                 src = np.array(self.pos)
         self._dev_pos = torch.from_numpy(src).to(torch.device("cuda", int(device)))
-        self._was_writeable = was_writeable
-        self.pos.flags.writeable = False
+        self._protect()
         return self
 
+    def _protect(self):
+        """while a device copy exists ``self.pos`` is a READ-ONLY view of the host array (an array that cannot be made
+        writeable again later -- one backed by a torch tensor, say -- keeps its flag: the view carries the protection)"""
+        if "_pos_rw" not in self.__dict__:
+            self._pos_rw = self.pos
+            view = self.pos.view()
+            view.flags.writeable = False
+            self.pos = view
+
+    def _unprotect(self):
+        rw = self.__dict__.pop("_pos_rw", None)
+        if rw is not None:
+            self.pos = rw
+
     def release_device(self):
+        rc = self.__dict__.pop("_resident", None)
+        if rc is not None and not rc.complete:
+            rc.finish()                 # (an upload in flight is completed first: its thread writes into the tensor)
         if getattr(self, "_dev_pos", None) is not None:
             self._dev_pos = None
-            if getattr(self, "_was_writeable", True):      # (an array that was read-only before stays read-only)
-                self.pos.flags.writeable = True
+            self._unprotect()
         return self
 
     def to_device(self, device=0):
@@ -336,51 +351,327 @@ def _usable_cpus():
     return max(1, n)
 
 
-def pack_trajectory(trajectory):
+def _gpu_for_uploads(device):
+    """torch, when a host trajectory can get a resident copy on ``device``; None otherwise (no GPU, torch missing, switched
+    off with AMOF_KEEP_ON_DEVICE=0)"""
+    import os
+    if device is None or isinstance(device, (list, tuple)) or os.environ.get("AMOF_KEEP_ON_DEVICE", "1") == "0":
+        return None
+    try:
+        import torch
+    except ImportError:
+        return None
+    if not torch.cuda.is_available() or int(device) >= torch.cuda.device_count():
+        return None
+    return torch
+
+
+class ResidentCopy(object):
+    """The device copy of a HOST trajectory, filled in frame order while its first analyses already run.
+
+    A list of frames or a host ``PackedTrajectory`` used to be staged over PCIe by every analysis call again (1.2 GB per
+    call at the headline size: 139 ms for RDF + MSD where the kernels need 75).  Now the first analysis that meets a host
+    trajectory starts ONE upload -- chunks of frames through page-locked memory on a stream of its own, every chunk marked
+    with an event -- and walks the chunks that have arrived like the batches of a stream (RDF / BAD / CN add their integer
+    counts up batch by batch: amof_amd/stream.py); when the upload is complete the trajectory keeps the copy
+    (``keep_on_device``: the host array is read-only while it exists; ``release_device()`` drops it) and every later
+    analysis of the same object reads it in place.  Offers what the classes ask of a stream: ``batches()``, ``read_all()``.
+    """
+
+    is_stream = True
+    on_device = False
+    CHUNK_BYTES = 48 << 20
+    PIECE_FRAMES = 512          # a batch handed to an analysis: at least this many frames (an RDF launch per batch)
+
+    def __init__(self, packed, device, torch, pinned_source=False, defer=False):
+        import threading
+        self.packed = packed
+        self.device = int(device)
+        self._torch = torch
+        F, N = packed.n_frames, packed.n_atoms
+        self.n_frames, self.n_atoms = F, N
+        self.numbers, self.masses, self.pbc, self.cell = packed.numbers, packed.masses, packed.pbc, packed.cell
+        self.dev = torch.empty((F, N, 3), dtype=torch.float64, device=torch.device("cuda", self.device))
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.chunk = max(1, min(F, self.CHUNK_BYTES // max(1, 24 * N)))
+        self._marks = []                # (frames uploaded so far, event)
+        self._cond = threading.Condition()
+        self._error = None
+        self._pinned_source = pinned_source
+        self.complete = F == 0
+        if not defer and F:
+            self._thread = threading.Thread(target=self._run, name="amof-upload", daemon=True)
+            self._thread.start()
+
+    # -- producer -------------------------------------------------------------------------------------------------------
+    def push(self, f0, f1):
+        """frames [f0, f1) of the host array are final: queue their copy (the host array is page-locked: truly asynchronous)"""
+        torch = self._torch
+        with torch.cuda.stream(self.stream):
+            self.dev[f0:f1].copy_(torch.from_numpy(self.packed.pos[f0:f1]), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        with self._cond:
+            self._marks.append((f1, ev))
+            self._cond.notify_all()
+
+    def _run(self):
+        try:
+            torch = self._torch
+            F = self.n_frames
+            if self._pinned_source:
+                for f0 in range(0, F, self.chunk):
+                    self.push(f0, min(F, f0 + self.chunk))
+                return
+            # pageable source: through two page-locked staging buffers (a pageable hipMemcpyAsync blocks the caller and
+            # runs at a fraction of the link rate)
+            slots = [torch.empty((self.chunk, self.n_atoms, 3), dtype=torch.float64, pin_memory=True) for _ in range(2)]
+            busy = [None, None]
+            src = self.packed.pos
+            for q, f0 in enumerate(range(0, F, self.chunk)):
+                f1 = min(F, f0 + self.chunk)
+                j = q % 2
+                if busy[j] is not None:
+                    busy[j].synchronize()
+                np.copyto(slots[j].numpy()[:f1 - f0], src[f0:f1])
+                with torch.cuda.stream(self.stream):
+                    self.dev[f0:f1].copy_(slots[j][:f1 - f0], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                busy[j] = ev
+                with self._cond:
+                    self._marks.append((f1, ev))
+                    self._cond.notify_all()
+            for ev in busy:
+                if ev is not None:
+                    ev.synchronize()
+        except BaseException as exc:       # handed to the consumers
+            with self._cond:
+                self._error = exc
+                self._cond.notify_all()
+
+    # -- consumers ------------------------------------------------------------------------------------------------------
+    def _wait_frames(self, f1):
+        """block until frames [0, f1) are on the device"""
+        with self._cond:
+            while True:
+                if self._error is not None:
+                    raise self._error
+                hit = next((ev for upto, ev in self._marks if upto >= f1), None)
+                if hit is not None:
+                    break
+                self._cond.wait(0.5)
+        hit.synchronize()
+
+    def __len__(self):
+        return self.n_frames
+
+    def unique_numbers(self):
+        return self.packed.unique_numbers()
+
+    def species_counts(self):
+        return self.packed.species_counts()
+
+    def formula_count(self):
+        return self.packed.formula_count()
+
+    def cell_lengths(self):
+        return self.packed.cell_lengths()
+
+    def volume_sum(self):
+        return self.packed.volume_sum()
+
+    def _piece(self, f0, f1):
+        cell = self.cell if self.cell.shape[0] == 1 else self.cell[f0:f1]
+        return PackedTrajectory(self.dev[f0:f1], cell, self.numbers, self.masses, self.pbc)
+
+    def batches(self):
+        """device-resident pieces in frame order, each as soon as it has arrived"""
+        F = self.n_frames
+        f0 = 0
+        while f0 < F:
+            f1 = min(F, f0 + self.PIECE_FRAMES)
+            with self._cond:
+                have = max([u for u, _ in self._marks] + [0])
+            if have > f1:               # more has arrived meanwhile: take it all in one batch
+                f1 = have
+            self._wait_frames(f1)
+            yield self._piece(f0, f1)
+            f0 = f1
+        self.finish()
+
+    def finish(self):
+        """wait for the whole copy and hand it to the trajectory (``keep_on_device`` semantics)"""
+        self._wait_frames(self.n_frames)
+        p = self.packed
+        if getattr(p, "_dev_pos", None) is None and not self.complete:
+            p._dev_pos = self.dev
+            p._protect()
+        self.complete = True
+        return p
+
+    def read_all(self):
+        return self.finish()
+
+
+def resident_source(packed, device, allow=True):
+    """What an analysis walks: the trajectory itself (resident already, a stream, no GPU for a copy, a multi-rank run) or its
+    ``ResidentCopy`` in the making (a host trajectory's first analyses)."""
+    if not allow or getattr(packed, "is_stream", False) or packed.on_device or getattr(packed, "_dev_pos", None) is not None:
+        return packed
+    rc = getattr(packed, "_resident", None)
+    if rc is not None:
+        if rc.complete:
+            return packed
+        return rc if rc.device == int(device) else packed
+    torch = _gpu_for_uploads(device)
+    if torch is None or packed.n_frames == 0 or packed.n_atoms == 0:
+        return packed
+    need = packed.n_frames * packed.n_atoms * 24
+    try:
+        free, _total = torch.cuda.mem_get_info(int(device))
+    except Exception:
+        return packed
+    if need < (32 << 20) or 2 * need + (4 << 30) > free:       # (small: not worth a thread; huge: staged per call as before)
+        return packed
+    packed._resident = ResidentCopy(packed, device, torch, pinned_source=getattr(packed, "_pinned", None) is not None)
+    return packed._resident
+
+
+# the lists packed last: a caller that hands the SAME list of frames to several analyses (the reference's documented use,
+# examples/Compute structural properties.py:58-118) packs and uploads it once.  A list is recognised by identity, length and
+# the identity of its frames, and is trusted only when a checksum of EVERY frame's bytes (amof_frames_checksum: memory
+# speed, all cores) equals the one taken when it was packed -- positions edited in place give a new pack.
+_PACKED_LISTS = []
+_PACKED_KEEP = 2
+
+
+def _frame_pointers(frames, n):
+    """(uint64 pointer array, keep-alive list): every frame's positions as a C-contiguous float64 [n][3] block"""
+    ptrs = np.empty(len(frames), dtype=np.uint64)
+    keep = []
+    for k, atoms in enumerate(frames):
+        p = getattr(atoms, "positions", None)
+        if p is None:
+            p = atoms.get_positions()
+        if not (isinstance(p, np.ndarray) and p.dtype == np.float64 and p.flags.c_contiguous):
+            p = np.ascontiguousarray(p, dtype=np.float64)
+        if p.shape != (n, 3):
+            raise ValueError("frame %d has %d atoms, frame 0 has %d" % (k, len(p), n))
+        keep.append(p)
+        ptrs[k] = p.__array_interface__["data"][0]
+    return ptrs, keep
+
+
+def pack_trajectory(trajectory, device=None):
     """Pack a list of ``ase.Atoms``-like frames into a :class:`PackedTrajectory`.
 
     Accepts a :class:`PackedTrajectory` unchanged.  Every frame must hold the
     same atoms in the same order (the reference assumes it: species are read
     from frame 0 only, amof/rdf.py:71, amof/cn.py:52, amof/msd.py:215).
+
+    ``device`` (what the analysis classes pass): the GPU the frames are headed for.  The copy of the frames into the packed
+    array (native, all cores: ``amof_pack_frames``) then goes into page-locked memory in batches, and every batch is on its
+    way to the device while the next one is packed (``ResidentCopy``); the list is remembered, so the next analysis of
+    the same, unchanged list reuses pack and upload.
     """
     if isinstance(trajectory, PackedTrajectory) or getattr(trajectory, "is_stream", False):
         return trajectory                   # (an amof_amd.stream.XyzStream: the classes walk it batch by batch)
-    frames = list(trajectory)
+    frames = trajectory if isinstance(trajectory, list) else list(trajectory)
     if len(frames) == 0:
         raise ValueError("empty trajectory")
     first = frames[0]
     numbers = np.array(first.get_atomic_numbers(), dtype=np.int64)
     n = len(numbers)
-    pos = np.empty((len(frames), n, 3), dtype=np.float64)
-    cell = np.empty((len(frames), 3, 3), dtype=np.float64)
-
-    def copy_range(k0, k1):
-        for k in range(k0, k1):
-            atoms = frames[k]
-            # ``atoms.positions`` is a view in ASE (and here): one copy, straight into the packed array
+    F = len(frames)
+    lib = None
+    if F * n * 24 >= (8 << 20):
+        try:
+            from . import _hip
+            lib = _hip.load_library()
+        except Exception:
+            lib = None
+    if lib is None:
+        # small trajectories (or no library): the plain loop
+        pos = np.empty((F, n, 3), dtype=np.float64)
+        for k, atoms in enumerate(frames):
             p = getattr(atoms, "positions", None)
             if p is None:
                 p = atoms.get_positions()
             if len(p) != n:
                 raise ValueError("frame %d has %d atoms, frame 0 has %d" % (k, len(p), n))
             pos[k] = p
-            c = getattr(atoms, "cell", None)
-            cell[k] = np.asarray(c if c is not None else atoms.get_cell(), dtype=np.float64).reshape(3, 3)
+        return PackedTrajectory(pos, _cells_of(frames), numbers, np.array(first.get_masses(), dtype=np.float64), _pbc_of(first))
+    import ctypes
+    threads = _usable_cpus()
+    # the same list, unchanged?  (cheap identities first: the list, its frames, their position arrays; then the bytes)
+    ids = np.fromiter(map(id, frames), dtype=np.int64, count=F)
+    for entry in _PACKED_LISTS:
+        if entry["list_id"] == id(trajectory) and entry["n"] == n and np.array_equal(entry["ids"], ids):
+            pids = np.fromiter((id(getattr(f, "positions", None)) for f in frames), dtype=np.int64, count=F)
+            if not np.array_equal(pids, entry["pids"]):
+                continue
+            sums = np.empty(F, dtype=np.uint64)
+            rc = lib.amof_frames_checksum(ctypes.c_void_p(entry["ptrs"].ctypes.data), F, n, ctypes.c_void_p(sums.ctypes.data), threads)
+            if rc == 0 and np.array_equal(sums, entry["sums"]) and np.array_equal(_cells_of(frames), entry["packed"].cell):
+                return entry["packed"]
+    ptrs, keep = _frame_pointers(frames, n)
+    pids = np.fromiter((id(getattr(f, "positions", None)) for f in frames), dtype=np.int64, count=F)
+    torch = _gpu_for_uploads(device)
+    pinned = None
+    if torch is not None:
+        try:
+            free, _total = torch.cuda.mem_get_info(int(device))
+            if 2 * F * n * 24 + (4 << 30) > free:
+                torch = None
+            else:
+                pinned = torch.empty((F, n, 3), dtype=torch.float64, pin_memory=True)
+        except Exception:
+            torch, pinned = None, None
+    pos = pinned.numpy() if pinned is not None else np.empty((F, n, 3), dtype=np.float64)
+    packed = PackedTrajectory(pos, _cells_of(frames), numbers, np.array(first.get_masses(), dtype=np.float64), _pbc_of(first))
+    sums = np.empty(F, dtype=np.uint64)
+    rcopy = None
+    if pinned is not None:
+        packed._pinned = pinned             # (keeps the page-locked allocation alive)
+        rcopy = ResidentCopy(packed, device, torch, pinned_source=True, defer=True)
+    step = rcopy.chunk if rcopy is not None else F
+    for f0 in range(0, F, step):
+        f1 = min(F, f0 + step)
+        rc = lib.amof_pack_frames(ctypes.c_void_p(ptrs[f0:].ctypes.data), f1 - f0, n, ctypes.c_void_p(pos[f0:].ctypes.data),
+                                  ctypes.c_void_p(sums[f0:].ctypes.data), threads)
+        if rc != 0:
+            raise RuntimeError("amof_pack_frames failed (%d)" % rc)
+        if rcopy is not None:
+            rcopy.push(f0, f1)              # on its way while the next batch is packed
+    if rcopy is not None:
+        packed._resident = rcopy
+    # (`keep` stays with the entry: the pointers remain valid while the frames keep their position arrays, which `pids` checks)
+    _PACKED_LISTS.insert(0, {"list_id": id(trajectory), "n": n, "ids": ids, "pids": pids, "ptrs": ptrs, "keep": keep, "sums": sums,
+                             "packed": packed})
+    del _PACKED_LISTS[_PACKED_KEEP:]
+    return packed
 
-    # big trajectories: the frame copies (numpy releases the GIL for them) on a few threads -- a 9792-atom x 5000-frame
-    # list is 1.2 GB of memcpy, which one thread moves in ~0.13 s, more than the analysis of the whole trajectory takes
-    nbytes = pos.nbytes
-    workers = min(8, _usable_cpus(), len(frames) // 64) if nbytes >= (64 << 20) else 1
-    if workers > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        step = (len(frames) + workers - 1) // workers
-        with ThreadPoolExecutor(workers) as ex:
-            list(ex.map(lambda w: copy_range(w * step, min((w + 1) * step, len(frames))), range(workers)))
-    else:
-        copy_range(0, len(frames))
+
+def forget_packed_lists():
+    """drop the remembered packs (and with them their page-locked arrays and device copies)"""
+    del _PACKED_LISTS[:]
+
+
+def _cells_of(frames):
+    def rows(atoms):
+        c = getattr(atoms, "cell", None)
+        if c is None:
+            c = atoms.get_cell()
+        return getattr(c, "array", c)          # (ase.cell.Cell keeps its 3 x 3 array in .array)
+    cell = np.array([rows(a) for a in frames], dtype=np.float64).reshape(len(frames), 3, 3)
     if (cell == cell[0]).all():
         cell = cell[:1].copy()
+    return cell
+
+
+def _pbc_of(first):
     pbc = np.array(getattr(first, "pbc", (True, True, True)), dtype=bool)
     if pbc.shape == ():
         pbc = np.array([bool(pbc)] * 3)
-    return PackedTrajectory(pos, cell, numbers, np.array(first.get_masses(), dtype=np.float64), pbc)
+    return pbc

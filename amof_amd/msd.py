@@ -22,7 +22,7 @@ from . import _hip
 from . import data as _data
 from . import dist as _dist
 from .files import path as _path
-from .frames import pack_trajectory, PackedTrajectory
+from .frames import pack_trajectory, resident_source, PackedTrajectory
 
 logger = logging.getLogger(__name__)
 
@@ -144,7 +144,7 @@ class WindowMsd(Msd, Deferred):
 
     def compute_msd(self, trajectory, window, time, parallel=False, unwrap=False, device=None, distributed=None):
         """compute the window MSD (reference amof/msd.py:207-268)"""
-        packed = pack_trajectory(trajectory)
+        packed = pack_trajectory(trajectory, device=device if device is not None else _hip.default_device())
         if getattr(packed, "is_stream", False):
             packed = packed.read_all()      # a window couples frames half a trajectory apart: nothing to stream
         elements = packed.unique_numbers()
@@ -181,8 +181,14 @@ class WindowMsd(Msd, Deferred):
                 ctx.msd_com(packed, _dist.shard_range(F, rank, world), com)
                 _dist.all_reduce_sum(com)
 
+        # (a host trajectory: its one device copy -- started by whichever analysis came first -- must be complete: the wait is
+        #  part of the lane job)
+        source = resident_source(packed, ctx.device, allow=not merge and hasattr(ctx, "submit"))
+
         def local():
             # this rank's kernels (a lane job: amof_amd/_lazy.py)
+            if getattr(source, "is_stream", False):
+                source.read_all()
             if on_device:
                 # the S x W sums stay in HBM from the kernels through their all-reduce
                 import torch

@@ -20,7 +20,7 @@ from . import _hip
 from . import data as _data
 from . import dist as _dist
 from .files import path as _path
-from .frames import pack_trajectory
+from .frames import pack_trajectory, resident_source
 
 logger = logging.getLogger(__name__)
 
@@ -107,13 +107,15 @@ class Rdf(Deferred):
 
     def compute_rdf(self, trajectory, dr, rmax, device=None, distributed=None):
         """compute rdf from a trajectory (reference amof/rdf.py:67-114)"""
-        packed = pack_trajectory(trajectory)
+        packed = pack_trajectory(trajectory, device=device if device is not None else _hip.default_device())
         atomic_numbers_unique = packed.unique_numbers()
         N_species = len(atomic_numbers_unique)
         rank, world = (0, 1) if distributed is False else _dist.world()
         merge = distributed is not False and _dist.merging(world)
         dev = device if device is not None else getattr(packed, "device_index", None)
         ctx = _hip.lane_context(dev, 0)
+        # a host trajectory gets ONE device copy, uploaded while its first analyses walk the part that has arrived
+        source = resident_source(packed, ctx.device, allow=not merge and hasattr(ctx, "submit"))
 
         # min over ALL frames of the three cell lengths, halved (amof/rdf.py:74)
         rmax_half_cell = np.min(packed.cell_lengths()) / 2
@@ -134,19 +136,24 @@ class Rdf(Deferred):
             raise ValueError("rmax // dr gives no bin")
 
         F_local = len(packed)
-        if getattr(packed, "is_stream", False):
-            # frames are independent: the integer counts of the batches add up (the parse of the next batch runs in the
-            # stream's background thread while this one is on the GPU)
+        if getattr(source, "is_stream", False):
+            # frames are independent: the integer counts of the batches add up (a file stream parses its next batch in a
+            # background thread, a host trajectory's next frames are on their way over PCIe, while this one is on the GPU)
             if merge:
                 raise ValueError("a streamed trajectory is analysed by one process (distributed=False)")
-            hist, vol_sum, kinds = None, 0.0, None
-            for batch in packed.batches():
-                h, v, kinds = ctx.rdf_accumulate(batch, rmax, bins)
-                hist = h if hist is None else hist + h
-                vol_sum += v
-            if packed.cell is not None:
-                vol_sum = packed.volume_sum()      # (the library's own left-to-right sum: identical to the unstreamed result)
-            self._finish(packed, hist, vol_sum, F_local, kinds, atomic_numbers_unique, rmax, bins, r)
+
+            def walk():
+                hist, vol_sum, kinds = None, 0.0, None
+                for batch in source.batches():
+                    h, v, kinds = ctx.rdf_accumulate(batch, rmax, bins)
+                    hist = h if hist is None else hist + h
+                    vol_sum += v
+                if source.cell is not None:
+                    vol_sum = source.volume_sum()      # (the library's own left-to-right sum: identical to the unstreamed result)
+                return hist, vol_sum, kinds
+
+            self._defer(ctx, walk, lambda raw: self._finish(packed, raw[0], raw[1], F_local, raw[2], atomic_numbers_unique,
+                                                            rmax, bins, r))
             return
         if merge and distributed != 'local':
             frame_range = _dist.shard_range(F_local, rank, world)

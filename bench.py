@@ -469,6 +469,86 @@ def realistic_cells(device, local_rank, ctx, head, do_verify=True, frames=400):
     return out
 
 
+def host_legs(packed, rdf, msd, local_rank, F, N):
+    """Supplementary (never `value`): the same analyses from HOST input, i.e. what a caller of the reference's API pays
+    before the kernels see a byte (amof/trajectory.py:27-35: a trajectory IS a list of Atoms).
+
+    * host_resident: Rdf + WindowMsd on a packed host trajectory (numpy).  Round 5: ONE upload, started by the first analysis,
+      which walks the frames that have arrived (amof_amd.frames.ResidentCopy); round 4 staged 1.2 GB per class.
+    * pack_atoms_list: a list of 5000 frames -> packed array (native copy on all cores, amof_pack_frames), no GPU involved.
+    * dropin_from_atoms_list: the list of 5000 frames handed to Rdf, WindowMsd, Bad and cn.CoordinationNumber one after the
+      other, as in the reference's example script (examples/Compute structural properties.py:58-118): packed once into
+      page-locked memory, uploaded once while it is packed, remembered for the three later constructors (a checksum of every
+      frame says the list is unchanged); every result compared with the device-resident step's."""
+    import torch
+    from amof_amd.rdf import Rdf
+    from amof_amd.msd import WindowMsd
+    from amof_amd.bad import Bad
+    from amof_amd.cn import CoordinationNumber
+    from amof_amd import frames as fr
+    out = {}
+    pos_host = packed.pos.cpu().numpy()
+    best = None
+    for rep in range(3):
+        host = fr.PackedTrajectory(pos_host, packed.cell, packed.numbers)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a_ = Rdf.from_trajectory(host, device=local_rank, distributed=False)
+        b_ = WindowMsd.from_trajectory(host, delta_time=100, timestep=1, device=local_rank, distributed=False)
+        a_.result(), b_.result()
+        w = time.perf_counter() - t0
+        best = w if best is None or w < best else best
+        same = bool(np.array_equal(np.asarray(a_.hist), np.asarray(rdf.hist)))
+        host.release_device()
+        del host, a_, b_
+    out["host_resident_frames_per_s"] = F / best
+    out["host_resident"] = {"wall_s": best, "verified": same,
+                            "what": "Rdf + WindowMsd on a host PackedTrajectory (pageable numpy): one upload through page-locked "
+                                    "staging, the RDF walks the frames as they arrive"}
+    frames = [fr.Frame(packed.numbers, pos_host[k], packed.cell_of(k)) for k in range(F)]
+    del pos_host
+    best = None
+    for rep in range(3):
+        fr.forget_packed_lists()
+        t0 = time.perf_counter()
+        fr.pack_trajectory(frames)
+        w = time.perf_counter() - t0
+        best = w if best is None or w < best else best
+    out["pack_atoms_list_frames_per_s"] = F / best
+    out["pack_atoms_list"] = {"wall_s": best, "frames": F, "threads": fr._usable_cpus(),
+                              "what": "list of %d frames -> packed host array (amof_pack_frames), no GPU" % F}
+    best, first = None, None
+    for rep in range(3):
+        fr.forget_packed_lists()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r_ = Rdf.from_trajectory(frames, device=local_rank, distributed=False)
+        m_ = WindowMsd.from_trajectory(frames, delta_time=100, timestep=1, device=local_rank, distributed=False)
+        b_ = Bad.from_trajectory(frames, {'Zn-N': 2.5}, dtheta=0.05, device=local_rank, distributed=False)
+        c_ = CoordinationNumber.from_trajectory(frames, {'Zn-N': 2.5}, device=local_rank, distributed=False)
+        t1 = time.perf_counter()
+        n_ = len(r_.data) + len(m_.data) + len(b_.data) + len(c_.data)
+        w = time.perf_counter() - t0
+        first = w if first is None else first
+        if best is None or w < best:
+            best, t_ctor = w, t1 - t0
+    ok_r = bool(np.array_equal(np.asarray(r_.hist), np.asarray(rdf.hist)) and r_.data.equals(rdf.data))
+    ok_m = bool(np.allclose(m_.sumsq, msd.sumsq, rtol=1e-12, atol=0.0))
+    b_ref = Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.05, device=local_rank, distributed=False)
+    c_ref = CoordinationNumber.from_trajectory(packed, {'Zn-N': 2.5}, device=local_rank, distributed=False)
+    ok_b = bool(np.array_equal(np.asarray(b_.hist), np.asarray(b_ref.hist)) and b_.data.equals(b_ref.data))
+    ok_c = bool(c_.data.equals(c_ref.data))
+    out["dropin_from_atoms_list"] = {
+        "workload": "list of %d Frame objects (%d atoms) -> Rdf + WindowMsd + Bad({'Zn-N': 2.5}) + CoordinationNumber({'Zn-N': 2.5}), "
+                    "every .data read" % (F, N),
+        "wall_s": best, "first_call_s": first, "constructors_returned_after_s": t_ctor, "frames_per_s": F / best,
+        "verified": bool(ok_r and ok_m and ok_b and ok_c),
+        "verification": {"rdf_equals_device_resident": ok_r, "msd": ok_m, "bad": ok_b, "cn": ok_c, "rows": n_}}
+    fr.forget_packed_lists()
+    del frames
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -788,26 +868,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(packed, rmax, nbins, window, args.cpu_rdf_frames)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
             out["speedup_vs_cpu_1core"] = fps / out["cpu_baseline"]["value"]
-            # supplementary (never `value`): the same step from a host-resident packed trajectory, i.e. including
-            # the 24*N*F-byte PCIe staging of both passes
-            from amof_amd.frames import PackedTrajectory
-            host = PackedTrajectory(packed.pos.cpu().numpy(), packed.cell, packed.numbers)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            a_ = Rdf.from_trajectory(host, device=local_rank, distributed=False)
-            b_ = WindowMsd.from_trajectory(host, delta_time=100, timestep=1, device=local_rank, distributed=False)
-            a_.result(), b_.result()
-            torch.cuda.synchronize()
-            out["host_resident_frames_per_s"] = F / (time.perf_counter() - t0)
-            # supplementary: packing a list of ase.Atoms-like frames into the arrays above (pure Python + memcpy,
-            # identical for a CPU and a GPU path; SURVEY 8d asks for it separately)
-            from amof_amd.frames import Frame, pack_trajectory
-            nfr = min(F, 600)                # (>= 64 MB: the threaded copy path of pack_trajectory)
-            frames = [Frame(host.numbers, host.pos[k], host.cell_of(k)) for k in range(nfr)]
-            t0 = time.perf_counter()
-            pack_trajectory(frames)
-            out["pack_atoms_list_frames_per_s"] = nfr / (time.perf_counter() - t0)
-            del host, frames
+            try:
+                out.update(host_legs(packed, rdf, msd, local_rank, F, N))
+            except Exception as exc:
+                out["host_legs_error"] = repr(exc)
         if world == 1 and not args.no_extra:
             # coordination numbers on the headline trajectory (never `value`): the one kernel of the path that is HBM bound as
             # north_star pictures it -- the Zn / N rows of every frame are fetched once and searched inside LDS

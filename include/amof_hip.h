@@ -276,6 +276,19 @@ int amof_xyz_read(const char *path, int64_t first, int64_t count, int64_t step, 
 int amof_cp2k_cell_read(const char *path, int64_t max_rows, double *cell, int64_t *n_rows);
 const char *amof_ingest_last_error(void);
 
+/*
+ * Packing a list of frames (host only).
+ * Replaces the per-frame Python walk over a list of ase.Atoms (amof/trajectory.py:27-35,56-59; amof/rdf.py:88-93,
+ * amof/msd.py:218-242) for the packed path: frame_pos[k] points at frame k's positions ([N][3] float64, C-contiguous --
+ * ase.Atoms.positions); amof_pack_frames copies them into dst[F][N][3] on n_threads threads (<= 0: all hardware threads)
+ * and, when checksums != NULL, fingerprints each frame's bytes; amof_frames_checksum fingerprints without copying (is a
+ * list that was packed before still the same?).  Equal bytes give equal checksums; the hash is not cryptographic.
+ */
+int amof_pack_frames(const double *const *frame_pos, int64_t n_frames, int64_t n_atoms, double *dst, uint64_t *checksums,
+                     int32_t n_threads);
+int amof_frames_checksum(const double *const *frame_pos, int64_t n_frames, int64_t n_atoms, uint64_t *checksums,
+                         int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

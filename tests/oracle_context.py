@@ -48,6 +48,12 @@ class OracleContext(_hip.Lane):
         pos, cell = self._frames(packed, frame_range)
         return clib.bad_hist(pos, cell, sp, len(kinds), np.asarray(cutoff, dtype=np.float64), triples, np.asarray(edges))
 
+    def bad_hist_by_cn(self, packed, cutoff, triples, edges, cn_max=16, frame_range=None):
+        self.calls.append("bad_by_cn")
+        kinds, sp = _hip.packed_species(packed)
+        pos, cell = self._frames(packed, frame_range)
+        return clib.bad_hist_by_cn(pos, cell, sp, len(kinds), np.asarray(cutoff, dtype=np.float64), triples, np.asarray(edges), cn_max)
+
     def msd_window(self, packed, windows, unwrap=False, remove_com=True, atom_range=None, com=None, out=None):
         assert com is None and out is None and remove_com
         self.calls.append("msd")

@@ -126,6 +126,40 @@ def test_input_produced_by_pending_torch_kernels(hip_ctx):
         del b
 
 
+def test_rdf_at_the_bench_launch_shape_through_the_class(hip_ctx):
+    """The bench's own launch shape -- 2560 frames x 9792 atoms, 16 frames per chunk (the default: no AMOF_RDF_FPC), one
+    tile-kernel launch, through Rdf.from_trajectory -- tied to the oracle by leave-one-out on seven frames spread over the
+    launch (first / last frame of a chunk, chunk interiors, first and last frame of the trajectory):
+    H[0,F) - H[0,k) - H[k+1,F) is frame k's histogram as the big launch counted it."""
+    import torch
+    from oracle import clib
+    from amof_amd.rdf import Rdf
+    assert "AMOF_RDF_FPC" not in os.environ
+    F = 2560
+    packed = H.device_walk(torch.device("cuda", 0), REPS, F, 0.05, 20261003)
+    torch.cuda.synchronize()
+    rdf = Rdf.from_trajectory(packed)
+    nb = len(rdf.data)
+    assert (nb, packed.n_atoms) == (2310, 9792)
+    assert rdf._stats["path"] == "rdf_tile_zf" and rdf._stats["kernel_launches"] == 1
+    kinds, sp = H.species_of(packed.numbers)
+    full = np.asarray(rdf.hist)
+    sample = [0, 15, 16, 1277, 1296, 2047, F - 1]
+    pos_s = _host_frames(packed, sample)
+    for q, k in enumerate(sample):
+        h_cpu, _ = clib.rdf_hist(pos_s[q:q + 1], packed.cell, sp, len(kinds), rdf.rmax, nb, cell_list=True)
+        rest = np.zeros_like(full)
+        for a, b in ((0, k), (k + 1, F)):
+            if b > a:
+                rest += hip_ctx.rdf_accumulate(packed, rdf.rmax, nb, frame_range=(a, b))[0]
+        assert np.array_equal(full - rest, h_cpu), k
+    # and the DataFrame is the normalisation of exactly these counts
+    from amof_amd.rdf import normalize_rdf
+    want = normalize_rdf(full.sum(axis=(0, 1)), F * packed.n_atoms, packed.n_atoms, abs(np.linalg.det(packed.cell[0])), rdf.rmax, nb)
+    np.testing.assert_allclose(rdf.data["X-X"].values, want, rtol=1e-13)
+    del packed
+
+
 def test_context_refuses_positions_of_another_device(hip_ctx):
     class FakeCtx(object):
         device = 3

@@ -941,6 +941,28 @@ def test_rdf_triangular_frame_kernel(hip_ctx, kind, jitter):
     assert np.array_equal(big, ref)
 
 
+@pytest.mark.parametrize("cell,rmax", [(((5.0, 0, 0), (20.0, 7.0, 0), (0, 0, 30.0)), 2.4),       # the advisor's cell: |L10| = 4 L00
+                                       (((6.0, 0, 0), (5.5, 6.5, 0), (0, 0, 28.0)), 2.9),        # |L10| ~ 0.92 L00
+                                       (((9.0, 0, 0), (-8.0, 9.5, 0), (1.0, 2.0, 31.0)), 4.4)])  # negative, with a sheared slab axis
+def test_rdf_skewed_non_reduced_cells_do_not_take_the_integer_x_wrap(hip_ctx, cell, rmax):
+    """Cells whose second vector leans over the first by about its length or more (not Niggli-reduced: nothing in the
+    reference asks for reduced cells).  The triangular-frame variants that wrap x in the integer domain form (int)(fy * c10),
+    which saturates beyond 2^31 once |c10| (R / L11) >= 1/2: selection must refuse them there (advisor, round 4) and
+    whatever kernel answers must equal the oracle."""
+    rng = np.random.default_rng(5)
+    cell = np.array(cell, dtype=float)
+    n = 700
+    pos = rng.uniform(0, 1, (3, n, 3)) @ cell
+    packed = PackedTrajectory(pos, cell, [1, 8] * (n // 2))
+    kinds, sp = H.species_of(packed.numbers)
+    for nb in (240, 997):
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
+        for env in ({}, {"AMOF_RDF_NOCELL": "1", "AMOF_RDF_NORANGE": "1"}, {"AMOF_RDF_NOCELL": "1", "AMOF_RDF_NORANGE": "1", "AMOF_RDF_NOCULL": "1"}):
+            with _env(**env):
+                got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert np.array_equal(got, ref), (env, hip_ctx.last_path(), int(np.abs(got.astype(np.int64) - ref.astype(np.int64)).sum()))
+
+
 def test_rdf_triangular_frame_lattice_on_faces_and_edges(hip_ctx):
     """an integer lattice in integer sheared cells: every distance on a bin edge, pairs exactly on cell faces (both images
     at the same distance) -- every in-range pair goes through the queue of the canonical pass, which overflows into the
