@@ -230,6 +230,7 @@ def _locked(method):
 
 
 AMOF_CTX_HIGH_PRIORITY = 1
+AMOF_CTX_LOW_PRIORITY = 2
 
 _tls = threading.local()      # .producer_stream: the stream a lane job orders itself after (see Lane.submit)
 
@@ -295,19 +296,23 @@ class Context(Lane):
     (``get_context``): lane 0 for the pair-evaluation-bound RDF, lane 1 -- a stream of the highest priority -- for the
     memory-bound MSD / BAD / CN, whose kernels and host work then run beside an RDF launch instead of behind it."""
 
-    def __init__(self, device=0, high_priority=False):
+    def __init__(self, device=0, high_priority=False, priority=None):
         self._lib = load_library()
         n = self._lib.amof_device_count()
         if n <= 0:
             raise RuntimeError("amof_amd: no GPU visible to HIP; the MI355X kernels cannot run "
                                "(there is no CPU fallback)")
         h = ctypes.c_void_p()
-        rc = self._lib.amof_ctx_create2(int(device), AMOF_CTX_HIGH_PRIORITY if high_priority else 0, ctypes.byref(h))
+        if priority is None:
+            priority = "high" if high_priority else "normal"
+        flags = {"high": AMOF_CTX_HIGH_PRIORITY, "low": AMOF_CTX_LOW_PRIORITY, "normal": 0}[priority]
+        rc = self._lib.amof_ctx_create2(int(device), flags, ctypes.byref(h))
         if rc != AMOF_OK:
             raise AmofError(rc, "amof_ctx_create2(device=%d) failed" % device)
         self._h = h
         self.device = int(device)
-        self.high_priority = bool(high_priority)
+        self.priority = priority
+        self.high_priority = priority == "high"
         self._lane_name = "amof-lane-%d%s" % (self.device, "h" if high_priority else "")
         self._lock = threading.RLock()
 
@@ -719,7 +724,7 @@ def get_context(device=None, lane=0):
     with _ctx_lock:
         ctx = _contexts.get(key)
         if ctx is None:
-            ctx = Context(device, high_priority=bool(lane))
+            ctx = Context(device, priority=os.environ.get("AMOF_LANE1_PRIORITY", "high") if lane else "normal")
             _contexts[key] = ctx
         return ctx
 

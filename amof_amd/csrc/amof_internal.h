@@ -68,6 +68,9 @@ struct amof_ctx {
     // synchronisation still reads it.
     unsigned char *pin = nullptr;
     size_t pin_cap = 0, pin_off = 0;
+    // page-locked landing area for what the library reads back (flags, result tables): see fetch()
+    unsigned char *rb = nullptr;
+    size_t rb_cap = 0;
     // amof_msd_shard_begin leaves scratch for amof_msd_shard_finish: valid while no other call ran on the context
     int64_t calls = 0;            // entry points that started device work (timing_begin)
     int64_t shard_ticket = 0;     // `calls` right after a begin; 0 = none pending
@@ -215,6 +218,10 @@ struct Stager {
 int stager_begin(amof_ctx *ctx, const amof_traj *t, bool allow_lazy, Stager &st);
 int stager_need(Stager &st, int64_t f1);
 int upload(amof_ctx *ctx, Slot s, const void *src, size_t bytes, void **out);
+// Device -> host of a flag word or a result table, complete on return (the stream is synchronised).  Through page-locked
+// memory: with a pageable destination -- a stack variable, the caller's numpy array -- the runtime pins or stages on the
+// fly, and the 4-byte flag read after the RDF launch showed as a 0.36 ms copy in the round-5 trace of bench.py.
+int fetch(amof_ctx *ctx, void *dst, const void *src_dev, size_t bytes);
 
 // Several small tables in ONE device buffer with ONE host-to-device copy: however small, a copy costs ~5 us of queue time and
 // a dozen of them in front of a 0.25 ms kernel were a third of a call.  add() the pieces, upload_pack(), then ptr<T>(i).

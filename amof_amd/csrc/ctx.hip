@@ -70,6 +70,20 @@ int upload(amof_ctx *ctx, Slot s, const void *src, size_t bytes, void **out)
     return AMOF_OK;
 }
 
+int fetch(amof_ctx *ctx, void *dst, const void *src_dev, size_t bytes)
+{
+    if (!bytes) return AMOF_OK;
+    if (ctx->rb && bytes <= ctx->rb_cap) {
+        AMOF_HIP_TRY(ctx, hipMemcpyAsync(ctx->rb, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_HIP_TRY(ctx, sync_stream(ctx));
+        memcpy(dst, ctx->rb, bytes);
+        return AMOF_OK;
+    }
+    AMOF_HIP_TRY(ctx, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_HIP_TRY(ctx, sync_stream(ctx));
+    return AMOF_OK;
+}
+
 int upload_pack(amof_ctx *ctx, Slot s, UploadPack &pk)
 {
     AMOF_TRY(ensure(ctx, s, pk.total, &pk.base));
@@ -351,10 +365,10 @@ int amof_ctx_create2(int device, int flags, amof_ctx **out)
     if (!ctx) return AMOF_ENOMEM;
     ctx->device = device;
     hipError_t se;
-    if (flags & AMOF_CTX_HIGH_PRIORITY) {
+    if (flags & (AMOF_CTX_HIGH_PRIORITY | AMOF_CTX_LOW_PRIORITY)) {
         int least = 0, greatest = 0;      // (numerically lowest = highest priority)
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-        se = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, greatest);
+        se = hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, (flags & AMOF_CTX_HIGH_PRIORITY) ? greatest : least);
     } else {
         se = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     }
@@ -374,6 +388,12 @@ int amof_ctx_create2(int device, int flags, amof_ctx **out)
     if (hipHostMalloc((void **)&ctx->pin, ctx->pin_cap, hipHostMallocDefault) != hipSuccess) {
         ctx->pin = nullptr;
         ctx->pin_cap = 0;
+        (void)hipGetLastError();
+    }
+    ctx->rb_cap = (size_t)1 << 20;
+    if (hipHostMalloc((void **)&ctx->rb, ctx->rb_cap, hipHostMallocDefault) != hipSuccess) {
+        ctx->rb = nullptr;
+        ctx->rb_cap = 0;
         (void)hipGetLastError();
     }
     if (hipEventCreate(&ctx->ev_all0) != hipSuccess || hipEventCreate(&ctx->ev_all1) != hipSuccess ||
@@ -400,6 +420,7 @@ void amof_ctx_destroy(amof_ctx *ctx)
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->rb) (void)hipHostFree(ctx->rb);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -1826,7 +1826,7 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
                              (double *)d_com, &d_RS));
         AMOF_TRY(fused_pass2(ctx, t, pos_dev, (const double *)d_geom, atom_begin, fd, (int)W, (const double *)d_com, total_mass, d_RS,
                              (const int32_t *)d_perm, (const int32_t *)d_sfa, (double *)d_out, &d_flag));
-        AMOF_HIP_TRY(ctx, hipMemcpyAsync(&evt, d_flag, sizeof evt, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_TRY(fetch(ctx, &evt, d_flag, sizeof evt));
         AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (not sync_stream: the staged tables stay where they are)
         done = evt == 0;       // else: an entry could wrap again under the centre-of-mass step -- the transposed forms answer
     }
@@ -2026,7 +2026,7 @@ static int msd_window_run(amof_ctx *ctx, const amof_traj *t, const int32_t *wind
     }
     timing_end(ctx);
     if (sumsq)
-        AMOF_HIP_TRY(ctx, hipMemcpyAsync(sumsq, d_out, (size_t)S * W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_TRY(fetch(ctx, sumsq, d_out, (size_t)S * W * sizeof(double)));
     AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
@@ -2184,7 +2184,7 @@ extern "C" int amof_msd_shard_finish(amof_ctx *ctx, const amof_traj *t, const in
     int32_t *d_flag = nullptr, evt = 0;
     AMOF_TRY(fused_pass2(ctx, t, t->pos, st.d_geom, a0, fd, (int)W, csum_dev, st.total_mass, (double *)d_RS, st.d_perm, st.d_sp_first,
                          (double *)d_out, &d_flag));
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(&evt, d_flag, sizeof evt, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_TRY(fetch(ctx, &evt, d_flag, sizeof evt));
     AMOF_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (evt) {
         // an entry could wrap again under the centre-of-mass step: the transposed forms with the completed centre of mass
@@ -2274,7 +2274,7 @@ extern "C" int amof_msd_direct(amof_ctx *ctx, const amof_traj *t, double *msd)
                        (const int32_t *)d_perm, (const int64_t *)d_spf, S, N, (double *)d_out);
     AMOF_HIP_TRY(ctx, hipGetLastError());
     timing_end(ctx);
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(msd, d_out, (size_t)F * (S + 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_TRY(fetch(ctx, msd, d_out, (size_t)F * (S + 1) * sizeof(double)));
     AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }

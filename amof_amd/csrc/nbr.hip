@@ -2321,7 +2321,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
             }
             timing_dom_end(ctx, launches);
             int32_t qflag = 0;
-            AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nw.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
+            AMOF_TRY(fetch(ctx, &qflag, nw.d_qflag, sizeof qflag));
             AMOF_HIP_TRY(ctx, sync_stream(ctx));
             if (qflag) {    // atoms absurdly far from the cell: the exact kernel answers (via the fast path's own check)
                 AMOF_HIP_TRY(ctx, hipMemsetAsync(d_sums, 0, F * n_sets * sizeof(int64_t), ctx->stream));
@@ -2368,7 +2368,7 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         }
         timing_dom_end(ctx, launches);
         int32_t qflag = 0;
-        AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nf.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_TRY(fetch(ctx, &qflag, nf.d_qflag, sizeof qflag));
         AMOF_HIP_TRY(ctx, sync_stream(ctx));
         if (qflag) {   // atoms absurdly far from the cell: redo with the exact kernel
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_sums, 0, F * n_sets * sizeof(int64_t), ctx->stream));
@@ -2394,9 +2394,9 @@ extern "C" int amof_cn_count(amof_ctx *ctx, const amof_traj *t, const double *cu
         timing_dom_end(ctx, 1);
     }
     timing_end(ctx);
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(sums, d_sums, F * n_sets * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_TRY(fetch(ctx, sums, d_sums, F * n_sets * sizeof(int64_t)));
     if (per_atom)
-        AMOF_HIP_TRY(ctx, hipMemcpyAsync(per_atom, d_pa, F * n_sets * N * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_TRY(fetch(ctx, per_atom, d_pa, F * n_sets * N * sizeof(int32_t)));
     AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
@@ -2447,7 +2447,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
     a.hist = (unsigned long long *)d_hs;
     a.n_angles = (unsigned long long *)d_ns;
     auto read_flags = [&](int32_t (&fl)[4]) -> int {
-        AMOF_HIP_TRY(ctx, hipMemcpyAsync(fl, d_flags, sizeof fl, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_TRY(fetch(ctx, fl, d_flags, sizeof fl));
         AMOF_HIP_TRY(ctx, sync_stream(ctx));
         return AMOF_OK;
     };
@@ -2704,7 +2704,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
             }
 #endif
             int32_t qflag = 0;
-            AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nw.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
+            AMOF_TRY(fetch(ctx, &qflag, nw.d_qflag, sizeof qflag));
             AMOF_TRY(read_flags(flags));
             if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
             if (qflag || flags[1]) {
@@ -2836,7 +2836,7 @@ static int bad_run(amof_ctx *ctx, const amof_traj *t, const double *cutoff, cons
         }
         timing_dom_end(ctx, launches);
         int32_t qflag = 0;
-        AMOF_HIP_TRY(ctx, hipMemcpyAsync(&qflag, nf.d_qflag, sizeof qflag, hipMemcpyDeviceToHost, ctx->stream));
+        AMOF_TRY(fetch(ctx, &qflag, nf.d_qflag, sizeof qflag));
         AMOF_TRY(read_flags(flags));
         if (flags[0]) return fail(ctx, AMOF_EANGLE, "Undefined angle");
         if (qflag) {           // atoms absurdly far from the cell: redo with the exact kernel
@@ -2965,8 +2965,8 @@ extern "C" int amof_bad_hist(amof_ctx *ctx, const amof_traj *t, const double *cu
     AMOF_TRY(upload(ctx, SLOT_OUT1, n_angles, nbts, &d_nang));
     int rc = bad_run(ctx, t, cutoff, triples, T, edges, nb, (unsigned long long *)d_hist, (unsigned long long *)d_nang);
     if (rc) return rc;
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, hb, hipMemcpyDeviceToHost, ctx->stream));
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(n_angles, d_nang, nbts, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_TRY(fetch(ctx, hist, d_hist, hb));
+    AMOF_TRY(fetch(ctx, n_angles, d_nang, nbts));
     AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }
@@ -2987,8 +2987,8 @@ extern "C" int amof_bad_hist_by_cn(amof_ctx *ctx, const amof_traj *t, const doub
     AMOF_TRY(upload(ctx, SLOT_OUT1, n_angles, nbts, &d_nang));
     int rc = bad_run(ctx, t, cutoff, triples, T, edges, nb, (unsigned long long *)d_hist, (unsigned long long *)d_nang, cn_max);
     if (rc) return rc;
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, hb, hipMemcpyDeviceToHost, ctx->stream));
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(n_angles, d_nang, nbts, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_TRY(fetch(ctx, hist, d_hist, hb));
+    AMOF_TRY(fetch(ctx, n_angles, d_nang, nbts));
     AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }

@@ -1888,7 +1888,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     }
                     timing_dom_end(ctx, launches);
                     int32_t flag3 = 0;
-                    AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag3, d_flag3, sizeof flag3, hipMemcpyDeviceToHost, ctx->stream));
+                    AMOF_TRY(fetch(ctx, &flag3, d_flag3, sizeof flag3));
                     AMOF_HIP_TRY(ctx, sync_stream(ctx));
                     if (flag3) AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));   // far-away atoms: exact kernels
                     else done = true;
@@ -1989,7 +1989,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 }
                 timing_dom_end(ctx, launches);
                 int32_t flag2 = 0;
-                AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag2, d_flag2, sizeof flag2, hipMemcpyDeviceToHost, ctx->stream));
+                AMOF_TRY(fetch(ctx, &flag2, d_flag2, sizeof flag2));
                 AMOF_HIP_TRY(ctx, sync_stream(ctx));
                 if (flag2) AMOF_HIP_TRY(ctx, hipMemsetAsync(d_U, 0, U_bytes, ctx->stream));
                 else done = true;
@@ -2166,7 +2166,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             }
             timing_dom_end(ctx, launches);
             int32_t flag = 0;
-            AMOF_HIP_TRY(ctx, hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+            AMOF_TRY(fetch(ctx, &flag, d_flag, sizeof flag));
             AMOF_HIP_TRY(ctx, sync_stream(ctx));
             if (flag) {
                 // some atom lies > 1e4 cells away from the origin: redo with the exact kernel
@@ -2252,7 +2252,7 @@ extern "C" int amof_rdf_accumulate(amof_ctx *ctx, const amof_traj *traj, double 
     void *d_hist = nullptr;
     AMOF_TRY(upload(ctx, SLOT_OUT0, hist, bytes, &d_hist));
     AMOF_TRY(rdf_run(ctx, traj, rmax, nbins, (unsigned long long *)d_hist, volume_sum));
-    AMOF_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AMOF_TRY(fetch(ctx, hist, d_hist, bytes));
     AMOF_HIP_TRY(ctx, sync_stream(ctx));
     return AMOF_OK;
 }

@@ -383,7 +383,7 @@ class ResidentCopy(object):
     CHUNK_BYTES = 48 << 20
     PIECE_FRAMES = 512          # a batch handed to an analysis: at least this many frames (an RDF launch per batch)
 
-    def __init__(self, packed, device, torch, pinned_source=False, defer=False):
+    def __init__(self, packed, device, torch):
         import threading
         self.packed = packed
         self.device = int(device)
@@ -397,33 +397,17 @@ class ResidentCopy(object):
         self._marks = []                # (frames uploaded so far, event)
         self._cond = threading.Condition()
         self._error = None
-        self._pinned_source = pinned_source
         self.complete = F == 0
-        if not defer and F:
+        if F:
             self._thread = threading.Thread(target=self._run, name="amof-upload", daemon=True)
             self._thread.start()
 
     # -- producer -------------------------------------------------------------------------------------------------------
-    def push(self, f0, f1):
-        """frames [f0, f1) of the host array are final: queue their copy (the host array is page-locked: truly asynchronous)"""
-        torch = self._torch
-        with torch.cuda.stream(self.stream):
-            self.dev[f0:f1].copy_(torch.from_numpy(self.packed.pos[f0:f1]), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        with self._cond:
-            self._marks.append((f1, ev))
-            self._cond.notify_all()
-
     def _run(self):
         try:
             torch = self._torch
             F = self.n_frames
-            if self._pinned_source:
-                for f0 in range(0, F, self.chunk):
-                    self.push(f0, min(F, f0 + self.chunk))
-                return
-            # pageable source: through two page-locked staging buffers (a pageable hipMemcpyAsync blocks the caller and
+            # through two page-locked staging buffers (a pageable hipMemcpyAsync blocks the caller and
             # runs at a fraction of the link rate)
             slots = [torch.empty((self.chunk, self.n_atoms, 3), dtype=torch.float64, pin_memory=True) for _ in range(2)]
             busy = [None, None]
@@ -534,7 +518,7 @@ def resident_source(packed, device, allow=True):
         return packed
     if need < (32 << 20) or 2 * need + (4 << 30) > free:       # (small: not worth a thread; huge: staged per call as before)
         return packed
-    packed._resident = ResidentCopy(packed, device, torch, pinned_source=getattr(packed, "_pinned", None) is not None)
+    packed._resident = ResidentCopy(packed, device, torch)
     return packed._resident
 
 
@@ -570,10 +554,9 @@ def pack_trajectory(trajectory, device=None):
     same atoms in the same order (the reference assumes it: species are read
     from frame 0 only, amof/rdf.py:71, amof/cn.py:52, amof/msd.py:215).
 
-    ``device`` (what the analysis classes pass): the GPU the frames are headed for.  The copy of the frames into the packed
-    array (native, all cores: ``amof_pack_frames``) then goes into page-locked memory in batches, and every batch is on its
-    way to the device while the next one is packed (``ResidentCopy``); the list is remembered, so the next analysis of
-    the same, unchanged list reuses pack and upload.
+    The frames are copied natively on all cores (``amof_pack_frames``: 13 ms for 5000 x 9792 atoms).  ``device`` (what the
+    analysis classes pass): the GPU the frames are headed for -- their ONE upload starts at once (``ResidentCopy``).  The
+    list is remembered, so the next analysis of the same, unchanged list reuses pack and device copy.
     """
     if isinstance(trajectory, PackedTrajectory) or getattr(trajectory, "is_stream", False):
         return trajectory                   # (an amof_amd.stream.XyzStream: the classes walk it batch by batch)
@@ -617,35 +600,18 @@ def pack_trajectory(trajectory, device=None):
                 return entry["packed"]
     ptrs, keep = _frame_pointers(frames, n)
     pids = np.fromiter((id(getattr(f, "positions", None)) for f in frames), dtype=np.int64, count=F)
-    torch = _gpu_for_uploads(device)
-    pinned = None
-    if torch is not None:
-        try:
-            free, _total = torch.cuda.mem_get_info(int(device))
-            if 2 * F * n * 24 + (4 << 30) > free:
-                torch = None
-            else:
-                pinned = torch.empty((F, n, 3), dtype=torch.float64, pin_memory=True)
-        except Exception:
-            torch, pinned = None, None
-    pos = pinned.numpy() if pinned is not None else np.empty((F, n, 3), dtype=np.float64)
+    pos = np.empty((F, n, 3), dtype=np.float64)
     packed = PackedTrajectory(pos, _cells_of(frames), numbers, np.array(first.get_masses(), dtype=np.float64), _pbc_of(first))
     sums = np.empty(F, dtype=np.uint64)
-    rcopy = None
-    if pinned is not None:
-        packed._pinned = pinned             # (keeps the page-locked allocation alive)
-        rcopy = ResidentCopy(packed, device, torch, pinned_source=True, defer=True)
-    step = rcopy.chunk if rcopy is not None else F
-    for f0 in range(0, F, step):
-        f1 = min(F, f0 + step)
-        rc = lib.amof_pack_frames(ctypes.c_void_p(ptrs[f0:].ctypes.data), f1 - f0, n, ctypes.c_void_p(pos[f0:].ctypes.data),
-                                  ctypes.c_void_p(sums[f0:].ctypes.data), threads)
-        if rc != 0:
-            raise RuntimeError("amof_pack_frames failed (%d)" % rc)
-        if rcopy is not None:
-            rcopy.push(f0, f1)              # on its way while the next batch is packed
-    if rcopy is not None:
-        packed._resident = rcopy
+    rc = lib.amof_pack_frames(ctypes.c_void_p(ptrs.ctypes.data), F, n, ctypes.c_void_p(pos.ctypes.data), ctypes.c_void_p(sums.ctypes.data),
+                              threads)
+    if rc != 0:
+        raise RuntimeError("amof_pack_frames failed (%d)" % rc)
+    # (measured and rejected: packing straight into a page-locked array and queueing every batch's DMA from it -- locking
+    #  1.2 GB of pages costs 150 ms per list, ten times the copy it saves.  The device copy is started by the first analysis:
+    #  resident_source -> ResidentCopy, a background thread through two page-locked 48 MB buffers.)
+    if device is not None:
+        resident_source(packed, device)
     # (`keep` stays with the entry: the pointers remain valid while the frames keep their position arrays, which `pids` checks)
     _PACKED_LISTS.insert(0, {"list_id": id(trajectory), "n": n, "ids": ids, "pids": pids, "ptrs": ptrs, "keep": keep, "sums": sums,
                              "packed": packed})

@@ -82,6 +82,9 @@ int amof_ctx_create(int device, amof_ctx **out);
  * examples/Compute structural properties.py:58-118, and parallelises inside them with joblib, amof/msd.py:252-256);
  * their workgroups are dispatched ahead of the RDF kernel's whenever a CU has room. */
 #define AMOF_CTX_HIGH_PRIORITY 1
+/* AMOF_CTX_LOW_PRIORITY: the lowest stream priority -- its workgroups are dispatched where the other context's kernel
+ * leaves compute units free: before that kernel starts and in its tail, instead of delaying it. */
+#define AMOF_CTX_LOW_PRIORITY 2
 int amof_ctx_create2(int device, int flags, amof_ctx **out);
 void amof_ctx_destroy(amof_ctx *ctx);
 const char *amof_last_error(const amof_ctx *ctx);

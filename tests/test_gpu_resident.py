@@ -43,7 +43,7 @@ def test_list_of_frames_is_packed_and_uploaded_once(hip_ctx, walk):
     got = _all_four(frames)                              # four constructors on the SAME list
     assert len(fr._PACKED_LISTS) == 1
     packed = fr._PACKED_LISTS[0]["packed"]
-    assert getattr(packed, "_pinned", None) is not None and packed._resident.device == 0
+    assert packed._resident.device == 0
     _same(got, ref)
     # the copy is kept, the packed host array is read-only while it exists
     assert packed._resident.complete and packed._dev_pos is not None and packed._dev_pos.is_cuda
