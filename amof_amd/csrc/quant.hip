@@ -82,6 +82,94 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_kernel(const double *_
     }
 }
 
+// One workgroup per FRAME, all species (round 5).  quantize_kernel above runs one workgroup per (species, frame) and
+// gathers its species' atoms through the permutation: the species are interleaved in the frame (a ZIF-4 supercell repeats
+// a 272-atom cell), so every 128-byte line of the frame is fetched by up to S workgroups -- 3.40 GB of traffic for 1.96 GB
+// of positions read + records written (profiles/traffic.json, round 4).  Here the frame is read ONCE, in atom order
+// (coalesced), a thread keeps its <= QF_APT atoms' fixed-point coordinates in registers between the counting and the
+// placement pass, and the 256 slab counters exist once per species in LDS.  Same output: Q[fl][species segments][slab
+// order], slab_start[fl][S][257]; the order inside a slab is arbitrary, as before.
+constexpr int QF_APT = 12;          // atoms per thread: frames of up to 12 288 atoms
+constexpr int QF_MAXS = 8;          // species with counters in LDS
+
+__global__ __launch_bounds__(QUANT_THREADS) void quantize_frame_kernel(const double *__restrict__ pos, const double *__restrict__ geom,
+                                                                       int n_cells, const int32_t *__restrict__ perm,
+                                                                       const int64_t *__restrict__ sp_first, int S, int64_t N, int f0,
+                                                                       int axis, QAtom *__restrict__ Q, uint32_t *__restrict__ slab_start,
+                                                                       int32_t *flag, int ax0, int ax1, const double *__restrict__ fold,
+                                                                       unsigned long long used_mask)
+{
+    extern __shared__ __align__(16) unsigned char qf_raw[];
+    uint8_t *spec = qf_raw;                                                              // [N] species of every atom
+    unsigned *cnt = reinterpret_cast<unsigned *>(qf_raw + (((size_t)N + 15) & ~(size_t)15));   // [S][QSLABS]
+    __shared__ unsigned wsum[QUANT_THREADS / 64];
+    const int fl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = f0 + fl;
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    const double *__restrict__ fo = fold ? fold + (size_t)(n_cells == 1 ? 0 : f) * 2 : nullptr;
+    for (int64_t k = tid; k < N; k += QUANT_THREADS) {
+        int sp = 0;
+        while (sp + 1 < S && k >= sp_first[sp + 1]) sp++;
+        spec[perm[k]] = (uint8_t)sp;
+    }
+    for (int i = tid; i < S * QSLABS; i += QUANT_THREADS) cnt[i] = 0u;
+    __syncthreads();
+    uint32_t ux[QF_APT], uy[QF_APT], uz[QF_APT];
+#pragma unroll
+    for (int j = 0; j < QF_APT; j++) {
+        const int64_t a = tid + (int64_t)j * QUANT_THREADS;
+        ux[j] = uy[j] = uz[j] = 0u;
+        if (a < N) {
+            const int sp = spec[a];
+            if ((used_mask >> sp) & 1ull) {
+                QAtom q = quantize_atom(pos, g, N, f, a, ax0, ax1, axis, flag);
+                if (fo) fold_atom(q, fo);
+                ux[j] = q.ux; uy[j] = q.uy; uz[j] = q.uz;
+                atomicAdd(&cnt[sp * QSLABS + (q.uz >> 24)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scans of the S x 256 counters: four species per round, one per group of four waves
+    for (int s0 = 0; s0 < S; s0 += QUANT_THREADS / QSLABS) {
+        const int grp = tid / QSLABS, sp = s0 + grp, t = tid % QSLABS;
+        const unsigned v = sp < S ? cnt[sp * QSLABS + t] : 0u;
+        unsigned incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned n = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 4 * grp; w < wv; w++) base += wsum[w];
+        const unsigned excl = base + incl - v;
+        if (sp < S) {
+            cnt[sp * QSLABS + t] = excl;
+            if (slab_start) {
+                uint32_t *st = slab_start + ((size_t)fl * S + sp) * (QSLABS + 1);
+                st[t] = excl;
+                if (t == QSLABS - 1) st[QSLABS] = excl + v;
+            }
+        }
+        __syncthreads();
+    }
+    QAtom *__restrict__ Qf = Q + (size_t)fl * N;
+#pragma unroll
+    for (int j = 0; j < QF_APT; j++) {
+        const int64_t a = tid + (int64_t)j * QUANT_THREADS;
+        if (a < N) {
+            const int sp = spec[a];
+            if ((used_mask >> sp) & 1ull) {
+                const unsigned slot = atomicAdd(&cnt[sp * QSLABS + (uz[j] >> 24)], 1u);
+                QAtom q;
+                q.ux = ux[j]; q.uy = uy[j]; q.uz = uz[j]; q.idx = (uint32_t)a;
+                Qf[sp_first[sp] + slot] = q;
+            }
+        }
+    }
+}
+
 // 3-D cell variant for the neighbour kernels (cutoffs far below the cell size): one workgroup per (species,
 // frame) counting-sorts the species segment by cell = (cz ny + cy) nx + cx (x fastest) with the counters in LDS,
 // positions read once (the quantised records wait in LDS between the counting and the placement pass, as in
@@ -365,6 +453,14 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
     if (ax0 < 0 || ax1 < 0) { ax0 = (axis + 1) % 3; ax1 = (axis + 2) % 3; }
     if (nf <= 0 || S <= 0) return AMOF_OK;
     if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
+    if (N <= (int64_t)QF_APT * QUANT_THREADS && S <= QF_MAXS && !getenv("AMOF_QUANT_PER_SPECIES")) {
+        // one workgroup per frame: the frame is read once, in atom order
+        const size_t lds = (((size_t)N + 15) & ~(size_t)15) + (size_t)S * QSLABS * sizeof(unsigned);
+        hipLaunchKernelGGL(quantize_frame_kernel, dim3((unsigned)nf), dim3(QUANT_THREADS), lds, ctx->stream, pos_dev, d_geom, n_cells, d_perm,
+                           d_spfirst, S, N, f0, axis, d_Q, d_slab_start, d_flag, ax0, ax1, d_fold, used_mask);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
+        return AMOF_OK;
+    }
     dim3 qgrid((unsigned)S, (unsigned)nf);
     // LDS record cache: up to 4608 atoms per species segment (72 KiB: two workgroups per CU); longer segments
     // (or species counts unknown here: the cap is only a capacity) take the two-read path
