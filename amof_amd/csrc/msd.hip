@@ -1030,7 +1030,10 @@ constexpr int FU_MAX_TPC = 21;    // threads per column: nq <= 105 (workgroups o
 
 // TPL atoms per lane (atoms a, a + 64, ...: a "tile" of cpart is 64 TPL atoms): their m p are added in the lane before the
 // wave sum -- the three double sums over the 64 lanes are ~60 of the ~130 instructions of a frame at TPL = 1.
-template <int TPL, int U>
+// CONSTCELL: one cell for all frames -- its nine numbers sit in registers.  (Loaded per frame they sat behind a
+// `s_waitcnt vmcnt(0)` in the frame's body: global loads retire in order, so every frame waited for ALL the positions
+// prefetched for later frames -- the kernel ran at 3.3 TB/s whatever its shape: profiles/r05/msd_fused_experiments.txt.)
+template <int TPL, int U, bool CONSTCELL>
 __global__ __launch_bounds__(256) void msd_seg_kernel(const double *__restrict__ pos, const double *__restrict__ geom, int n_cells,
                                                       int64_t N, int F, int d, int nq, int64_t a_begin, int64_t a_end,
                                                       const double *__restrict__ masses, double *__restrict__ RS,
@@ -1056,6 +1059,13 @@ __global__ __launch_bounds__(256) void msd_seg_kernel(const double *__restrict__
             px[t] = p[t][-(ptrdiff_t)N3]; py[t] = p[t][1 - (ptrdiff_t)N3]; pz[t] = p[t][2 - (ptrdiff_t)N3];
         }
     }
+    double gc[MSD_GEOM];        // (the entries wrap_delta_t<true> reads: diagonal of the cell and of its inverse, periodic flags)
+#pragma unroll
+    for (int q = 0; q < MSD_GEOM; q++) gc[q] = 0.0;
+    if (CONSTCELL) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { gc[4 * c] = geom[4 * c]; gc[9 + 4 * c] = geom[9 + 4 * c]; gc[18 + c] = geom[18 + c]; }
+    }
     // U frames per round, the next round's loads issued before this round's arithmetic
     double qx[U][TPL], qy[U][TPL], qz[U][TPL], nx[U][TPL], ny[U][TPL], nz[U][TPL];
 #pragma unroll
@@ -1079,9 +1089,13 @@ __global__ __launch_bounds__(256) void msd_seg_kernel(const double *__restrict__
 #pragma unroll
                 for (int t = 0; t < TPL; t++) {
                     if (k >= 1) {
-                        const double *g = geom + (size_t)(n_cells == 1 ? 0 : k - 1) * MSD_GEOM;
                         double dx, dy, dz;
-                        wrap_delta_t<true>(g, qx[j][t] - px[t], qy[j][t] - py[t], qz[j][t] - pz[t], dx, dy, dz);
+                        if (CONSTCELL) {
+                            wrap_delta_t<true>(gc, qx[j][t] - px[t], qy[j][t] - py[t], qz[j][t] - pz[t], dx, dy, dz);
+                        } else {
+                            const double *g = geom + (size_t)(k - 1) * MSD_GEOM;
+                            wrap_delta_t<true>(g, qx[j][t] - px[t], qy[j][t] - py[t], qz[j][t] - pz[t], dx, dy, dz);
+                        }
                         rx[t] += dx; ry[t] += dy; rz[t] += dz;
                     }
                     mx += m[t] * qx[j][t]; my += m[t] * qy[j][t]; mz += m[t] * qz[j][t];
@@ -1641,18 +1655,25 @@ int fused_pass1(amof_ctx *ctx, const amof_traj *t, const double *pos_dev, const 
                 int64_t a1, const FusedDims &fd, double *d_csum, double **d_RS_out)
 {
     const int64_t N = t->n_atoms, F = t->n_frames;
-    // four atoms per lane where that still gives every SIMD a wave, else one
-    int tpl = (a1 - a0) * (int64_t)fd.nq >= (int64_t)4 * 64 * 1024 ? 4 : 1, useg = 4;
-    // (atoms per lane x frames per round 1 x 4, 1 x 8, 2 x 4, 4 x 2 all take 0.35 - 0.37 ms at the headline size: the kernel is
-    //  not bound by its instruction count or by its loads in flight -- profiles/r05/msd_fused_experiments.txt)
+    // four atoms per lane where that still gives every SIMD a wave, two down to a quarter of that, else one (measured on the
+    // headline shape and its eighth, profiles/r05/msd_fused_experiments.txt: 4 x 2 0.248 / 0.092, 2 x 4 0.256 / 0.067,
+    // 1 x 4 0.273 / 0.073 ms)
+    const int64_t work = (a1 - a0) * (int64_t)fd.nq;
+    int tpl = work >= (int64_t)4 * 64 * 1024 ? 4 : work >= (int64_t)2 * 64 * 256 ? 2 : 1, useg = 4;
     const int ntiles = (int)((a1 - a0 + 64 * tpl - 1) / (64 * tpl));
     void *d_RS, *d_cpart;
     AMOF_TRY(ensure(ctx, SLOT_AUX7, (size_t)fd.nq * (size_t)fd.stride * sizeof(double), &d_RS));
     AMOF_TRY(ensure(ctx, SLOT_AUX6, (size_t)ntiles * (size_t)F * 3 * sizeof(double), &d_cpart));
     const dim3 grid((unsigned)ntiles, (unsigned)((fd.nq + 3) / 4));
 #define AMOF_SEG(T, UU)                                                                                                     \
-    hipLaunchKernelGGL((msd_seg_kernel<T, UU>), grid, dim3(256), 0, ctx->stream, pos_dev, d_geom, (int)t->n_cells, N, (int)F, fd.d, \
-                       fd.nq, a0, a1, d_mass, (double *)d_RS, fd.stride, (double *)d_cpart)
+    do {                                                                                                                    \
+        if (t->n_cells == 1)                                                                                                \
+            hipLaunchKernelGGL((msd_seg_kernel<T, UU, true>), grid, dim3(256), 0, ctx->stream, pos_dev, d_geom, (int)t->n_cells, N, \
+                               (int)F, fd.d, fd.nq, a0, a1, d_mass, (double *)d_RS, fd.stride, (double *)d_cpart);          \
+        else                                                                                                                \
+            hipLaunchKernelGGL((msd_seg_kernel<T, UU, false>), grid, dim3(256), 0, ctx->stream, pos_dev, d_geom, (int)t->n_cells, N, \
+                               (int)F, fd.d, fd.nq, a0, a1, d_mass, (double *)d_RS, fd.stride, (double *)d_cpart);          \
+    } while (0)
     if (tpl == 4) AMOF_SEG(4, 2);
     else if (tpl == 2) AMOF_SEG(2, 4);
     else if (useg == 8) AMOF_SEG(1, 8);
