@@ -8,6 +8,7 @@ raise -- they never silently compute somewhere else.
 import ctypes
 import os
 import threading
+import time
 
 import numpy as np
 
@@ -29,7 +30,7 @@ ABI_VERSION = 4
 
 EXPORTS = [
     "amof_abi_version", "amof_device_count", "amof_ctx_create", "amof_ctx_create2", "amof_ctx_destroy", "amof_last_error",
-    "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_ctx_wait_stream", "amof_ctx_debug_poison", "amof_last_kernel_seconds", "amof_last_kernel_launches",
+    "amof_ctx_set_stream", "amof_ctx_synchronize", "amof_ctx_wait_stream", "amof_ctx_follow", "amof_ctx_calls", "amof_ctx_debug_poison", "amof_last_kernel_seconds", "amof_last_kernel_launches",
     "amof_last_path",
     "amof_rdf_accumulate", "amof_rdf_accumulate_dev", "amof_cn_count", "amof_bad_hist", "amof_bad_hist_dev",
     "amof_bad_hist_by_cn",
@@ -101,6 +102,9 @@ def load_library():
         lib.amof_ctx_set_stream.argtypes = [P, P]
         lib.amof_ctx_synchronize.argtypes = [P]
         lib.amof_ctx_wait_stream.argtypes = [P, P]
+        lib.amof_ctx_follow.argtypes = [P, P, ctypes.c_int64, ctypes.c_double]
+        lib.amof_ctx_calls.argtypes = [P]
+        lib.amof_ctx_calls.restype = ctypes.c_int64
         lib.amof_ctx_debug_poison.argtypes = [P, ctypes.c_int]
         lib.amof_last_kernel_seconds.argtypes = [P, ctypes.c_int]
         lib.amof_last_kernel_seconds.restype = ctypes.c_double
@@ -245,6 +249,11 @@ class Lane(object):
     _lane_thread = None
     _last_job = None
     _lane_name = "amof-lane"
+    _follows = None         # the lane whose kernels this lane's jobs are queued behind (Context.follow_leader)
+    _jobs_submitted = 0     # (plain counters, written under the GIL: submit by the callers, the other two by the worker)
+    _jobs_started = 0
+    _jobs_finished = 0
+    _calls_at_job_start = 0
 
     def submit(self, fn):
         """Run ``fn()`` on the worker thread, after everything submitted before; returns the
@@ -267,13 +276,26 @@ class Lane(object):
         def job():
             self._lane_thread = threading.get_ident()
             _tls.producer_stream = producer
+            self._calls_at_job_start = self.device_calls()
+            self._jobs_started += 1
             try:
+                if self._follows is not None:
+                    self.follow_leader()
                 return fn()
             finally:
                 _tls.producer_stream = None
+                self._jobs_finished += 1
+        self._jobs_submitted += 1
         fut = self._lane.submit(job)
         self._last_job = fut
         return fut
+
+    def device_calls(self):
+        """device calls begun on this lane's context so far (0: not a GPU context)"""
+        return 0
+
+    def follow_leader(self):
+        """(GPU contexts) queue this lane's next kernels behind the leader lane's"""
 
     def drain(self):
         """wait for every job submitted to the lane (their errors stay with their futures)"""
@@ -339,6 +361,42 @@ class Context(Lane):
         if rc == AMOF_EUNSUPPORTED:
             raise Unsupported(rc, msg)
         raise AmofError(rc, msg)
+
+    def device_calls(self):
+        """calls of this context that have started device work (``amof_ctx_calls``; any thread may ask)"""
+        return int(self._lib.amof_ctx_calls(self._h)) if getattr(self, "_h", None) else 0
+
+    def follow_leader(self):
+        """Queue this context's next kernels BEHIND the leader lane's (``amof_ctx_follow``; lane 1 follows lane 0 of its
+        device).  If the leader has a job pending, wait -- on the host, a fraction of a millisecond -- until that job has
+        queued its dominant kernel, then order this context's stream after the leader's: the kernels of the memory-bound
+        analyses then run when the RDF tile kernel has finished, beside the RDF's read-back and DataFrame assembly, and
+        this lane's host work beside the tile kernel.  Side by side the two lose: the tile kernel fills LDS and registers,
+        a second stream's workgroups trickle in between (profiles/r05/stops.txt A).  Nothing to follow (leader idle):
+        returns at once.  OPT-IN, ``AMOF_LANE_ORDER=1``: measured against the unordered lanes it changes nothing at N = 1
+        (74.2 / 74.6 against 74.8 / 74.6 ms per step, sequential 74.6 / 74.1) and costs 0.1 - 0.2 ms for one rank of eight,
+        where the followers' kernels and result assembly end up behind the RDF's instead of before it
+        (profiles/r05/lane_order.txt)."""
+        lead = self._follows
+        if lead is None or lead is self or os.environ.get("AMOF_LANE_ORDER", "0") != "1":
+            return
+        target = lead._jobs_submitted
+        if lead._jobs_finished >= target:
+            return                                  # the leader is idle: nothing queued that this lane could be stuck behind
+        while lead._jobs_finished < target:
+            if lead._jobs_started >= target:
+                # the job we follow is running: its first device call is number _calls_at_job_start + 1 of its context
+                with self._lock:
+                    rc = self._lib.amof_ctx_follow(self._h, lead._h, lead._calls_at_job_start + 1, 0.0005)
+                if rc < 0:
+                    self._check(rc)
+                if rc == 1:
+                    return
+            else:
+                time.sleep(2e-5)                    # (still queued behind an earlier job of its lane)
+        # the leader's job ended without a dominant kernel (an empty trajectory, an error): plain stream order
+        with self._lock:
+            self._check(min(0, self._lib.amof_ctx_follow(self._h, lead._h, 0, 0.0)))
 
     @_locked
     def set_stream(self, stream_ptr):
@@ -726,6 +784,11 @@ def get_context(device=None, lane=0):
         if ctx is None:
             ctx = Context(device, priority=os.environ.get("AMOF_LANE1_PRIORITY", "high") if lane else "normal")
             _contexts[key] = ctx
+            if lane:
+                lead = _contexts.get(device)
+                if lead is None:
+                    lead = _contexts[device] = Context(device, priority="normal")
+                ctx._follows = lead
         return ctx
 
 

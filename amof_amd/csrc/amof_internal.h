@@ -31,6 +31,7 @@ enum Slot {
     SLOT_HISTU,     // unordered-key histograms (u64)
     SLOT_SELF,      // self-image histogram (u64)
     SLOT_SPEC,      // species index per atom
+    SLOT_QSPEC,     // species of every atom as a byte (quantize_frame_kernel)
     SLOT_AUX0,
     SLOT_AUX1,
     SLOT_AUX2,
@@ -73,6 +74,7 @@ struct amof_ctx {
     size_t rb_cap = 0;
     // amof_msd_shard_begin leaves scratch for amof_msd_shard_finish: valid while no other call ran on the context
     int64_t calls = 0;            // entry points that started device work (timing_begin)
+    int64_t progress = 0;         // 2 calls + (the call's dominant kernel is queued): read by OTHER threads (amof_ctx_follow), atomically
     int64_t shard_ticket = 0;     // `calls` right after a begin; 0 = none pending
     int64_t shard_key[7] = {0, 0, 0, 0, 0, 0, 0};
 };

@@ -6,6 +6,9 @@
 
 #include <algorithm>
 
+#include <chrono>
+#include <thread>
+
 #include "amof_internal.h"
 
 namespace amof {
@@ -158,6 +161,7 @@ void timing_begin(amof_ctx *ctx)
     ctx->ev_valid = false;
     ctx->dom_launches = 0;
     ctx->calls++;
+    __atomic_store_n(&ctx->progress, 2 * ctx->calls, __ATOMIC_RELEASE);
     (void)hipEventRecord(ctx->ev_all0, ctx->stream);
 }
 void timing_end(amof_ctx *ctx)
@@ -174,6 +178,7 @@ void timing_dom_end(amof_ctx *ctx, int64_t launches)
 {
     (void)hipEventRecord(ctx->ev_dom1, ctx->stream);
     ctx->dom_launches = launches;
+    __atomic_store_n(&ctx->progress, 2 * ctx->calls + 1, __ATOMIC_RELEASE);
 }
 
 int validate_traj(amof_ctx *ctx, const amof_traj *t, bool need_masses)
@@ -450,6 +455,29 @@ int amof_ctx_wait_stream(amof_ctx *ctx, void *hip_stream)
     AMOF_HIP_TRY(ctx, hipEventRecord(ctx->ev_order, (hipStream_t)hip_stream));
     AMOF_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
     return AMOF_OK;
+}
+
+int64_t amof_ctx_calls(const amof_ctx *ctx)
+{
+    return ctx ? __atomic_load_n(&ctx->progress, __ATOMIC_ACQUIRE) / 2 : 0;
+}
+
+int amof_ctx_follow(amof_ctx *ctx, amof_ctx *other, int64_t min_calls, double timeout_s)
+{
+    if (!ctx || !other) return AMOF_EINVAL;
+    if (ctx == other) return 1;
+    if (ctx->device != other->device) return fail(ctx, AMOF_EINVAL, "amof_ctx_follow: the two contexts are on different devices");
+    if (min_calls > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const int64_t p = __atomic_load_n(&other->progress, __ATOMIC_ACQUIRE);
+            if (p / 2 > min_calls || (p / 2 == min_calls && (p & 1))) break;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= timeout_s) return 0;
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    AMOF_TRY(amof_ctx_wait_stream(ctx, (void *)other->stream));
+    return 1;
 }
 
 int amof_ctx_debug_poison(amof_ctx *ctx, int byte)

@@ -1025,7 +1025,12 @@ __global__ __launch_bounds__(MSD_THREADS) void msd_reduce_kernel(const double *_
 // Shape of pass 2's workgroups (256 threads, <= 128 VGPRs, 10 kB of LDS): what ONE retiring workgroup of the RDF tile
 // kernel frees on a CU, so that they are placed beside a running RDF launch (second lane: amof_amd/_lazy.py).
 constexpr int FU_EB = 5;          // comb entries (segments) per thread
-constexpr int FU_CPW = 24;        // columns (= 8 atoms) per workgroup; 32 (whole 128-byte lines, 5-wave workgroups) measured slower: 0.64 vs 0.47 ms
+#ifndef AMOF_FU_CPW
+#define AMOF_FU_CPW 24
+#endif
+// columns (= 8 atoms) per workgroup; whole 128-byte lines measured slower: 32 (5-wave workgroups) 0.64, 16 (2.5-wave
+// workgroups) 0.57 against 0.47 ms (-DAMOF_FU_CPW=..: experiments)
+constexpr int FU_CPW = AMOF_FU_CPW;
 constexpr int FU_MAX_TPC = 21;    // threads per column: nq <= 105 (workgroups of <= 512 threads: 168 registers per lane)
 
 // TPL atoms per lane (atoms a, a + 64, ...: a "tile" of cpart is 64 TPL atoms): their m p are added in the lane before the
@@ -1262,7 +1267,9 @@ __device__ __forceinline__ void msd_fused_body(const double *__restrict__ pos, c
     const int nrow = L + TPC * FU_EB;
     const int tid = threadIdx.x, cl = tid % FU_CPW, eb = tid / FU_CPW;
     // (measured and rejected: consecutive column blocks dealt to ONE XCD, so that the 128-byte lines two neighbouring blocks
-    //  share -- a block's row is 192 bytes -- come from that XCD's L2 the second time: 0.473 vs 0.467 ms, no gain)
+    //  share -- a block's row is 192 bytes -- come from that XCD's L2 the second time: 0.476 vs 0.470 ms and the SAME
+    //  FETCH_SIZE, 1.565 GB = 4/3 of the positions; 16 columns per block (whole lines, AMOF_FU_CPW=16) fetch 1.176 GB and
+    //  take 0.567 ms -- 2.5 waves per workgroup: profiles/r05/msd_fused_experiments.txt)
     const int64_t lc = (int64_t)blockIdx.x * FU_CPW + cl;        // column of this call's atom range
     const bool on = eb < TPC && lc < ncols;
     const int64_t col = 3 * a_begin + (lc < ncols ? lc : 0);     // column of the frame rows: 3 a + c (idle lanes: one that exists)
@@ -1351,7 +1358,9 @@ __device__ __forceinline__ void msd_fused_body(const double *__restrict__ pos, c
         // the next step's loads: in flight behind the barrier and this step's products
 #pragma unroll
         for (int i = 0; i < FU_EB; i++) {
-            if (FAST ? r + 1 < d : (i * d + r + 1 < rem && r + 1 < d)) {
+            // (GENERAL: by the entry's own length also in a fast step -- the last segment is short there, and the step
+            //  r_fast - 1 would otherwise load row F, one frame behind the trajectory)
+            if (!GENERAL ? r + 1 < d : (i * d + r + 1 < rem && r + 1 < d)) {
                 pp[i] += N3;
                 dp[i] += 1;
                 cur[SL][i] = *pp[i];

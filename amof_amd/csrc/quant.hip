@@ -87,46 +87,60 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_kernel(const double *_
 // a 272-atom cell), so every 128-byte line of the frame is fetched by up to S workgroups -- 3.40 GB of traffic for 1.96 GB
 // of positions read + records written (profiles/traffic.json, round 4).  Here the frame is read ONCE, in atom order
 // (coalesced), a thread keeps its <= QF_APT atoms' fixed-point coordinates in registers between the counting and the
-// placement pass, and the 256 slab counters exist once per species in LDS.  Same output: Q[fl][species segments][slab
-// order], slab_start[fl][S][257]; the order inside a slab is arbitrary, as before.
+// placement pass, and the 256 slab counters exist once per species in LDS; the placement goes species by species through an
+// LDS stage, so that the records leave as whole lines.  Same output: Q[fl][species segments][slab order],
+// slab_start[fl][S][257]; the order inside a slab is arbitrary, as before.
 constexpr int QF_APT = 12;          // atoms per thread: frames of up to 12 288 atoms
 constexpr int QF_MAXS = 8;          // species with counters in LDS
 
-__global__ __launch_bounds__(QUANT_THREADS) void quantize_frame_kernel(const double *__restrict__ pos, const double *__restrict__ geom,
-                                                                       int n_cells, const int32_t *__restrict__ perm,
-                                                                       const int64_t *__restrict__ sp_first, int S, int64_t N, int f0,
-                                                                       int axis, QAtom *__restrict__ Q, uint32_t *__restrict__ slab_start,
-                                                                       int32_t *flag, int ax0, int ax1, const double *__restrict__ fold,
-                                                                       unsigned long long used_mask)
+// species of every atom as a byte, in atom order (once per launch_quantize: the per-frame workgroups used to rebuild it in
+// LDS from the permutation -- ten dependent L2 round trips per thread at the head of a workgroup that lives ~35 us)
+__global__ __launch_bounds__(256) void species_bytes_kernel(const int32_t *__restrict__ perm, const int64_t *__restrict__ sp_first,
+                                                            int S, int64_t N, uint8_t *__restrict__ spec)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    int sp = 0;
+    while (sp + 1 < S && k >= sp_first[sp + 1]) sp++;
+    spec[perm[k]] = (uint8_t)sp;
+}
+
+// (86 registers: one workgroup per CU.  Held to 64 for two, the compiler spills 96 bytes per lane and the kernel is slower
+//  than before, 0.83 against 0.57 ms for quantisation + finalisation of 5000 frames: profiles/r05/quantize_experiments.txt)
+__global__ __launch_bounds__(QUANT_THREADS) void quantize_frame_kernel(
+    const double *__restrict__ pos, const double *__restrict__ geom, int n_cells, const uint8_t *__restrict__ spec,
+    const int64_t *__restrict__ sp_first, int S, int64_t N, int f0, int axis, QAtom *__restrict__ Q, uint32_t *__restrict__ slab_start,
+    int32_t *flag, int ax0, int ax1, const double *__restrict__ fold, unsigned long long used_mask, int stage_cap)
 {
     extern __shared__ __align__(16) unsigned char qf_raw[];
-    uint8_t *spec = qf_raw;                                                              // [N] species of every atom
-    unsigned *cnt = reinterpret_cast<unsigned *>(qf_raw + (((size_t)N + 15) & ~(size_t)15));   // [S][QSLABS]
+    unsigned *cnt = reinterpret_cast<unsigned *>(qf_raw);                                // [S][QSLABS], then stage[stage_cap]
     __shared__ unsigned wsum[QUANT_THREADS / 64];
     const int fl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int f = f0 + fl;
     const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
     const double *__restrict__ fo = fold ? fold + (size_t)(n_cells == 1 ? 0 : f) * 2 : nullptr;
-    for (int64_t k = tid; k < N; k += QUANT_THREADS) {
-        int sp = 0;
-        while (sp + 1 < S && k >= sp_first[sp + 1]) sp++;
-        spec[perm[k]] = (uint8_t)sp;
-    }
     for (int i = tid; i < S * QSLABS; i += QUANT_THREADS) cnt[i] = 0u;
+    // the species of this thread's atoms, four bits each (15: no atom, or a species nobody reads)
+    unsigned long long spk = 0ull;
+#pragma unroll
+    for (int j = 0; j < QF_APT; j++) {
+        const int64_t a = tid + (int64_t)j * QUANT_THREADS;
+        unsigned sp = a < N ? (unsigned)spec[a] : 15u;
+        if (sp < 15u && !((used_mask >> sp) & 1ull)) sp = 15u;
+        spk |= (unsigned long long)sp << (4 * j);
+    }
     __syncthreads();
     uint32_t ux[QF_APT], uy[QF_APT], uz[QF_APT];
 #pragma unroll
     for (int j = 0; j < QF_APT; j++) {
         const int64_t a = tid + (int64_t)j * QUANT_THREADS;
         ux[j] = uy[j] = uz[j] = 0u;
-        if (a < N) {
-            const int sp = spec[a];
-            if ((used_mask >> sp) & 1ull) {
-                QAtom q = quantize_atom(pos, g, N, f, a, ax0, ax1, axis, flag);
-                if (fo) fold_atom(q, fo);
-                ux[j] = q.ux; uy[j] = q.uy; uz[j] = q.uz;
-                atomicAdd(&cnt[sp * QSLABS + (q.uz >> 24)], 1u);
-            }
+        const unsigned sp = (unsigned)(spk >> (4 * j)) & 15u;
+        if (sp < 15u) {
+            QAtom q = quantize_atom(pos, g, N, f, a, ax0, ax1, axis, flag);
+            if (fo) fold_atom(q, fo);
+            ux[j] = q.ux; uy[j] = q.uy; uz[j] = q.uz;
+            atomicAdd(&cnt[sp * QSLABS + (q.uz >> 24)], 1u);
         }
     }
     __syncthreads();
@@ -154,18 +168,30 @@ __global__ __launch_bounds__(QUANT_THREADS) void quantize_frame_kernel(const dou
         }
         __syncthreads();
     }
+    // placement, species by species: the records of a species segment are put in slab order in LDS and leave as whole
+    // lines (scattered from the threads, 16 bytes each over a frame's 157 kB, lines left the L2 partly written: 1.76 GB
+    // written for 0.78 GB of records); a segment longer than the stage (stage_cap records) is scattered directly
     QAtom *__restrict__ Qf = Q + (size_t)fl * N;
+    QAtom *stage = reinterpret_cast<QAtom *>(cnt + (size_t)S * QSLABS);
+    for (int s = 0; s < S; s++) {
+        if (!((used_mask >> s) & 1ull)) continue;
+        const int64_t k0 = sp_first[s];
+        const int count = (int)(sp_first[s + 1] - k0);
+        const bool staged = count <= stage_cap;
 #pragma unroll
-    for (int j = 0; j < QF_APT; j++) {
-        const int64_t a = tid + (int64_t)j * QUANT_THREADS;
-        if (a < N) {
-            const int sp = spec[a];
-            if ((used_mask >> sp) & 1ull) {
-                const unsigned slot = atomicAdd(&cnt[sp * QSLABS + (uz[j] >> 24)], 1u);
+        for (int j = 0; j < QF_APT; j++) {
+            if (((unsigned)(spk >> (4 * j)) & 15u) == (unsigned)s) {
+                const unsigned slot = atomicAdd(&cnt[s * QSLABS + (uz[j] >> 24)], 1u);
                 QAtom q;
-                q.ux = ux[j]; q.uy = uy[j]; q.uz = uz[j]; q.idx = (uint32_t)a;
-                Qf[sp_first[sp] + slot] = q;
+                q.ux = ux[j]; q.uy = uy[j]; q.uz = uz[j]; q.idx = (uint32_t)(tid + j * QUANT_THREADS);
+                if (staged) stage[slot] = q;
+                else Qf[k0 + slot] = q;
             }
+        }
+        if (staged) {
+            __syncthreads();
+            for (int k = tid; k < count; k += QUANT_THREADS) Qf[k0 + k] = stage[k];
+            __syncthreads();
         }
     }
 }
@@ -455,9 +481,19 @@ int launch_quantize(amof_ctx *ctx, const double *pos_dev, const double *d_geom, 
     if (nf > 65535) return fail(ctx, AMOF_ECAPACITY, "frame batch too large");
     if (N <= (int64_t)QF_APT * QUANT_THREADS && S <= QF_MAXS && !getenv("AMOF_QUANT_PER_SPECIES")) {
         // one workgroup per frame: the frame is read once, in atom order
-        const size_t lds = (((size_t)N + 15) & ~(size_t)15) + (size_t)S * QSLABS * sizeof(unsigned);
-        hipLaunchKernelGGL(quantize_frame_kernel, dim3((unsigned)nf), dim3(QUANT_THREADS), lds, ctx->stream, pos_dev, d_geom, n_cells, d_perm,
-                           d_spfirst, S, N, f0, axis, d_Q, d_slab_start, d_flag, ax0, ax1, d_fold, used_mask);
+        void *d_spec;
+        AMOF_TRY(ensure(ctx, SLOT_QSPEC, (size_t)N, &d_spec));
+        hipLaunchKernelGGL(species_bytes_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_perm, d_spfirst, S, N,
+                           (uint8_t *)d_spec);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
+        // the stage: 4608 records (72 KiB, as quantize_kernel's cache; the callers do not pass the species counts: N is
+        // the bound); AMOF_QUANT_NOSTAGE (experiments): every record scattered from its thread
+        const int stage_cap = getenv("AMOF_QUANT_NOSTAGE") ? 0 : (int)std::min<int64_t>(N, 4608);
+        const size_t lds = (size_t)S * QSLABS * sizeof(unsigned) + (size_t)stage_cap * sizeof(QAtom);
+        AMOF_HIP_TRY(ctx, allow_max_lds((const void *)quantize_frame_kernel));
+        hipLaunchKernelGGL(quantize_frame_kernel, dim3((unsigned)nf), dim3(QUANT_THREADS), lds, ctx->stream, pos_dev, d_geom, n_cells,
+                           (const uint8_t *)d_spec, d_spfirst, S, N, f0, axis, d_Q, d_slab_start, d_flag, ax0, ax1, d_fold, used_mask,
+                           stage_cap);
         AMOF_HIP_TRY(ctx, hipGetLastError());
         return AMOF_OK;
     }

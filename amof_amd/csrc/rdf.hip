@@ -235,7 +235,9 @@ struct RdfFastArgs {
     double guard64_2;        // 2 g_m (1 + 1e-9), g_m^2 (1 + 1e-9): level 2 decides on T - e^2 against +-(2 e g_m + g_m^2)
     double guard64_sq;
     int32_t xcd_map;         // 1: chunk -> XCD affinity mapping of the grid
-    int32_t n_chunks;        // tile kernel: frames [c nf / n_chunks, (c+1) nf / n_chunks) belong to chunk c
+    int32_t n_chunks;        // tile kernel: frames [c nf_main / n_chunks, (c+1) nf_main / n_chunks) belong to chunk c
+    int32_t nf_main;         // tile kernel: frames dealt in chunks (nf, or with the XCD mapping the multiple of 8 below it: the
+                             // nf % 8 frames behind them are rows n_chunks .. of the grid, one frame each, on whatever XCD)
     int32_t img_queue;       // IMG variant: capacity of one parking buffer
     int32_t img_defer;       // 1: two small buffers, a step's parked pairs are evaluated at the start of the next step
                              // (no extra barrier); 0: one large buffer, evaluated at the end of the step
@@ -510,12 +512,33 @@ __device__ __forceinline__ int tri_xwrap(float c10, int ix, float fy)
     return XW ? (int)((uint32_t)ix + (uint32_t)(int)(fy * c10)) : ix;
 }
 
+// squared distance of a candidate in bins^2 (f32) | its root
 template <bool XW>
-__device__ __forceinline__ float tri_q(const float *sc, float c10, int ix, float fy, float dz)
+__device__ __forceinline__ float tri_t(const float *sc, float c10, int ix, float fy, float dz)
 {
     const float dxf = XW ? (float)tri_xwrap<true>(c10, ix, fy) : fmaf(fy, c10, (float)ix);
     const float x2 = dxf * dxf, y2 = fy * fy;
-    return __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(y2, sc[4], x2 * sc[3])));
+    return fmaf(dz, dz, fmaf(y2, sc[4], x2 * sc[3]));
+}
+
+template <bool XW>
+__device__ __forceinline__ float tri_q(const float *sc, float c10, int ix, float fy, float dz)
+{
+    return __builtin_amdgcn_sqrtf(tri_t<XW>(sc, c10, ix, fy, dz));
+}
+
+// near mode 4: the nearer of the pair's two candidates -- the image it minimised and the one a cell further along y, x wrapped
+// again with the new y.  The host admits the mode only where the two differ by a lattice vector of length >= 2 rmax: then at
+// most one of them is in range, and when the nearer one is clear of the last bin edge by the guard the other is out of range
+// by the same margin (a pair inside that band is flagged and goes the canonical way with every listed image, like any pair on
+// a bin edge).  One root, one clamp, one edge test, one histogram add per pair; the first version counted both candidates
+// (the second into the trash words for the 85 % of pairs that have none): 2.3x the diagonal cell's cost per visited pair.
+template <bool XW>
+__device__ __forceinline__ float tri_q_twin(const float *sc, float c10, int ix, float fy, float dz)
+{
+    const float t1 = tri_t<XW>(sc, c10, ix, fy, dz);
+    const float t2 = tri_t<true>(sc, c10, ix, fy - copysignf(4294967296.f, fy), dz);
+    return __builtin_amdgcn_sqrtf(__builtin_fminf(t1, t2));
 }
 
 struct TriConst {
@@ -528,11 +551,10 @@ struct TriConst {
 // coordinate; else the raw folded ones (per-pair correction).  NEAR: 0 no second image possible anywhere; 1 only for pairs
 // inside the guard band of the last bin edge, which are flagged anyway: the slow path tests, the fast path does not; 2 the
 // fast path tests y, 3 y and z (the slow path always both: every instruction of its body costs, so NEAR = 0 has none);
-// 4 for cells whose second image along y is COMMON (hexagonal: 15 % of the pairs): the fast path evaluates BOTH candidates
-// of every pair -- the image it minimised and the one a cell further along y, x wrapped again with the new y; for a pair
-// that is not near, the second lands in the trash words -- and a pair with either candidate inside the guard of a bin
-// edge is parked for the canonical arithmetic (first version: the twin in the slow path, which then ran on every
-// wave-level pair with a few live lanes: 4.4x the diagonal cell's cost per visited pair).
+// 4 for cells whose second image along y is COMMON (hexagonal: 15 % of the pairs): the fast path takes the nearer of the
+// pair's two candidates (tri_q_twin), and a pair whose nearer candidate is inside the guard of a bin edge is parked for the
+// canonical arithmetic (first version: the twin in the slow path, which then ran on every wave-level pair with a few live
+// lanes: 4.4x the diagonal cell's cost per visited pair; second: both candidates counted, 2.3x).
 template <bool ZF, int NEAR, bool XW>
 __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, const TriConst &tc, bool live, float half_m_guard,
                                              uint32_t ux, uint32_t uy, uint32_t uz, uint4 qj, float &q, float zif,
@@ -549,20 +571,13 @@ __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, co
         dz = (float)iz * sc[8];
     }
     const float fy = (float)iy;
-    q = tri_q<XW>(sc, tc.c10, ix, fy, dz);
+    q = NEAR == 4 ? tri_q_twin<XW>(sc, tc.c10, ix, fy, dz) : tri_q<XW>(sc, tc.c10, ix, fy, dz);
     if (!live_all) q = live ? q : __builtin_inff();
     q = __builtin_fminf(q, clampv);
     bool flag = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
     if (NEAR == 2) flag |= live && (fabsf(fy) > tc.near_y);
     if (NEAR == 3) flag |= live && ((fabsf(fy) > tc.near_y) | (fabsf(dz) > tc.near_z));
     atomicAdd(&hist[(int)q], 1u);
-    if (NEAR == 4) {
-        float q2 = tri_q<true>(sc, tc.c10, ix, fy - copysignf(4294967296.f, fy), dz);
-        if (!live_all) q2 = live ? q2 : __builtin_inff();
-        q2 = __builtin_fminf(q2, clampv);
-        flag |= !(fabsf(__builtin_amdgcn_fractf(q2) - 0.5f) < half_m_guard);
-        atomicAdd(&hist[(int)q2], 1u);
-    }
     return flag;
 }
 
@@ -580,12 +595,9 @@ __device__ __forceinline__ void rdf_pair_refine_tri(unsigned *hist, const RdfFas
     else tri_int(qj, ux, uy, uz, tc.kx, tc.ky, ix, iy, iz);
     const int cand = (int)q;
     if (NEAR == 4) {
-        // one of the pair's two candidates is within the guard of a bin edge: both provisional counts back (the second
-        // candidate recomputed exactly as fast_bin_tri formed it), the pair goes the canonical way with every listed image
-        const float fy = (float)iy, dzf = ZF ? __uint_as_float(qj.w) - zif : (float)iz * sc[8];
-        const float q2 = __builtin_fminf(tri_q<true>(sc, tc.c10, ix, fy - copysignf(4294967296.f, fy), dzf), clampv);
+        // the nearer candidate is within the guard of a bin edge: its provisional count back, the pair goes the canonical way
+        // with every listed image
         atomicAdd(&hist[cand], 0xffffffffu);
-        atomicAdd(&hist[(int)q2], 0xffffffffu);
         park();
         return;
     }
@@ -729,15 +741,18 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     // with its own 4 MiB L2.  All work items of one frame chunk go to the same XCD so that the
     // chunk's quantised frames (16 frames x 16 B x N) are re-read from that L2, not from the
     // fabric.  Pure bijection of the grid: correctness does not depend on the placement.
+    // The frames that do not divide by 8 (nf % 8 of them) come last, one frame per grid row, their work items on all XCDs:
+    // kept in the XCDs' ranges they made one XCD's share a whole frame longer (625 frames: 79 against 78 1/8, 1.1 % of a
+    // rank's launch in an 8-GPU run).
     unsigned chunk = blockIdx.y, bx = blockIdx.x;
-    if (fa.xcd_map) {      // (off when there are too few chunks to give every XCD its share)
+    const bool tail = (int)blockIdx.y >= fa.n_chunks;
+    if (fa.xcd_map && !tail) {      // (off when there are too few chunks to give every XCD its share)
         const unsigned long long lin = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
         const unsigned xcd = (unsigned)(lin & 7ull);
         const unsigned long long kk = lin >> 3;
         chunk = (unsigned)(kk / gridDim.x) * 8u + xcd;
         bx = (unsigned)(kk % gridDim.x);
     }
-    if ((int)chunk >= fa.n_chunks) return;
     const int2 pr = a.pairs[bx];
     const Tile ti = a.tiles[pr.x];
     const Tile tj = a.tiles[pr.y];
@@ -748,8 +763,8 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     // equal shares (+-1 frame): with the XCD mapping n_chunks is a multiple of 8, so every XCD gets the same work
     // (with the XCD mapping, XCD x owns the contiguous frame range [x nf/8, (x+1) nf/8), cut into n_chunks/8 shares)
     const unsigned cs = fa.xcd_map ? (chunk & 7u) * ((unsigned)fa.n_chunks >> 3) + (chunk >> 3) : chunk;
-    const int f0 = (int)((long long)cs * fa.nf / fa.n_chunks);
-    const int f1 = (int)((long long)(cs + 1) * fa.nf / fa.n_chunks);
+    const int f0 = tail ? fa.nf_main + ((int)blockIdx.y - fa.n_chunks) : (int)((long long)cs * fa.nf_main / fa.n_chunks);
+    const int f1 = tail ? f0 + 1 : (int)((long long)(cs + 1) * fa.nf_main / fa.n_chunks);
     // The (up to four) 128-atom centre sub-tiles of tile I are handled by the same workgroup, frame by
     // frame: a step is (frame, sub-tile); tile J of a frame is staged once and serves all its sub-tiles,
     // and the LDS histogram is flushed once for everything.
@@ -1581,7 +1596,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 bool ok = true;
                 double slack = 1e300, share = 0.0, l10b = 0.0, c10max = 0.0, tau_max = 0.0;
                 int near = 0;
-                bool twin = false, xw_wraps = false, twin_wraps = false;
+                bool twin = false, xw_wraps = false, twin_wraps = false, twin_short = false;
                 std::vector<double> fold((size_t)nc * 2), rec((size_t)nc * 9);
                 for (int64_t k = 0; k < nc && ok; k++) {
                     const double *c = t->cell + 9 * k;
@@ -1598,6 +1613,12 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     //  slow path itself, near mode 4; along z only what the canonical queue can take)
                     if (tau_y > 0.09 || tau_z > 0.0075) { ok = false; break; }
                     if (tau_y > 0.0075) twin = true;
+                    // (near mode 4 counts the nearer of two candidates that differ by a lattice vector +-(B - k A), x wrapped:
+                    //  only where every such vector is at least 2 rmax long can the other one never be in range as well)
+                    {
+                        const double xr = L[3] - L[0] * rint(L[3] / L[0]);
+                        if (sqrt(L[4] * L[4] + xr * xr) * (1.0 + 1e-12) < 2.0 * rmax) twin_short = true;
+                    }
                     tau_max = std::max(tau_max, std::max(tau_y, 0.0));
                     // The x wrap of XW and of the twin image forms (int)(fy * c10), fy = the y difference in units of 2^-32 of the
                     // cell: modular arithmetic only while |fy c10| < 2^31 (the conversion saturates beyond).  In range means
@@ -1643,7 +1664,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 // (measured: + 8 % per compare, + 24 % for the wrap, profiles/r04/tri_experiments.txt)
                 if (twin) {
                     if (near == 3) ok = false;      // (a common twin along y AND near tests along z: the image-aware / exact kernels)
-                    if (twin_wraps) ok = false;
+                    if (twin_wraps || twin_short) ok = false;
                     near = 4;
                 }
                 if (!(slack > 0.0) && xw_wraps) ok = false;
@@ -2099,10 +2120,14 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 if (nf >= 64) fpc = std::min<int64_t>(fpc, nf / 32);   // >= 32 chunks: every XCD gets >= 4
                 int64_t chunks = (nf + fpc - 1) / fpc;
                 fa.xcd_map = chunks >= 32 ? 1 : 0;
-                if (fa.xcd_map) chunks = (chunks + 7) / 8 * 8;         // the XCD mapping deals chunks in groups of 8
+                // the XCD mapping deals chunks in groups of 8, over a number of frames that divides by 8; the rest: one grid
+                // row per frame behind the chunks (rdf_tile_kernel_fast)
+                const int64_t nf_tail = fa.xcd_map && !getenv("AMOF_RDF_NOTAIL") ? nf % 8 : 0;
+                if (fa.xcd_map) chunks = ((nf - nf_tail + fpc - 1) / fpc + 7) / 8 * 8;
                 fa.a.frames_per_chunk = (int32_t)fpc;
                 fa.n_chunks = (int32_t)chunks;
-                dim3 grid((unsigned)fpairs.size(), (unsigned)chunks);
+                fa.nf_main = (int32_t)(nf - nf_tail);
+                dim3 grid((unsigned)fpairs.size(), (unsigned)(chunks + nf_tail));
                 if (launches == 0) timing_dom_begin(ctx, tri ? "rdf_tile_tri" : fast_img ? "rdf_tile_img" : use_zf ? "rdf_tile_zf" : "rdf_tile");
                 auto launch = [&](auto kern) -> hipError_t {
                     hipError_t e2 = allow_max_lds((const void *)kern);
@@ -2112,7 +2137,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 };
                 hipError_t e;
                 if (tri) {
-                    ft.Q = fa.Q; ft.f_base = fa.f_base; ft.nf = fa.nf; ft.xcd_map = fa.xcd_map; ft.n_chunks = fa.n_chunks;
+                    ft.Q = fa.Q; ft.f_base = fa.f_base; ft.nf = fa.nf; ft.xcd_map = fa.xcd_map; ft.n_chunks = fa.n_chunks; ft.nf_main = fa.nf_main;
                     ft.a.frames_per_chunk = fa.a.frames_per_chunk;
                     auto launch_tri = [&](auto kern) -> hipError_t {
                         hipError_t e2 = allow_max_lds((const void *)kern);

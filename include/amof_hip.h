@@ -99,6 +99,21 @@ int amof_ctx_synchronize(amof_ctx *ctx);
  * calls this first: the library's kernels otherwise run on the context's non-blocking stream with
  * no ordering against the producer. */
 int amof_ctx_wait_stream(amof_ctx *ctx, void *hip_stream);
+/* Two contexts of one device, driven by two host threads (amof_amd/_lazy.py: the RDF on one, the memory-bound analyses on
+ * the other).  Their kernels do not run well side by side -- the RDF tile kernel fills the LDS and the register file of every
+ * CU, a second stream's workgroups trickle in between and both lose (profiles/r05/stops.txt A) -- so the second context
+ * FOLLOWS the first: amof_ctx_follow waits on the HOST (at most timeout_s) until `other` has begun its call number
+ * min_calls (amof_ctx_calls counts them; 0: no host wait) and queued that call's dominant kernel, then orders ctx's stream
+ * after everything `other` has queued so far (amof_ctx_wait_stream).  The follower's host work (tables, uploads) then runs
+ * beside the leader's kernel, its kernels right behind it, beside the leader's read-back and result assembly.
+ * Returns 1 when ordered, 0 on timeout (nothing ordered: the caller decides), < 0 on error.  Safe to call while `other` is
+ * inside a call on another thread.  The classes use it only on request (AMOF_LANE_ORDER=1): on the headline workload the
+ * ordered lanes measure the same as the unordered ones at N = 1 and 0.1 - 0.2 ms slower for one rank of eight
+ * (profiles/r05/lane_order.txt).  Replaces nothing in the reference (its analyses run one after the other:
+ * examples/Compute structural properties.py:58-118). */
+int amof_ctx_follow(amof_ctx *ctx, amof_ctx *other, int64_t min_calls, double timeout_s);
+/* calls of this context that have started device work so far (any thread may ask) */
+int64_t amof_ctx_calls(const amof_ctx *ctx);
 /* Diagnostics for the test-suite: fill every scratch buffer the context currently owns with `byte`
  * (after a synchronisation).  No call may depend on what a previous call left in scratch; a test
  * that poisons between calls turns such a dependence into a wrong answer instead of a lucky one. */

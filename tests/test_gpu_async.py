@@ -77,3 +77,43 @@ def test_library_errors_surface_at_access(hip_ctx):
     # the contexts are in working order afterwards
     ok = Rdf.from_trajectory(z, dr=0.05, rmax=2.0)
     assert len(ok.data) == int(2.0 // 0.05)
+
+
+def test_second_lane_queues_its_kernels_behind_the_rdf_launch(hip_ctx, monkeypatch):
+    """amof_ctx_follow (include/amof_hip.h): lane 1 waits until lane 0's pending job has queued its dominant kernel and
+    orders its stream behind it -- the MSD kernels run after the RDF tile kernel, not between its workgroups"""
+    import time
+    import torch
+    from amof_amd import _hip
+    from amof_amd.rdf import Rdf
+    from amof_amd.msd import WindowMsd
+    traj = H.device_walk(torch.device("cuda", 0), (2, 2, 2), 4000, 0.05, 78)       # an RDF of ~3 ms
+    torch.cuda.synchronize()
+    lane1 = _hip.get_context(0, lane=1)
+    assert lane1._follows is hip_ctx and hip_ctx._follows is None
+    assert lane1.device_calls() == int(lane1._lib.amof_ctx_calls(lane1._h))
+    monkeypatch.setenv("AMOF_LANE_ORDER", "1")                                     # (opt-in: profiles/r05/lane_order.txt)
+    alone = WindowMsd.from_trajectory(traj, delta_time=50, timestep=1)             # leader idle: nothing to follow
+    alone.data
+    t_alone = alone._stats["kernel_s_all"]
+    for rep in range(3):
+        c0 = hip_ctx.device_calls()
+        rdf = Rdf.from_trajectory(traj)
+        msd = WindowMsd.from_trajectory(traj, delta_time=50, timestep=1)
+        t0 = time.perf_counter()
+        assert np.array_equal(msd.sumsq, alone.sumsq)                              # (waits for the MSD: it ran behind the RDF)
+        waited = time.perf_counter() - t0
+        t_rdf = rdf._stats["kernel_s_dominant"]
+        assert hip_ctx.device_calls() == c0 + 1
+        assert waited > 0.5 * t_rdf, (waited, t_rdf)
+        # HIP events around the MSD's kernels: queued behind the stream order, they do not contain the tile kernel
+        assert msd._stats["kernel_s_all"] < max(4 * t_alone, 0.25 * t_rdf), (msd._stats, t_alone, t_rdf)
+    # the default, unordered lanes: results unchanged
+    monkeypatch.delenv("AMOF_LANE_ORDER")
+    rdf2 = Rdf.from_trajectory(traj)
+    msd2 = WindowMsd.from_trajectory(traj, delta_time=50, timestep=1)
+    assert np.array_equal(msd2.sumsq, alone.sumsq) and rdf2.data.equals(rdf.data)
+    # the C entry point: no host wait asked for -> ordered at once; a call number that never comes -> 0 after the timeout
+    assert lane1._lib.amof_ctx_follow(lane1._h, hip_ctx._h, 0, 0.0) == 1
+    assert lane1._lib.amof_ctx_follow(lane1._h, hip_ctx._h, hip_ctx.device_calls() + 5, 0.002) == 0
+    assert lane1._lib.amof_ctx_follow(lane1._h, lane1._h, 0, 0.0) == 1

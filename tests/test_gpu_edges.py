@@ -264,6 +264,26 @@ def test_permutation_and_frame_order_invariance(hip_ctx):
     assert np.array_equal(hip_ctx.rdf_accumulate(packed, 7.0, 350)[0], h0)
 
 
+@pytest.mark.parametrize("frames", [64, 69, 71, 79, 133])
+def test_frame_counts_that_do_not_divide_by_the_xcds(hip_ctx, frames):
+    """the tile kernel deals its frame chunks to the 8 XCDs and the frames % 8 behind them one grid row each
+    (csrc/rdf.hip rdf_tile_kernel_fast): every frame exactly once -- against the oracle, and added up over ranges that take the
+    unmapped grid (< 32 chunks)"""
+    import torch
+    packed = H.device_walk(torch.device("cuda", 0), (1, 2, 2), frames, 0.05, 77 + frames)       # 1088 atoms
+    rmax = float(np.min(packed.cell_lengths()) / 2)
+    nb = int(rmax // 0.02)
+    full, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+    assert hip_ctx.last_path().startswith("rdf_tile")
+    cut = frames - frames % 8 - 8
+    parts = hip_ctx.rdf_accumulate(packed, rmax, nb, frame_range=(0, cut))[0] + \
+        sum(hip_ctx.rdf_accumulate(packed, rmax, nb, frame_range=(k, min(k + 5, frames)))[0] for k in range(cut, frames, 5))
+    assert np.array_equal(parts, full)
+    with H_env(AMOF_RDF_NOTAIL="1"):
+        assert np.array_equal(hip_ctx.rdf_accumulate(packed, rmax, nb)[0], full)
+    assert np.array_equal(_oracle_rdf(packed, rmax, nb), full)
+
+
 def test_msd_atom_sharding_adds_up(hip_ctx):
     packed = H.random_walk(H.zif4_frame(), 30, 0.2, 14)
     w = np.arange(0, 15, 2)

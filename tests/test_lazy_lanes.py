@@ -147,3 +147,21 @@ def test_lane_runs_jobs_in_order_and_drain_waits():
     lane.submit(lambda: lane.drain())      # draining from the lane's own thread must not wait on itself
     lane.drain()
     lane.close_lane()
+
+
+def test_a_following_lane_without_a_gpu_context_runs_at_once():
+    """Lane.follow_leader is a GPU matter (amof_amd/_hip.py Context.follow_leader): the stand-in lanes of the CPU suite have
+    no leader, count their jobs all the same, and run a job as soon as it is submitted"""
+    from tests.oracle_context import OracleContext
+    lead, second = OracleContext("lead"), OracleContext("second")
+    assert second._follows is None and second.device_calls() == 0
+    import threading
+    gate = threading.Event()
+    f0 = lead.submit(lambda: gate.wait(5) and "lead done")
+    f1 = second.submit(lambda: "second done")
+    assert f1.result(timeout=5) == "second done" and not f0.done()
+    gate.set()
+    assert f0.result(timeout=5) == "lead done"
+    assert (lead._jobs_submitted, lead._jobs_started, lead._jobs_finished) == (1, 1, 1)
+    lead.close_lane()
+    second.close_lane()
