@@ -106,7 +106,7 @@ out = {"_comment": "HBM-side bytes per launch on the headline workload (9792 ato
                    "is. Infinity-Cache hits are included.", "cfg3": {}}
 if "rdf" in tables:
     out["cfg3"]["rdf_tile_kernel_fast"] = traffic(tables["rdf"], lambda k: k.startswith("rdf_tile_kernel_fast"))
-    out["cfg3"]["quantize_kernel"] = traffic(tables["rdf"], lambda k: k.startswith("quantize"))
+    out["cfg3"]["quantize_kernel"] = traffic(tables["rdf"], lambda k: k.startswith("quantize") or k.startswith("species_bytes"))
 if "msd" in tables:
     out["cfg3"]["msd_pipeline"] = traffic(tables["msd"], lambda k: True)
     out["cfg3"]["msd_kernels"] = {k: traffic(tables["msd"], lambda q, k=k: q == k) for k in tables["msd"]}

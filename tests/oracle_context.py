@@ -76,6 +76,7 @@ class OracleContext(_hip.Lane):
 def install(monkeypatch=None):
     """route `_hip.get_context` / `_hip.lane_context` to two oracle-backed lanes; returns them"""
     lanes = {0: OracleContext("oracle-lane-0"), 1: OracleContext("oracle-lane-1")}
+    lanes[1]._follows = lanes[0]            # (as _hip.get_context(device, lane=1) sets it: lane 1 follows lane 0)
 
     def lane_context(device, lane):
         from amof_amd import _lazy

@@ -104,6 +104,14 @@ def _worker_classes(rank, world, port, out_dir):
     assert all(o.__dict__.get("_pending") is not None for o in (rdf, msd, bad, cn))
     frames = {"cn": cn.data, "msd": msd.data, "rdf": rdf.data, "bad": bad.data}
     assert lanes[0].calls == ["rdf"] and lanes[1].calls == ["msd", "bad", "cn"]
+    # looking at the first lane's result first: the other lanes' pending results are merged before it, oldest first
+    # (amof_amd/_lazy.py Deferred._finish_followers_first) -- on every rank alike, or the collectives below would hang
+    rdf2 = Rdf.from_trajectory(packed, dr=0.05, rmax=6.0)
+    msd2 = WindowMsd.from_trajectory(packed, delta_time=2, timestep=1)
+    bad2 = Bad.from_trajectory(packed, {'Zn-N': 2.5}, dtheta=0.5)
+    assert rdf2.data.equals(frames["rdf"])
+    assert msd2.__dict__["_pending"] is None and bad2.__dict__["_pending"] is None
+    assert msd2.data.equals(frames["msd"]) and bad2.data.equals(frames["bad"])
     if rank == 0:
         for k, v in frames.items():
             v.to_pickle(os.path.join(out_dir, k + ".pkl"))

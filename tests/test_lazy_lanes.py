@@ -165,3 +165,42 @@ def test_a_following_lane_without_a_gpu_context_runs_at_once():
     assert (lead._jobs_submitted, lead._jobs_started, lead._jobs_finished) == (1, 1, 1)
     lead.close_lane()
     second.close_lane()
+
+
+def test_reading_the_first_lanes_result_finishes_the_other_lanes_first(monkeypatch):
+    """results merged in the calling thread (multi-rank runs): a look at the first lane's result first finishes the pending
+    results of the lanes that follow it, oldest first; what one of them raises stays with it"""
+    from amof_amd._lazy import Deferred
+    from tests.oracle_context import OracleContext
+    monkeypatch.setenv("AMOF_ASYNC", "1")
+    lead, second = OracleContext("lead"), OracleContext("second")
+    second._follows = lead
+
+    class Result(Deferred):
+        pass
+    order = []
+    a, b, c, d = Result(), Result(), Result(), Result()
+    b._defer(second, lambda: "b", lambda raw: order.append(raw), collective=True)
+    a._defer(lead, lambda: "a", lambda raw: order.append(raw), collective=True)
+
+    def boom(raw):
+        order.append(raw)
+        raise ValueError("c failed")
+    c._defer(second, lambda: "c", boom, collective=True)
+    d._defer(second, lambda: order.append("d (wholly on its lane)"), lambda raw: None, collective=False)
+    a.result()
+    assert [x for x in order if len(x) == 1] == ["b", "c", "a"]
+    assert b.__dict__["_pending"] is None and a.__dict__["_pending"] is None
+    for _ in range(2):
+        with pytest.raises(ValueError):
+            c.result()
+    assert [x for x in order if len(x) == 1] == ["b", "c", "a"]        # (the failed step is not run again)
+    # a follower's own reader finishes nothing else
+    e, f = Result(), Result()
+    e._defer(lead, lambda: "e", lambda raw: order.append(raw), collective=True)
+    f._defer(second, lambda: "f", lambda raw: order.append(raw), collective=True)
+    f.result()
+    assert e.__dict__["_pending"] is not None and order[-1] == "f"
+    e.result()
+    lead.close_lane()
+    second.close_lane()
