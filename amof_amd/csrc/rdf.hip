@@ -375,6 +375,30 @@ __device__ __forceinline__ bool near_pair(const float *near_f, int ix, int iy, i
     return (fabsf((float)ix) > near_f[0]) | (fabsf((float)iy) > near_f[1]) | (fabsf((float)iz) > near_f[2]);
 }
 
+// The always-add scheme's clamp (see fast_bin<AA>): out-of-range and dead candidates go to the trash words -- and, for
+// bin_count's conversion, candidates below a quarter of a bin are raised to 1/4 (such a pair is in bin 0 whatever a
+// refinement would say: its true q is < 1/4 + guard).  One v_med3_f32 where a v_min_f32 stood.
+__device__ __forceinline__ float clamp_candidate(float q, float clampv)
+{
+    return __builtin_amdgcn_fmed3f(q, 0.25f, clampv);
+}
+
+// hist[floor(q)] += 1 for a clamped candidate, 1/4 <= q < 2^20, without the half-rate conversion: 4 q - 1/2 + 2^23 (one fma,
+// one rounding; the sum lies in [2^23, 2^24), where floats are the integers) rounds to floor(4 q) -- a tie exists only where
+// 4 q is an integer, and goes to the even neighbour: 4 q itself or 4 q - 1, which lie above the same multiple of four unless q
+// is an integer, and there the even neighbour IS 4 q -- so the low bits of the sum are floor(4 q) and (bits & 0x7ffffc) is
+// the counter's byte offset 4 floor(q).  v_fmaak_f32 + v_and_b32 + v_add_u32 (2.2 issue cycles each) instead of
+// v_cvt_i32_f32 + v_lshl_add_u32 (4.1 each): the headline launch 72.0 -> 69.9 ms, the first move of this kernel since round 2
+// (profiles/r05/tile_bin_address.txt; round 3 had tried 4 q through the conversion and an integer mask: slower).
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+__device__ __forceinline__ void bin_count(unsigned *hist, float q)
+{
+    const unsigned base = (unsigned)(uintptr_t)(lds_u32 *)hist;          // (LDS addresses as 32-bit integers)
+    const unsigned off = __float_as_uint(fmaf(q, 4.0f, 8388607.5f)) & 0x007ffffcu;
+    lds_u32 *p = (lds_u32 *)(uintptr_t)(base + off);
+    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <bool ORTHO, bool IMG = false, bool ZF = false, bool AA = false>
 __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool live, float half_m_guard,
                                          float nb_hi, uint32_t uix, uint32_t uiy, uint32_t uiz, uint4 qj,
@@ -399,9 +423,9 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
         // is exactly "in range and within the guard of a bin edge"; such a pair has been counted provisionally and
         // rdf_pair_refine<PROV> takes that count back before it adds the exact one.
         if (!live_all) q = live ? q : __builtin_inff();
-        q = __builtin_fminf(q, clampv);
+        q = clamp_candidate(q, clampv);
         const bool unsafe = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
-        atomicAdd(&hist[(int)q], 1u);
+        bin_count(hist, q);
         return unsafe;
     }
     const bool in = live && (q < nb_hi);
@@ -573,11 +597,11 @@ __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, co
     const float fy = (float)iy;
     q = NEAR == 4 ? tri_q_twin<XW>(sc, tc.c10, ix, fy, dz) : tri_q<XW>(sc, tc.c10, ix, fy, dz);
     if (!live_all) q = live ? q : __builtin_inff();
-    q = __builtin_fminf(q, clampv);
+    q = clamp_candidate(q, clampv);
     bool flag = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
     if (NEAR == 2) flag |= live && (fabsf(fy) > tc.near_y);
     if (NEAR == 3) flag |= live && ((fabsf(fy) > tc.near_y) | (fabsf(dz) > tc.near_z));
-    atomicAdd(&hist[(int)q], 1u);
+    bin_count(hist, q);
     return flag;
 }
 
@@ -725,13 +749,14 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const RdfArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // double-buffered tiles: J (512 entries) and the centre sub-tile (128 entries)
-    uint4 *tqb = reinterpret_cast<uint4 *>(lds_raw);                         // [2][FAST_TILE]
+    // (the histogram first: bin_count forms LDS byte addresses from the candidate's bits)
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);                  // [nbins + trash], padded to 16 bytes
+    uint4 *tqb = reinterpret_cast<uint4 *>(hist + ((fa.a.nbins + FAST_TRASH + 2 + 3) & ~3));      // [2][FAST_TILE]
     uint4 *tcb = tqb + 2 * FAST_TILE;                                        // [2][FAST_SUB]
-    unsigned *hist = reinterpret_cast<unsigned *>(tcb + 2 * FAST_SUB);       // [nbins]
     // IMG: queue of the pairs that need the canonical evaluation (drained densely once per step), two counters
     // (two buffers: a step parks into one while the previous step's is drained; three counters so that one can be
     // reset a whole step away from its last reader and its next writer)
-    uint2 *nq_base = reinterpret_cast<uint2 *>(hist + ((fa.a.nbins + FAST_TRASH + 1) & ~1));   // [2][img_queue]
+    uint2 *nq_base = reinterpret_cast<uint2 *>(tcb + 2 * FAST_SUB);                             // [2][img_queue]
     const unsigned nq_cap = (unsigned)fa.img_queue;
     __shared__ unsigned nq_count[3];
 
@@ -2027,7 +2052,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
             AMOF_TRY(ensure(ctx, SLOT_FLAGS, sizeof(int32_t), &d_flag));
             AMOF_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int32_t), ctx->stream));
             fa.Q = (const QAtom *)d_Q;
-            size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)(nbins + FAST_TRASH) * sizeof(unsigned);
+            size_t lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 2 + 3) & ~3) * sizeof(unsigned);
             fa.img_queue = 0;
             fa.img_defer = 0;
             const double *d_fold = nullptr;
@@ -2085,7 +2110,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 const double want = std::max(96.0, ceil(4.0 * expect / 32.0) * 32.0);
                 ft.img_defer = want <= 256.0 ? 1 : 0;
                 ft.img_queue = ft.img_defer ? (int32_t)want : IMG_QUEUE_MAX;
-                lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 1) & ~1) * sizeof(unsigned) +
+                lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 2 + 3) & ~3) * sizeof(unsigned) +
                       (ft.img_defer ? 2 : 1) * (size_t)ft.img_queue * sizeof(uint2);
             }
             if (fast_img) {
@@ -2096,7 +2121,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 const double want = std::max(96.0, ceil(4.0 * expect / 32.0) * 32.0);
                 fa.img_defer = want <= 256.0 ? 1 : 0;
                 fa.img_queue = fa.img_defer ? (int32_t)want : IMG_QUEUE_MAX;
-                lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 1) & ~1) * sizeof(unsigned) +
+                lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 2 + 3) & ~3) * sizeof(unsigned) +
                       (fa.img_defer ? 2 : 1) * (size_t)fa.img_queue * sizeof(uint2);
             }
             int64_t launches = 0;
