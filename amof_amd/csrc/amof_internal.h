@@ -116,6 +116,17 @@ inline hipError_t allow_max_lds(const void *kern)
     return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, per_block - (int)attr.sharedSizeBytes);
 }
 
+// the same for a kernel that takes its dynamic LDS to start at LDS address 0 (rdf_tile_kernel_fast forms histogram addresses
+// from integers: bin_count): refused -- loudly, hipErrorInvalidValue -- if the kernel has static LDS in front of it
+inline hipError_t allow_max_lds_from_zero(const void *kern)
+{
+    hipFuncAttributes attr;
+    hipError_t e = hipFuncGetAttributes(&attr, kern);
+    if (e != hipSuccess) return e;
+    if (attr.sharedSizeBytes != 0) return hipErrorInvalidValue;
+    return allow_max_lds(kern);
+}
+
 // --------------------------------------------------------------- geometry --
 // One record per distinct cell: 24 doubles.
 //   [0..8]  cell rows          [9..17] cell^-1 with non-periodic columns zeroed

@@ -387,15 +387,17 @@ __device__ __forceinline__ float clamp_candidate(float q, float clampv)
 // one rounding; the sum lies in [2^23, 2^24), where floats are the integers) rounds to floor(4 q) -- a tie exists only where
 // 4 q is an integer, and goes to the even neighbour: 4 q itself or 4 q - 1, which lie above the same multiple of four unless q
 // is an integer, and there the even neighbour IS 4 q -- so the low bits of the sum are floor(4 q) and (bits & 0x7ffffc) is
-// the counter's byte offset 4 floor(q).  v_fmaak_f32 + v_and_b32 + v_add_u32 (2.2 issue cycles each) instead of
-// v_cvt_i32_f32 + v_lshl_add_u32 (4.1 each): the headline launch 72.0 -> 69.9 ms, the first move of this kernel since round 2
+// the counter's byte offset 4 floor(q).  v_fmaak_f32 + v_and_b32 (2.2 issue cycles each) instead of v_cvt_i32_f32 +
+// v_lshl_add_u32 (4.1 each): the headline launch 72.0 -> 69.9 ms with the base still added, the first move of this kernel since round 2
 // (profiles/r05/tile_bin_address.txt; round 3 had tried 4 q through the conversion and an integer mask: slower).
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 __device__ __forceinline__ void bin_count(unsigned *hist, float q)
 {
-    const unsigned base = (unsigned)(uintptr_t)(lds_u32 *)hist;          // (LDS addresses as 32-bit integers)
+    // (the histogram is the first thing in the kernel's dynamic LDS and the kernel has no static LDS: its byte offset IS its
+    //  LDS address -- checked on the host before every launch, allow_max_lds_from_zero -- so no base is added)
+    (void)hist;
     const unsigned off = __float_as_uint(fmaf(q, 4.0f, 8388607.5f)) & 0x007ffffcu;
-    lds_u32 *p = (lds_u32 *)(uintptr_t)(base + off);
+    lds_u32 *p = (lds_u32 *)(uintptr_t)off;
     __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -758,7 +760,9 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     // reset a whole step away from its last reader and its next writer)
     uint2 *nq_base = reinterpret_cast<uint2 *>(tcb + 2 * FAST_SUB);                             // [2][img_queue]
     const unsigned nq_cap = (unsigned)fa.img_queue;
-    __shared__ unsigned nq_count[3];
+    // (the three counters behind the queue, in the dynamic LDS like everything else: the kernel has NO static LDS, so that
+    //  the dynamic part starts at LDS address 0 -- bin_count)
+    unsigned *nq_count = reinterpret_cast<unsigned *>(nq_base + (size_t)(fa.img_defer ? 2 : 1) * nq_cap);        // [3]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: the quad loops below count in SGPRs)
@@ -2111,7 +2115,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 ft.img_defer = want <= 256.0 ? 1 : 0;
                 ft.img_queue = ft.img_defer ? (int32_t)want : IMG_QUEUE_MAX;
                 lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 2 + 3) & ~3) * sizeof(unsigned) +
-                      (ft.img_defer ? 2 : 1) * (size_t)ft.img_queue * sizeof(uint2);
+                      (ft.img_defer ? 2 : 1) * (size_t)ft.img_queue * sizeof(uint2) + 16;
             }
             if (fast_img) {
                 // expected number of parked pairs per step (a step is 128 x 512 pairs).  Slightly sheared cells: two
@@ -2122,7 +2126,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 fa.img_defer = want <= 256.0 ? 1 : 0;
                 fa.img_queue = fa.img_defer ? (int32_t)want : IMG_QUEUE_MAX;
                 lds = 2 * (FAST_TILE + FAST_SUB) * sizeof(uint4) + (size_t)((nbins + FAST_TRASH + 2 + 3) & ~3) * sizeof(unsigned) +
-                      (fa.img_defer ? 2 : 1) * (size_t)fa.img_queue * sizeof(uint2);
+                      (fa.img_defer ? 2 : 1) * (size_t)fa.img_queue * sizeof(uint2) + 16;
             }
             int64_t launches = 0;
             for (int64_t fb = 0; fb < t->n_frames; fb += cur, cur = std::min<int64_t>(2 * cur, FB)) {
@@ -2155,7 +2159,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 dim3 grid((unsigned)fpairs.size(), (unsigned)(chunks + nf_tail));
                 if (launches == 0) timing_dom_begin(ctx, tri ? "rdf_tile_tri" : fast_img ? "rdf_tile_img" : use_zf ? "rdf_tile_zf" : "rdf_tile");
                 auto launch = [&](auto kern) -> hipError_t {
-                    hipError_t e2 = allow_max_lds((const void *)kern);
+                    hipError_t e2 = allow_max_lds_from_zero((const void *)kern);
                     if (e2 != hipSuccess) return e2;
                     hipLaunchKernelGGL(kern, grid, dim3(FAST_THREADS), lds, ctx->stream, fa);
                     return hipSuccess;
@@ -2165,7 +2169,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     ft.Q = fa.Q; ft.f_base = fa.f_base; ft.nf = fa.nf; ft.xcd_map = fa.xcd_map; ft.n_chunks = fa.n_chunks; ft.nf_main = fa.nf_main;
                     ft.a.frames_per_chunk = fa.a.frames_per_chunk;
                     auto launch_tri = [&](auto kern) -> hipError_t {
-                        hipError_t e2 = allow_max_lds((const void *)kern);
+                        hipError_t e2 = allow_max_lds_from_zero((const void *)kern);
                         if (e2 != hipSuccess) return e2;
                         hipLaunchKernelGGL(kern, grid, dim3(FAST_THREADS), lds, ctx->stream, ft);
                         return hipSuccess;
@@ -2196,8 +2200,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     RdfFastArgs fz = fa;
                     fz.nb_hi = zf_nb_hi;
                     fz.half_m_guard = zf_half_m_guard;
-                    hipError_t e2 = cull ? allow_max_lds((const void *)rdf_tile_kernel_fast<true, true, false, true>)
-                                         : allow_max_lds((const void *)rdf_tile_kernel_fast<true, false, false, true>);
+                    hipError_t e2 = cull ? allow_max_lds_from_zero((const void *)rdf_tile_kernel_fast<true, true, false, true>)
+                                         : allow_max_lds_from_zero((const void *)rdf_tile_kernel_fast<true, false, false, true>);
                     if (e2 == hipSuccess && cull)
                         hipLaunchKernelGGL((rdf_tile_kernel_fast<true, true, false, true>), grid, dim3(FAST_THREADS), lds,
                                            ctx->stream, fz);
