@@ -6,7 +6,10 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/amof_hip.h"
@@ -101,30 +104,46 @@ int ensure(amof_ctx *ctx, Slot s, size_t bytes, void **out);
     } while (0)
 
 // Raise a kernel's dynamic-LDS cap to everything a workgroup may have besides the kernel's static
-// LDS.  The value depends on the kernel only, not on the launch, so contexts used from different
-// threads cannot undercut each other by setting it for the same kernel.
-inline hipError_t allow_max_lds(const void *kern)
+// LDS.  The value depends on the kernel (and the device) only, not on the launch, so contexts used from different
+// threads cannot undercut each other by setting it for the same kernel -- and it is set once per kernel and device:
+// the three runtime calls cost ~10 us, per launch, in front of kernels that one rank of eight runs for 9 ms.
+// *static_bytes (optional): the kernel's static LDS.
+inline hipError_t allow_max_lds(const void *kern, size_t *static_bytes = nullptr)
 {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> done;
     int dev = 0, per_block = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = done.find(std::make_pair(kern, dev));
+        if (it != done.end()) {
+            if (static_bytes) *static_bytes = it->second;
+            return hipSuccess;
+        }
+    }
     e = hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
     if (e != hipSuccess) return e;
     hipFuncAttributes attr;
     e = hipFuncGetAttributes(&attr, kern);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, per_block - (int)attr.sharedSizeBytes);
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, per_block - (int)attr.sharedSizeBytes);
+    if (e != hipSuccess) return e;
+    if (static_bytes) *static_bytes = attr.sharedSizeBytes;
+    std::lock_guard<std::mutex> lock(mu);
+    done[std::make_pair(kern, dev)] = attr.sharedSizeBytes;
+    return hipSuccess;
 }
 
 // the same for a kernel that takes its dynamic LDS to start at LDS address 0 (rdf_tile_kernel_fast forms histogram addresses
 // from integers: bin_count): refused -- loudly, hipErrorInvalidValue -- if the kernel has static LDS in front of it
 inline hipError_t allow_max_lds_from_zero(const void *kern)
 {
-    hipFuncAttributes attr;
-    hipError_t e = hipFuncGetAttributes(&attr, kern);
+    size_t static_bytes = 0;
+    hipError_t e = allow_max_lds(kern, &static_bytes);
     if (e != hipSuccess) return e;
-    if (attr.sharedSizeBytes != 0) return hipErrorInvalidValue;
-    return allow_max_lds(kern);
+    return static_bytes == 0 ? hipSuccess : hipErrorInvalidValue;
 }
 
 // --------------------------------------------------------------- geometry --

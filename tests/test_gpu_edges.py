@@ -61,6 +61,30 @@ def test_ragged_tile_sizes(hip_ctx, n_atoms):
     assert np.array_equal(h, _oracle_rdf(packed, 4.5, 450))
 
 
+@pytest.mark.parametrize("env", [None, ("AMOF_QUANT_NOSTAGE", "1"), ("AMOF_QUANT_PER_SPECIES", "1")])
+def test_species_segments_longer_than_the_quantisers_stage(hip_ctx, monkeypatch, env):
+    """quantize_frame_kernel (csrc/quant.hip) places a species' records through an LDS stage of 4608 records and scatters a
+    longer segment directly; 5200 atoms of one species beside two short ones, RDF and neighbour counts against the oracle
+    (and the same with the stage switched off, and through the per-species kernel)"""
+    if env:
+        monkeypatch.setenv(*env)
+    rng = np.random.default_rng(5200)
+    numbers = np.concatenate([np.full(5200, 18), np.full(300, 8), np.full(7, 30)])
+    rng.shuffle(numbers)
+    packed = H.random_gas(len(numbers), [38.0, 41.0, 44.0], numbers, 52, F=2)
+    h, _, _ = hip_ctx.rdf_accumulate(packed, 19.0, 380)
+    assert hip_ctx.last_path().startswith("rdf_tile")
+    kinds, sp = H.species_of(packed.numbers)
+    ref = clib.rdf_hist(packed.pos_host(), packed.cell, sp, len(kinds), 19.0, 380, cell_list=True)[0]
+    assert np.array_equal(h, ref)
+    rcm = np.zeros((3, 3))
+    rcm[kinds.index(18), kinds.index(18)] = 3.1
+    rcm[kinds.index(8), kinds.index(18)] = rcm[kinds.index(18), kinds.index(8)] = 3.4
+    sets = [(kinds.index(18), kinds.index(18)), (kinds.index(8), kinds.index(18))]
+    got = hip_ctx.cn_count(packed, rcm, sets)
+    assert np.array_equal(got, clib.cn_counts(packed.pos_host(), packed.cell, sp, 3, rcm, sets))
+
+
 def test_empty_inputs(hip_ctx):
     z = H.zif4_frame()
     empty = PackedTrajectory(np.zeros((0, 272, 3)), z.cell, z.numbers)
