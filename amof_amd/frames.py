@@ -14,6 +14,8 @@ this package is built and tested, so two carriers are defined here:
   (host) or a torch CUDA tensor (already resident in HBM).
 """
 
+import os
+
 import numpy as np
 
 from . import data as _data
@@ -366,6 +368,30 @@ def _gpu_for_uploads(device):
     return torch
 
 
+# Two page-locked staging buffers, kept for the process: locking 2 x 48 MB of pages costs ~10 ms -- per upload, when every
+# ResidentCopy allocated its own.  One upload at a time borrows them; a concurrent one allocates its own pair.
+_STAGING = []
+_STAGING_LOCK = None
+
+
+def _staging_slots(torch, n_doubles):
+    """(two pinned float64 buffers of >= n_doubles elements, borrowed?) -- borrowed ones are returned by releasing
+    _STAGING_LOCK when the upload is through"""
+    global _STAGING_LOCK
+    import threading
+    if _STAGING_LOCK is None:
+        _STAGING_LOCK = threading.Lock()
+    if _STAGING_LOCK.acquire(False):
+        try:
+            if not _STAGING or _STAGING[0].numel() < n_doubles:
+                _STAGING[:] = [torch.empty(n_doubles, dtype=torch.float64, pin_memory=True) for _ in range(2)]
+            return list(_STAGING), True
+        except BaseException:
+            _STAGING_LOCK.release()
+            raise
+    return [torch.empty(n_doubles, dtype=torch.float64, pin_memory=True) for _ in range(2)], False
+
+
 class ResidentCopy(object):
     """The device copy of a HOST trajectory, filled in frame order while its first analyses already run.
 
@@ -404,20 +430,45 @@ class ResidentCopy(object):
 
     # -- producer -------------------------------------------------------------------------------------------------------
     def _run(self):
+        lent = False
         try:
             torch = self._torch
             F = self.n_frames
             # through two page-locked staging buffers (a pageable hipMemcpyAsync blocks the caller and
             # runs at a fraction of the link rate)
-            slots = [torch.empty((self.chunk, self.n_atoms, 3), dtype=torch.float64, pin_memory=True) for _ in range(2)]
+            slots, lent = _staging_slots(torch, self.chunk * self.n_atoms * 3)
+            slots = [b[:self.chunk * self.n_atoms * 3].view(self.chunk, self.n_atoms, 3) for b in slots]
             busy = [None, None]
             src = self.packed.pos
+            # the copy into the staging buffer on several cores (amof_pack_frames with the frames of the contiguous array
+            # as its "list"): one core moves 48 MB in ~4 ms, 1.2 GB in ~100 -- longer than the RDF needs for the frames, which
+            # then waited for the upload; the DMA itself takes 1 - 2 ms per chunk
+            copy = None
+            if src.flags.c_contiguous and src.dtype == np.float64 and self.n_atoms > 0:
+                try:
+                    import ctypes
+                    from . import _hip
+                    lib = _hip.load_library()
+                    ptrs = (np.uint64(src.__array_interface__["data"][0]) +
+                            np.arange(F, dtype=np.uint64) * np.uint64(24 * self.n_atoms))
+                    threads = max(1, int(os.environ.get("AMOF_UPLOAD_THREADS", 0)) or min(8, _usable_cpus() // 2))
+
+                    def copy(dst, f0, f1):
+                        rc = lib.amof_pack_frames(ctypes.c_void_p(ptrs[f0:f1].ctypes.data), f1 - f0, self.n_atoms,
+                                                  ctypes.c_void_p(dst.data_ptr()), None, threads)
+                        if rc != 0:
+                            raise RuntimeError("amof_pack_frames failed (%d)" % rc)
+                except Exception:
+                    copy = None
             for q, f0 in enumerate(range(0, F, self.chunk)):
                 f1 = min(F, f0 + self.chunk)
                 j = q % 2
                 if busy[j] is not None:
                     busy[j].synchronize()
-                np.copyto(slots[j].numpy()[:f1 - f0], src[f0:f1])
+                if copy is not None:
+                    copy(slots[j], f0, f1)
+                else:
+                    np.copyto(slots[j].numpy()[:f1 - f0], src[f0:f1])
                 with torch.cuda.stream(self.stream):
                     self.dev[f0:f1].copy_(slots[j][:f1 - f0], non_blocking=True)
                     ev = torch.cuda.Event()
@@ -433,6 +484,12 @@ class ResidentCopy(object):
             with self._cond:
                 self._error = exc
                 self._cond.notify_all()
+        finally:
+            if lent:                        # (nothing of this upload may still read the borrowed buffers)
+                try:
+                    self.stream.synchronize()
+                finally:
+                    _STAGING_LOCK.release()
 
     # -- consumers ------------------------------------------------------------------------------------------------------
     def _wait_frames(self, f1):
@@ -467,17 +524,33 @@ class ResidentCopy(object):
 
     def _piece(self, f0, f1):
         cell = self.cell if self.cell.shape[0] == 1 else self.cell[f0:f1]
-        return PackedTrajectory(self.dev[f0:f1], cell, self.numbers, self.masses, self.pbc)
+        piece = PackedTrajectory(self.dev[f0:f1], cell, self.numbers, self.masses, self.pbc)
+        # (what depends on the atoms only is computed once, for the trajectory, not per batch)
+        if "_abi_species" not in self.packed.__dict__:
+            from . import _hip
+            _hip.packed_species(self.packed)
+        self.packed.__dict__.setdefault("_const_cache", {})
+        for key in ("_const_cache", "_abi_species"):
+            if key in self.packed.__dict__:
+                piece.__dict__[key] = self.packed.__dict__[key]
+        return piece
 
     def batches(self):
         """device-resident pieces in frame order, each as soon as it has arrived"""
         F = self.n_frames
         f0 = 0
         while f0 < F:
-            f1 = min(F, f0 + self.PIECE_FRAMES)
+            # (the first batch: one staging chunk -- the analysis starts ~3 ms after the upload instead of ~8)
+            f1 = min(F, f0 + (self.PIECE_FRAMES if f0 else min(self.PIECE_FRAMES, self.chunk)))
+            # more has ARRIVED meanwhile (its copy is complete, not merely queued: waiting for the chunk in flight cost ~1 ms of
+            # idle GPU between two batches): take it all in one batch
             with self._cond:
-                have = max([u for u, _ in self._marks] + [0])
-            if have > f1:               # more has arrived meanwhile: take it all in one batch
+                marks = list(self._marks)
+            have = 0
+            for upto, ev in marks:
+                if upto > have and ev.query():
+                    have = upto
+            if have > f1:
                 f1 = have
             self._wait_frames(f1)
             yield self._piece(f0, f1)
