@@ -436,7 +436,14 @@ __device__ __forceinline__ bool fast_bin(unsigned *hist, const float *sc, bool l
     return in && !safe;
 }
 
-template <bool ORTHO, bool DIAG, bool TAIL, bool IMG = false, bool ZF = false, bool ZFK = false, bool AA = false>
+// a lane's two-deep queue of pairs that wait for their refinement (PARK; see fast_quad)
+struct LaneQueue {
+    unsigned pk0, pk1;      // (partner index in tile J) << 1 | (centre b?); QUEUE_EMPTY: free
+    float pq0, pq1;         // the pair's clamped f32 candidate
+};
+constexpr unsigned QUEUE_EMPTY = 0xffffffffu;
+
+template <bool ORTHO, bool DIAG, bool TAIL, bool IMG = false, bool ZF = false, bool ZFK = false, bool AA = false, bool PARK = false>
 __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa, const double *sc64,
                                           const double *__restrict__ g, const float *sc, const uint4 *tq,
                                           int j0, int cntj, bool has_a, bool has_b, int ia, int ib,
@@ -446,7 +453,7 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
                                           const float *near_f = nullptr, int gi = 0, uint2 *nq = nullptr,
                                           unsigned *nq_count = nullptr, unsigned nq_cap = 0,
                                           float zaf = 0.0f, float zbf = 0.0f, const QAtom *__restrict__ qseg = nullptr,
-                                          float clampv = 0.0f)
+                                          float clampv = 0.0f, LaneQueue *lq = nullptr)
 {
     // ZF: this step uses the f32 slab coordinates; ZFK: the kernel is a ZF kernel (the .w of the LDS copies may have
     // been overwritten by an earlier step of the frame: atom indices always come from the quantised frame)
@@ -471,10 +478,36 @@ __device__ __forceinline__ void fast_quad(unsigned *hist, const RdfFastArgs &fa,
         anynear |= ma | mb;
     }
     if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {   // a few % of the pairs
+        if (PARK) {
+            // PARK: a flagged pair waits in its lane's two-deep register queue for the end of the step, where ONE body per
+            // queue level serves every lane that has an entry (half the lanes at the first level) -- instead of one body per
+            // pair slot of every quad that has a flagged lane (~0.5 bodies of ~100 issue cycles per quad, each for one or two
+            // live lanes).  A lane whose queue is full keeps the old way for that pair (ovf).
+            unsigned ovf = 0u;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (na[u]) rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qa[u], uax, uay, uaz, qj[u], p, ida, qseg, j0 + u);
-            if (nb[u]) rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qb[u], ubx, uby, ubz, qj[u], p, idb, qseg, j0 + u);
+            for (int u = 0; u < 4; u++) {
+                if (na[u]) {
+                    if (lq->pk1 != QUEUE_EMPTY) ovf |= 1u << (2 * u);
+                    else { lq->pk1 = lq->pk0; lq->pq1 = lq->pq0; lq->pk0 = (unsigned)(j0 + u) << 1; lq->pq0 = qa[u]; }
+                }
+                if (nb[u]) {
+                    if (lq->pk1 != QUEUE_EMPTY) ovf |= 2u << (2 * u);
+                    else { lq->pk1 = lq->pk0; lq->pq1 = lq->pq0; lq->pk0 = ((unsigned)(j0 + u) << 1) | 1u; lq->pq0 = qb[u]; }
+                }
+            }
+            if (ovf) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (ovf & (1u << (2 * u))) rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qa[u], uax, uay, uaz, qj[u], p, ida, qseg, j0 + u);
+                    if (ovf & (2u << (2 * u))) rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qb[u], ubx, uby, ubz, qj[u], p, idb, qseg, j0 + u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (na[u]) rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qa[u], uax, uay, uaz, qj[u], p, ida, qseg, j0 + u);
+                if (nb[u]) rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qb[u], ubx, uby, ubz, qj[u], p, idb, qseg, j0 + u);
+            }
         }
     }
     if (IMG) {
@@ -746,6 +779,9 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     // general-cell variant spills under it (nine scales, 96 VGPRs) and keeps the masked form
     constexpr bool AA = ORTHO || IMG;
     constexpr bool QUEUE = IMG || TRI >= 0;     // parked pairs, drained densely by the canonical arithmetic
+    // flagged pairs wait in per-lane register queues for the end of the step (fast_quad): the diagonal-cell kernels.  68.6 ->
+    // 67.0 ms per headline launch -- the first parking scheme that pays (seven with LDS queues lost: profiles/r04/rdf_tile_stop.txt)
+    constexpr bool PARK = ORTHO && ZFK && !IMG && TRI < 0 && AA;
     constexpr int NEAR = TRI >= 0 ? TRI % 5 : 0;
     constexpr bool XW = TRI >= 5;
     const RdfArgs &a = fa.a;
@@ -1039,6 +1075,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         const QAtom *__restrict__ qseg = fa.Q + (size_t)fl * (size_t)a.N + tj.start;
+        LaneQueue lq = {QUEUE_EMPTY, QUEUE_EMPTY, 0.0f, 0.0f};
         auto run = [&](auto zf_tag, const int *qbr, const int *qer) {
             constexpr bool ZF = decltype(zf_tag)::value;
 #pragma unroll 1
@@ -1071,27 +1108,43 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                 }
                 if (diag) {
                     for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
-                        fast_quad<ORTHO, true, true, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
+                        fast_quad<ORTHO, true, true, IMG, ZF, ZFK, AA, PARK>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
                                                                    half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
                                                                    idb, p, near_f, gi, nq, &nq_count[step % 3], nq_cap, zaf,
-                                                                   zbf, qseg, clampv);
+                                                                   zbf, qseg, clampv, &lq);
                 } else {
                     int j0 = qb + 4 * wave;
                     for (; j0 < qe_full; j0 += 16)
-                        fast_quad<ORTHO, false, false, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
+                        fast_quad<ORTHO, false, false, IMG, ZF, ZFK, AA, PARK>(hist, fa, sc64, g, sc, tq, j0, cntj, has_a, has_b, ia, ib,
                                                                      half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
                                                                      idb, p, near_f, gi, nq, &nq_count[step % 3], nq_cap,
-                                                                     zaf, zbf, qseg, clampv);
+                                                                     zaf, zbf, qseg, clampv, &lq);
                     if (j0 == full && j0 < qe && full < cntj)
-                        fast_quad<ORTHO, false, true, IMG, ZF, ZFK, AA>(hist, fa, sc64, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
+                        fast_quad<ORTHO, false, true, IMG, ZF, ZFK, AA, PARK>(hist, fa, sc64, g, sc, tq, full, cntj, has_a, has_b, ia, ib,
                                                                     half_m_guard, nb_hi, uax, uay, uaz, ida, ubx, uby, ubz,
                                                                     idb, p, near_f, gi, nq, &nq_count[step % 3], nq_cap, zaf,
-                                                                    zbf, qseg, clampv);
+                                                                    zbf, qseg, clampv, &lq);
                 }
             }
         };
         if (ZFK && zf) run(std::true_type{}, zqb, zqe);
         run(std::false_type{}, iqb, iqe);
+        if (PARK) {
+            // the step's parked pairs: one refinement body per queue level, for every lane that has an entry there (the
+            // partner's record from the tile's LDS copy again, the centre by the entry's low bit)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const unsigned code = k == 0 ? lq.pk0 : lq.pk1;
+                const float qk = k == 0 ? lq.pq0 : lq.pq1;
+                if (code != QUEUE_EMPTY) {
+                    const int j = (int)(code >> 1);
+                    const bool isb = (code & 1u) != 0u;
+                    const uint4 qr = tq[j];
+                    rdf_pair_refine<ORTHO, ZFK, AA>(hist, fa, sc64, g, qk, isb ? ubx : uax, isb ? uby : uay, isb ? ubz : uaz, qr, p,
+                                                    isb ? idb : ida, qseg, j);
+                }
+            }
+        }
         if (QUEUE && !fa.img_defer) {
             // large shares: dense canonical pass over this step's parked pairs right away (one more barrier per step)
             __syncthreads();

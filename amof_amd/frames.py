@@ -15,6 +15,7 @@ this package is built and tested, so two carriers are defined here:
 """
 
 import os
+import threading
 
 import numpy as np
 
@@ -371,16 +372,12 @@ def _gpu_for_uploads(device):
 # Two page-locked staging buffers, kept for the process: locking 2 x 48 MB of pages costs ~10 ms -- per upload, when every
 # ResidentCopy allocated its own.  One upload at a time borrows them; a concurrent one allocates its own pair.
 _STAGING = []
-_STAGING_LOCK = None
+_STAGING_LOCK = threading.Lock()
 
 
 def _staging_slots(torch, n_doubles):
     """(two pinned float64 buffers of >= n_doubles elements, borrowed?) -- borrowed ones are returned by releasing
     _STAGING_LOCK when the upload is through"""
-    global _STAGING_LOCK
-    import threading
-    if _STAGING_LOCK is None:
-        _STAGING_LOCK = threading.Lock()
     if _STAGING_LOCK.acquire(False):
         try:
             if not _STAGING or _STAGING[0].numel() < n_doubles:
