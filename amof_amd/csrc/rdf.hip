@@ -866,6 +866,11 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     const double *p_prev = nullptr, *g_prev = nullptr;
     int gi_prev = 0;
     if (nsteps > 0) { stage_j(f0, 0); stage_c(f0, 0, 0); }
+    float sc[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    double sc64r[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    TriConst trc = {0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u};
+    float near_f[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    uint32_t cull_gap = 0u;
     for (int step = 0, fl = f0, sub = 0; step < nsteps; step++) {
         const int jb = (fl - f0) & 1, cbuf = step & 1;
         const int cnti = min(FAST_SUB, ti.count - sub * FAST_SUB);     // centre atoms of this sub-tile
@@ -877,39 +882,38 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
         const int gi = a.n_cells == 1 ? 0 : f;
         const FrameScale *__restrict__ fs = fa.fs + gi;
         const double *__restrict__ g = a.geom + (size_t)gi * GEOM_STRIDE;
-        float sc[9];      // wave-uniform: keep them in scalar registers
+        // wave-uniform per-cell constants: kept in scalar registers; a constant cell's are read once, at the first step
+        // (per step they cost ~20 v_readfirstlane and a global-memory latency at the head of every step)
+        if (step == 0 || a.n_cells != 1) {
+            cull_gap = __builtin_amdgcn_readfirstlane(fs->cull_gap);
 #pragma unroll
-        for (int k = 0; k < 9; k++)
-            sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
-        // the f64 scales of the level-2 refinement: diagonal cells keep their three in scalar registers (a vector load
-        // at the head of every refinement visit costs a memory latency each time)
-        double sc64r[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (ORTHO) {
+            for (int k = 0; k < 9; k++)
+                sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
+            // the f64 scales of the level-2 refinement: diagonal cells keep their three in scalar registers (a vector load
+            // at the head of every refinement visit costs a memory latency each time)
+            if (ORTHO) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) sc64r[k] = uniform_f64(fs->sc64[k]);
-        }
-        if (TRI >= 0) {     // L00, L10, L11, L22 of the level-2 form (rdf_pair_refine_tri): a load at the head of every visit would cost its latency
-            sc64r[0] = uniform_f64(fs->sc64[0]); sc64r[3] = uniform_f64(fs->sc64[3]);
-            sc64r[4] = uniform_f64(fs->sc64[4]); sc64r[8] = uniform_f64(fs->sc64[8]);
-        }
-        const double *sc64 = (ORTHO || TRI >= 0) ? sc64r : fs->sc64;
-        TriConst trc = {0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u};
-        if (TRI >= 0) {
-            trc.c10 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_c10)));
-            trc.near_y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_y)));
-            trc.near_z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_z)));
-            trc.near_x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_x)));
-            trc.kx = __builtin_amdgcn_readfirstlane(fs->tri_kx);
-            trc.ky = __builtin_amdgcn_readfirstlane(fs->tri_ky);
-        }
-        float near_f[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-        if (IMG) {
+                for (int k = 0; k < 3; k++) sc64r[k] = uniform_f64(fs->sc64[k]);
+            }
+            if (TRI >= 0) {     // L00, L10, L11, L22 of the level-2 form (rdf_pair_refine_tri): a load at the head of every visit would cost its latency
+                sc64r[0] = uniform_f64(fs->sc64[0]); sc64r[3] = uniform_f64(fs->sc64[3]);
+                sc64r[4] = uniform_f64(fs->sc64[4]); sc64r[8] = uniform_f64(fs->sc64[8]);
+                trc.c10 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_c10)));
+                trc.near_y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_y)));
+                trc.near_z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_z)));
+                trc.near_x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->tri_near_x)));
+                trc.kx = __builtin_amdgcn_readfirstlane(fs->tri_kx);
+                trc.ky = __builtin_amdgcn_readfirstlane(fs->tri_ky);
+            }
+            if (IMG) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const uint32_t tk = __builtin_amdgcn_readfirstlane(fs->near_t[k]);
-                if (tk != 0x7fffffffu) near_f[k] = __uint_as_float(__float_as_uint(__uint2float_rd(tk)) - 1u);
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t tk = __builtin_amdgcn_readfirstlane(fs->near_t[k]);
+                    near_f[k] = tk != 0x7fffffffu ? __uint_as_float(__float_as_uint(__uint2float_rd(tk)) - 1u) : __builtin_inff();
+                }
             }
         }
+        const double *sc64 = (ORTHO || TRI >= 0) ? sc64r : fs->sc64;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for this step has landed
         __syncthreads();                                    // everyone's has; the previous step is fully consumed
         if (QUEUE) {
@@ -964,7 +968,7 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                 return min(4 * fq, cntj);
             };
             if (CULL) {
-                const uint32_t G = __builtin_amdgcn_readfirstlane(fs->cull_gap);
+                const uint32_t G = cull_gap;
                 // reachable keys: [wlo - G, whi + G] (mod 2^32), widened to whole slabs (2^24 each)
                 const unsigned long long span = (unsigned long long)W + 2ull * G + (2ull << 24);
                 if (G != 0u && span < (1ull << 32)) {
