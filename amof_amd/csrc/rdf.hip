@@ -592,9 +592,22 @@ __device__ __forceinline__ float tri_q(const float *sc, float c10, int ix, float
 // by the same margin (a pair inside that band is flagged and goes the canonical way with every listed image, like any pair on
 // a bin edge).  One root, one clamp, one edge test, one histogram add per pair; the first version counted both candidates
 // (the second into the trash words for the 85 % of pairs that have none): 2.3x the diagonal cell's cost per visited pair.
-template <bool XW>
-__device__ __forceinline__ float tri_q_twin(const float *sc, float c10, int ix, float fy, float dz)
+// HALF = +-1: c10 = +-1/2 exactly (hexagonal cells: two equal in-plane vectors at 120 or 60 degrees).  The y term of the x
+// wrap is then iy / 2 -- an arithmetic shift and an integer add where the float product, its conversion and the add stood --
+// and the twin image's x, a further half cell along, is the first candidate's with the top bit flipped (+-2^31 modulo 2^32);
+// the twin's |y| is | |iy| - 2^32 |.  Exact to one grid unit (the float product: 1 + 256 |c10| units, which the guard keeps).
+template <bool XW, int HALF>
+__device__ __forceinline__ float tri_q_twin(const float *sc, float c10, int ix, int iy, float fy, float dz)
 {
+    if (HALF != 0) {
+        const uint32_t h = (uint32_t)(iy >> 1);
+        const uint32_t x1 = HALF > 0 ? (uint32_t)ix + h : (uint32_t)ix - h;
+        const float f1 = (float)(int)x1, f2 = (float)(int)(x1 ^ 0x80000000u);
+        const float y2 = fabsf(fy) - 4294967296.f;
+        const float t1 = fmaf(dz, dz, fmaf(fy * fy, sc[4], (f1 * f1) * sc[3]));
+        const float t2 = fmaf(dz, dz, fmaf(y2 * y2, sc[4], (f2 * f2) * sc[3]));
+        return __builtin_amdgcn_sqrtf(__builtin_fminf(t1, t2));
+    }
     const float t1 = tri_t<XW>(sc, c10, ix, fy, dz);
     const float t2 = tri_t<true>(sc, c10, ix, fy - copysignf(4294967296.f, fy), dz);
     return __builtin_amdgcn_sqrtf(__builtin_fminf(t1, t2));
@@ -614,7 +627,7 @@ struct TriConst {
 // pair's two candidates (tri_q_twin), and a pair whose nearer candidate is inside the guard of a bin edge is parked for the
 // canonical arithmetic (first version: the twin in the slow path, which then ran on every wave-level pair with a few live
 // lanes: 4.4x the diagonal cell's cost per visited pair; second: both candidates counted, 2.3x).
-template <bool ZF, int NEAR, bool XW>
+template <bool ZF, int NEAR, bool XW, int HALF = 0>
 __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, const TriConst &tc, bool live, float half_m_guard,
                                              uint32_t ux, uint32_t uy, uint32_t uz, uint4 qj, float &q, float zif,
                                              float clampv, bool live_all)
@@ -630,7 +643,8 @@ __device__ __forceinline__ bool fast_bin_tri(unsigned *hist, const float *sc, co
         dz = (float)iz * sc[8];
     }
     const float fy = (float)iy;
-    q = NEAR == 4 ? tri_q_twin<XW>(sc, tc.c10, ix, fy, dz) : tri_q<XW>(sc, tc.c10, ix, fy, dz);
+    static_assert(HALF == 0 || NEAR == 4, "the exact-half x wrap exists for near mode 4 only");
+    q = NEAR == 4 ? tri_q_twin<XW, HALF>(sc, tc.c10, ix, iy, fy, dz) : tri_q<XW>(sc, tc.c10, ix, fy, dz);
     if (!live_all) q = live ? q : __builtin_inff();
     q = clamp_candidate(q, clampv);
     bool flag = !(fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard);
@@ -703,7 +717,7 @@ __device__ __forceinline__ uint32_t scalar_idx(const QAtom *q)
     return v;
 }
 
-template <bool DIAG, bool TAIL, bool ZF, int NEAR, bool XW>
+template <bool DIAG, bool TAIL, bool ZF, int NEAR, bool XW, int HALF = 0>
 __device__ __forceinline__ void fast_quad_tri(unsigned *hist, const RdfFastArgs &fa, const double *sc64, const float *sc,
                                               const TriConst &tc, const uint4 *tq, int j0, int cntj, bool has_a, bool has_b,
                                               int ia, int ib, float half_m_guard,
@@ -723,8 +737,8 @@ __device__ __forceinline__ void fast_quad_tri(unsigned *hist, const RdfFastArgs 
         const int j = j0 + u;
         const bool la = has_a && (!TAIL || j < cntj) && (!DIAG || j > ia);
         const bool lb = has_b && (!TAIL || j < cntj) && (!DIAG || j > ib);
-        na[u] = fast_bin_tri<ZF, NEAR, XW>(hist, sc, tc, la, half_m_guard, uax, uay, uaz, qj[u], qa[u], zaf, clampv, ZF && !DIAG && !TAIL);
-        nb[u] = fast_bin_tri<ZF, NEAR, XW>(hist, sc, tc, lb, half_m_guard, ubx, uby, ubz, qj[u], qb[u], zbf, clampv, ZF && !DIAG && !TAIL);
+        na[u] = fast_bin_tri<ZF, NEAR, XW, HALF>(hist, sc, tc, la, half_m_guard, uax, uay, uaz, qj[u], qa[u], zaf, clampv, ZF && !DIAG && !TAIL);
+        nb[u] = fast_bin_tri<ZF, NEAR, XW, HALF>(hist, sc, tc, lb, half_m_guard, ubx, uby, ubz, qj[u], qb[u], zbf, clampv, ZF && !DIAG && !TAIL);
     }
     if (na[0] | na[1] | na[2] | na[3] | nb[0] | nb[1] | nb[2] | nb[3]) {
         unsigned ovf = 0u;      // pairs of this lane that found the queue full: bit 2 u + (0: centre a, 1: centre b)
@@ -782,8 +796,10 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
     // flagged pairs wait in per-lane register queues for the end of the step (fast_quad): the diagonal-cell kernels.  68.6 ->
     // 67.0 ms per headline launch -- the first parking scheme that pays (seven with LDS queues lost: profiles/r04/rdf_tile_stop.txt)
     constexpr bool PARK = ORTHO && ZFK && !IMG && TRI < 0 && AA;
-    constexpr int NEAR = TRI >= 0 ? TRI % 5 : 0;
+    // TRI = 10 / 11: near mode 4 with the exact-half x wrap, c10 = + 1/2 / - 1/2 (tri_q_twin)
+    constexpr int NEAR = TRI >= 10 ? 4 : (TRI >= 0 ? TRI % 5 : 0);
     constexpr bool XW = TRI >= 5;
+    constexpr int HALF = TRI == 10 ? 1 : (TRI == 11 ? -1 : 0);
     const RdfArgs &a = fa.a;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // double-buffered tiles: J (512 entries) and the centre sub-tile (128 entries)
@@ -1094,17 +1110,17 @@ __global__ __launch_bounds__(FAST_THREADS, 5) void rdf_tile_kernel_fast(RdfFastA
                     unsigned *nqc = &nq_count[step % 3];
                     if (diag) {
                         for (int j0 = qb + 4 * wave; j0 < qe; j0 += 16)
-                            fast_quad_tri<true, true, ZF, NEAR, XW>(hist, fa, sc64, sc, trc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                            fast_quad_tri<true, true, ZF, NEAR, XW, HALF>(hist, fa, sc64, sc, trc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
                                                                 cax, cay, uaz, ida, cbx, cby, ubz, idb,
                                                                 nq, nqc, nq_cap, g, p, gi, zaf, zbf, qseg, clampv);
                     } else {
                         int j0 = qb + 4 * wave;
                         for (; j0 < qe_full; j0 += 16)
-                            fast_quad_tri<false, false, ZF, NEAR, XW>(hist, fa, sc64, sc, trc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
+                            fast_quad_tri<false, false, ZF, NEAR, XW, HALF>(hist, fa, sc64, sc, trc, tq, j0, cntj, has_a, has_b, ia, ib, half_m_guard,
                                                                   cax, cay, uaz, ida, cbx, cby, ubz, idb,
                                                                   nq, nqc, nq_cap, g, p, gi, zaf, zbf, qseg, clampv);
                         if (j0 == full && j0 < qe && full < cntj)
-                            fast_quad_tri<false, true, ZF, NEAR, XW>(hist, fa, sc64, sc, trc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard,
+                            fast_quad_tri<false, true, ZF, NEAR, XW, HALF>(hist, fa, sc64, sc, trc, tq, full, cntj, has_a, has_b, ia, ib, half_m_guard,
                                                                  cax, cay, uaz, ida, cbx, cby, ubz, idb,
                                                                  nq, nqc, nq_cap, g, p, gi, zaf, zbf, qseg, clampv);
                     }
@@ -1682,7 +1698,7 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                 bool ok = true;
                 double slack = 1e300, share = 0.0, l10b = 0.0, c10max = 0.0, tau_max = 0.0;
                 int near = 0;
-                bool twin = false, xw_wraps = false, twin_wraps = false, twin_short = false;
+                bool twin = false, xw_wraps = false, twin_wraps = false, twin_short = false, half_p = true, half_m = true;
                 std::vector<double> fold((size_t)nc * 2), rec((size_t)nc * 9);
                 for (int64_t k = 0; k < nc && ok; k++) {
                     const double *c = t->cell + 9 * k;
@@ -1736,6 +1752,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     share = std::max(share, tau_y > 0.0075 ? 0.012 : 2.0 * std::max(tau_y, 0.0) + 2.0 * std::max(tau_z, 0.0));
                     l10b = std::max(l10b, fabs(L[3]) / dr);
                     const double c10 = L[3] / L[0], r20 = L[6] / L[0], r21 = L[7] / L[4];
+                    // (c10 = +-1/2 to 2^-33: the exact-half x wrap of near mode 4, tri_q_twin<HALF>, is then right to one grid unit)
+                    if (fabs(c10 - 0.5) > 1e-10) half_p = false;
+                    if (fabs(c10 + 0.5) > 1e-10) half_m = false;
                     fold[(size_t)k * 2] = r20 - c10 * r21;
                     fold[(size_t)k * 2 + 1] = r21;
                     double *r = &rec[(size_t)k * 9];
@@ -1754,7 +1773,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     near = 4;
                 }
                 if (!(slack > 0.0) && xw_wraps) ok = false;
-                const int code = near + (slack > 0.0 ? 0 : 5);
+                int code = near + (slack > 0.0 ? 0 : 5);
+                if (near == 4 && (half_p || half_m) && !getenv("AMOF_RDF_NOHALF")) code = half_p ? 10 : 11;
                 const double cost = (near == 0 ? 0.0 : near == 1 ? 0.5 : near == 4 ? 6.0 : (double)(near - 1) * 1.5) +
                                     (slack > 0.0 ? 0.0 : 2.5);
                 if (ok && (!tri || cost < best_cost)) {
@@ -1772,8 +1792,8 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                   (1.0 + 256.0 * tri_c10) * 1.5 * csum * two32_ / dr + (double)nbins * 1e-12 < 0.25)) tri = false;
         }
         if (tri && getenv("AMOF_RDF_DEBUG"))
-            fprintf(stderr, "rdf_tile_tri: code %d (near mode %d, x wrap %d) axes (%d, %d | %d) parked share %.4f tau %.5f c10 %.5f\n", tri_code, tri_code % 5,
-                    tri_code / 5, tri_ax0, tri_ax1, tri_axis, tri_share, tri_tau, tri_c10);
+            fprintf(stderr, "rdf_tile_tri: code %d (near mode %d, x wrap %d) axes (%d, %d | %d) parked share %.4f tau %.5f c10 %.5f\n", tri_code,
+                    tri_code >= 10 ? 4 : tri_code % 5, tri_code >= 10 ? 2 : tri_code / 5, tri_ax0, tri_ax1, tri_axis, tri_share, tri_tau, tri_c10);
         bool done = false;
         const bool fast_plain = fast;      // the cell-list / range kernels below rest on the plain criterion (cutoff clear of every half height)
         if (tri) { fast = true; fast_img = false; }
@@ -2243,7 +2263,9 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     case 6: e = AMOF_TRI(6); break;
                     case 7: e = AMOF_TRI(7); break;
                     case 8: e = AMOF_TRI(8); break;
-                    default: e = AMOF_TRI(9); break;
+                    case 9: e = AMOF_TRI(9); break;
+                    case 10: e = AMOF_TRI(10); break;
+                    default: e = AMOF_TRI(11); break;
                     }
 #undef AMOF_TRI
                 }

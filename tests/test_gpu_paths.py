@@ -907,10 +907,39 @@ def _tri_cell(kind):
         hexc = np.array([[a_hex, 0.0, 0.0], [-0.5 * a_hex, np.sqrt(3.0) / 2.0 * a_hex, 0.0], [0.0, 0.0, d3[2, 2]]])
         frac = np.linalg.solve(np.asarray(base.cell).T, base.positions.T).T
         return Frame(base.numbers, frac @ hexc, hexc)
+    if kind == "hexagonal60":       # the same lattice described with gamma = 60 degrees (c10 = + 1/2), the hexagonal plane = (b, c)
+        base = H.replicate(z, (2, 2, 2))
+        d3 = np.diag(np.diag(base.cell))
+        a_hex = float(np.sqrt(d3[1, 1] * d3[2, 2] / (np.sqrt(3.0) / 2.0)))
+        # (the first axis the longest: it becomes the slab axis, the hexagonal pair the in-plane one)
+        hexc = np.array([[1.4 * a_hex, 0.0, 0.0], [0.0, a_hex, 0.0], [0.0, 0.5 * a_hex, np.sqrt(3.0) / 2.0 * a_hex]])
+        frac = np.linalg.solve(np.asarray(base.cell).T, base.positions.T).T
+        return Frame(base.numbers, frac @ hexc, hexc)
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize("kind", ["fixture", "equal_ab", "short_c", "cubic", "hexagonal"])
+@pytest.mark.parametrize("kind", ["hexagonal", "hexagonal60"])
+def test_rdf_hexagonal_cells_take_the_exact_half_x_wrap(hip_ctx, kind, capfd):
+    """c10 = -+ 1/2 exactly: near mode 4 with the x wrap's y term as a shift and the twin's x as a flipped top bit
+    (csrc/rdf.hip tri_q_twin<HALF>: codes 10 / 11) -- against the oracle and against the float-product form (code 4 / 9)"""
+    packed = H.random_walk(_tri_cell(kind), 3, 0.08, 43)
+    kinds, sp = H.species_of(packed.numbers)
+    rmax = float(np.min(packed.cell_lengths()) / 2)
+    for nb in (1540, 311):
+        with _env(AMOF_RDF_NOCELL="1", AMOF_RDF_NORANGE="1", AMOF_RDF_DEBUG="1"):
+            capfd.readouterr()
+            got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            err = capfd.readouterr().err
+            assert hip_ctx.last_path() == "rdf_tile_tri" and ("code 10 " in err or "code 11 " in err), err
+            with _env(AMOF_RDF_NOHALF="1"):
+                plain, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+                err = capfd.readouterr().err
+                assert hip_ctx.last_path() == "rdf_tile_tri" and ("code 4 " in err or "code 9 " in err), err
+        ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), rmax, nb, cell_list=True)
+        assert np.array_equal(got, ref) and np.array_equal(plain, ref)
+
+
+@pytest.mark.parametrize("kind", ["fixture", "equal_ab", "short_c", "cubic", "hexagonal", "hexagonal60"])
 @pytest.mark.parametrize("jitter", [0.0, 0.004])
 def test_rdf_triangular_frame_kernel(hip_ctx, kind, jitter):
     """General cells at the reference's default cutoff (half the shortest cell LENGTH, amof/rdf.py:74): the tile kernel in
@@ -935,7 +964,7 @@ def test_rdf_triangular_frame_kernel(hip_ctx, kind, jitter):
     # a cutoff beyond half the shortest length (only the C ABI allows it): second images along that axis -- as y or z it
     # gets the near test, as x (both in-plane axes too short) the variant is refused
     big, _, _ = hip_ctx.rdf_accumulate(packed, 1.01 * rmax, 800)
-    if kind in ("equal_ab", "cubic", "hexagonal"):
+    if kind in ("equal_ab", "cubic", "hexagonal", "hexagonal60"):
         assert hip_ctx.last_path() != "rdf_tile_tri"
     ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, len(kinds), 1.01 * rmax, 800, cell_list=True)
     assert np.array_equal(big, ref)

@@ -27,6 +27,14 @@ while time.time() < t_end:
     cell = np.diag(L) + np.tril(rng.uniform(-1, 1, (3, 3)) * eps * L[:, None], k=-1)
     if seed % 2:
         cell = cell.T.copy() if seed % 4 == 1 else cell          # upper- or lower-triangular
+    if seed % 5 == 0:
+        # exactly hexagonal (two equal vectors at 120 or 60 degrees, the third perpendicular, any order of the rows): the
+        # exact-half x wrap of near mode 4 (csrc/rdf.hip tri_q_twin<HALF>)
+        a_h = float(L[0])
+        sgn = -0.5 if seed % 10 == 0 else 0.5
+        hexc = np.array([[a_h, 0.0, 0.0], [sgn * a_h, np.sqrt(3.0) / 2.0 * a_h, 0.0], [0.0, 0.0, float(L[2])]])
+        perm = [(0, 1, 2), (2, 0, 1), (1, 2, 0), (1, 0, 2)][(seed // 5) % 4]
+        cell = hexc[list(perm)][:, list(perm)] if seed % 15 else hexc[list(perm)]
     F = int(rng.integers(1, 4))
     kinds = [1, 6, 7, 30][:S]
     numbers = rng.choice(kinds, size=N)
