@@ -1498,6 +1498,255 @@ __global__ __launch_bounds__(CELL_THREADS, 8) void rdf_cell_kernel(RdfCellArgs c
     }
 }
 
+// --------------------------------------------------------------------------
+// Cell-list kernel, one WAVE per centre cell (round 5; the default of the "rdf_cell" family).
+//
+// rdf_cell_kernel above gives every lane its own centre atom and lets it gather its own partners: the lanes of a wave walk
+// runs of different lengths (a wave lasts as long as its longest lane, row by row), every candidate is a 16-byte gather per
+// lane, and the kernel runs at ~1e12 candidates/s where the LDS-broadcast tile kernel does 3.6e12 pair evaluations/s.
+// Here the roles are swapped and the centre side is made wave-uniform:
+//   * a wave owns one CELL of the same grid (>= rmax / 2 thick, ~8 atoms).  The partners of ALL its atoms are the same
+//     13 half-shell rows, trimmed ONCE per cell to the cells within reach of the cell (the per-lane trim of the kernel above
+//     with the cell's extent in place of the atom's point): up to 26 contiguous index runs, ~650 partners;
+//   * the runs are concatenated (lanes 0 .. 12 compute one row each: bounds, table look-ups; a 16-lane scan gives the run
+//     offsets, kept in LDS) and the LANES take consecutive partners of the concatenation, 64 at a time, by a five-step
+//     binary search over the 32 run offsets: a dense, mostly contiguous load of 64 records, every lane busy but in the
+//     last chunk of a cell;
+//   * the cell's centre atoms are wave-uniform: their records come through the scalar cache into SGPRs, the pair arithmetic
+//     reads them as scalar operands, and the "once" rule needs one compare only in the chunks that hold the cell's own atoms
+//     (partner behind the centre in the sorted order; every other row of the half shell counts whole).
+// Per centre the wave evaluates the cell's ~650 partners instead of the ~525 the per-lane trim leaves, but every evaluation
+// is a dense broadcast one.  Same three-level pair arithmetic, same LDS histogram of every unordered species pair, same frame
+// chunks and XCD mapping as the kernel above (RdfCellArgs; cpt = cell groups of 8 cells per workgroup).
+#ifndef CW_THREADS_N
+#define CW_THREADS_N 512
+#endif
+#ifndef CW_MIN_WAVES
+#define CW_MIN_WAVES 4
+#endif
+constexpr int CW_THREADS = CW_THREADS_N;
+constexpr int CW_WAVES = CW_THREADS / 64;
+constexpr int CW_RUNS = 32;          // 13 rows x 2 runs, padded to a power of two with the total
+constexpr int CW_QCAP = 126;         // flagged pairs a wave parks per cell (~40 on configs[4]); beyond: refined in place
+constexpr int CW_WAVE_WORDS = 2 * CW_RUNS + 2 + 2 * CW_QCAP;     // LDS words per wave behind the histograms
+
+template <bool ORTHO>
+__global__ __launch_bounds__(CW_THREADS, CW_MIN_WAVES) void rdf_cellwave_kernel(RdfCellArgs ca)
+{
+    const RdfFastArgs &fa = ca.f;
+    const RdfArgs &a = fa.a;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);          // [npk * nbins]
+    unsigned *koff = hist + (size_t)ca.npk * a.nbins;                // [S * S]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = a.S, nbins = a.nbins;
+    // (per-wave tables on an even word: the queue entries are 8-byte pairs)
+    unsigned *pre = hist + (((size_t)ca.npk * a.nbins + (size_t)S * S + 1) & ~(size_t)1) + wave * CW_WAVE_WORDS;   // [CW_RUNS] first element of run k
+    unsigned *rbase = pre + CW_RUNS;                                 // [CW_RUNS] sorted index of the run's first atom
+    unsigned *wq_count = rbase + CW_RUNS;                            // the wave's queue of flagged pairs: entries so far
+    uint2 *wq = reinterpret_cast<uint2 *>(wq_count + 2);             // [CW_QCAP] (partner, centre) by sorted index
+    unsigned chunk = blockIdx.y, bx = blockIdx.x, xcd = 0, fstep = 1;
+    if (fa.xcd_map) {
+        const unsigned long long lin = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned long long kk = lin >> 3;
+        xcd = (unsigned)(lin & 7ull);
+        chunk = (unsigned)(kk / gridDim.x);
+        bx = (unsigned)(kk % gridDim.x);
+        fstep = 8;
+    }
+    if ((int)(chunk * (unsigned)ca.fpc * fstep + xcd) >= fa.nf) return;
+    for (int k = tid; k < ca.npk * nbins; k += CW_THREADS) hist[k] = 0u;
+    for (int k = tid; k < S * S; k += CW_THREADS) koff[k] = ca.keyoff[k];
+    __syncthreads();
+    const int nx = ca.nx, ny = ca.ny, nz = ca.nz;
+    const int ncell = nx * ny * nz;
+    const float half_m_guard = fa.half_m_guard, nb_hi = fa.nb_hi;
+
+    for (int ff = 0; ff < ca.fpc; ff++) {
+        const unsigned fl = (chunk * (unsigned)ca.fpc + (unsigned)ff) * fstep + xcd;
+        if ((int)fl >= fa.nf) break;
+        const int f = fa.f_base + (int)fl;
+        const double *__restrict__ p = a.pos + (size_t)f * (size_t)a.N * 3;
+        const QAtom *__restrict__ Qf = fa.Q + (size_t)fl * (size_t)a.N;
+        const int gi = a.n_cells == 1 ? 0 : f;
+        const FrameScale *__restrict__ fs = fa.fs + gi;
+        const double *__restrict__ g = a.geom + (size_t)gi * GEOM_STRIDE;
+        float sc[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) sc[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fs->sc[k])));
+        const uint32_t *__restrict__ st = ca.start3 + (size_t)fl * ((size_t)ncell * S + 1);
+        // the row bounds relative to the centre cell depend on the row and the frame's scales only (every cell has the same
+        // extent): lanes 0 .. 12 hold them for the cells of this frame
+        int rel_lo = -2, rel_hi = 2;
+        const int row = lane < 13 ? lane : 12;
+        const int rdz = row < 3 ? 0 : (row < 8 ? 1 : 2);
+        const int rdy = row < 3 ? row : (row < 8 ? row - 5 : row - 10);
+        if (row == 0) rel_lo = 0;
+        if (ca.trim) {
+            const float wx = 4294967296.f / (float)nx, wy = 4294967296.f / (float)ny, wz = 4294967296.f / (float)nz;
+            const float ex = wx * 2e-5f + 2048.f, ey = wy * 2e-5f + 2048.f, ez = wz * 2e-5f + 2048.f;
+            const float Rq = nb_hi * 1.0001f + 2.f;
+            const float s_xx = sc[0], s_yx = ORTHO ? 0.f : sc[3], s_yy = ORTHO ? sc[1] : sc[4], s_zx = ORTHO ? 0.f : sc[6],
+                        s_zy = ORTHO ? 0.f : sc[7], s_zz = ORTHO ? sc[2] : sc[8];
+            // differences partner - centre in grid units: the partner anywhere in its cell, the centre anywhere in mine
+            const float zl = (float)(rdz - 1) * wz - ez, zh = (float)(rdz + 1) * wz + ez;
+            const float yl = (float)(rdy - 1) * wy - ey, yh = (float)(rdy + 1) * wy + ey;
+            const float dzmin = (zl > 0.f ? zl : (zh < 0.f ? -zh : 0.f)) * s_zz;
+            const float yc_lo = yl * s_yy + fminf(zl * s_zy, zh * s_zy), yc_hi = yh * s_yy + fmaxf(zl * s_zy, zh * s_zy);
+            const float dymin = yc_lo > 0.f ? yc_lo : (yc_hi < 0.f ? -yc_hi : 0.f);
+            const float rem = Rq * Rq - dzmin * dzmin - dymin * dymin;
+            if (rem < 0.f) {
+                rel_hi = rel_lo - 1;        // nothing of this row is within reach of any atom of the cell
+            } else {
+                const float rho = __builtin_amdgcn_sqrtf(rem) * 1.0001f + 1.f;
+                const float e_lo = fminf(yl * s_yx, yh * s_yx) + fminf(zl * s_zx, zh * s_zx);
+                const float e_hi = fmaxf(yl * s_yx, yh * s_yx) + fmaxf(zl * s_zx, zh * s_zx);
+                // partner x - (my cell's lower edge) lies in [fx_lo - ex, wx + fx_hi + ex]
+                const float fx_lo = (-rho - e_hi) / s_xx, fx_hi = (rho - e_lo) / s_xx;
+                const float inv_wx = (float)nx * (1.f / 4294967296.f);
+                rel_lo = max(rel_lo, (int)floorf((fx_lo - ex) * inv_wx - 1e-3f));
+                rel_hi = min(rel_hi, (int)floorf((wx + fx_hi + ex) * inv_wx + 1e-3f));
+                if (row == 0) rel_lo = 0;
+            }
+        }
+
+        for (int cc = 0; cc < ca.cpt; cc++) {
+            const int cell = (int)((bx * (unsigned)ca.cpt + (unsigned)cc) * CW_WAVES) + wave;      // wave-uniform
+            if (cell >= ncell) break;
+            const int c_begin = __builtin_amdgcn_readfirstlane((int)st[(size_t)cell * S]);
+            const int c_end = __builtin_amdgcn_readfirstlane((int)st[(size_t)(cell + 1) * S]);
+            const int nown = c_end - c_begin;
+            if (nown <= 0) continue;
+            const int cx = cell % nx, cy = (cell / nx) % ny, cz = cell / (nx * ny);
+            // ---- the cell's partner runs: one row per lane (lanes 0 .. 12) ----
+            int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0;
+            if (lane < 13) {
+                int cz2 = cz + rdz, cy2 = cy + rdy;
+                if (cz2 >= nz) cz2 -= nz;
+                if (cy2 >= ny) cy2 -= ny;
+                if (cy2 < 0) cy2 += ny;
+                const int rowbase = (cz2 * ny + cy2) * nx;
+                const int xlo = cx + rel_lo, xhi = cx + rel_hi;
+                if (xlo <= xhi) {
+                    int xa0, xb0, xa1 = 0, xb1 = -1;
+                    if (xhi < 0) { xa0 = xlo + nx; xb0 = xhi + nx; }
+                    else if (xlo >= nx) { xa0 = xlo - nx; xb0 = xhi - nx; }
+                    else if (xlo < 0) { xa0 = xlo + nx; xb0 = nx - 1; xa1 = 0; xb1 = xhi; }
+                    else if (xhi >= nx) { xa0 = xlo; xb0 = nx - 1; xa1 = 0; xb1 = xhi - nx; }
+                    else { xa0 = xlo; xb0 = xhi; }
+                    ja0 = (int)st[(size_t)(rowbase + xa0) * S];
+                    ja1 = (int)st[(size_t)(rowbase + xb0 + 1) * S];
+                    if (xa1 <= xb1) {
+                        jb0 = (int)st[(size_t)(rowbase + xa1) * S];
+                        jb1 = (int)st[(size_t)(rowbase + xb1 + 1) * S];
+                    }
+                }
+            }
+            const int la = ja1 - ja0, lb = jb1 - jb0;
+            int incl = la + lb;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const int n = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += n;
+            }
+            const int T = __builtin_amdgcn_readlane(incl, 15);         // (lanes 13 .. 15 add nothing)
+            if (lane < 16) {
+                const int excl = incl - la - lb;
+                pre[2 * lane] = (unsigned)excl;
+                pre[2 * lane + 1] = (unsigned)(excl + la);
+                rbase[2 * lane] = (unsigned)ja0;
+                rbase[2 * lane + 1] = (unsigned)jb0;
+            }
+            // (the wave reads what its own lanes wrote: LDS operations of one wave complete in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // row 0's first run starts with the cell's own atoms: elements 0 .. nown - 1 of the concatenation
+            auto locate = [&](int e) {          // sorted index of element e of the concatenation (e < T)
+                int k = 0;
+#pragma unroll
+                for (int step = CW_RUNS / 2; step > 0; step >>= 1)
+                    if (pre[k + step] <= (unsigned)e) k += step;
+                return (int)rbase[k] + (e - (int)pre[k]);
+            };
+            // a pair whose candidate lies within the guard of a bin edge is parked in the wave's LDS queue (partner and centre by
+            // sorted index) and refined at the end of the cell, one pair per lane: refined in line, the ~150-instruction body ran
+            // in 40 % of the centre steps for one or two live lanes (17 of 64 lanes are in range, ~3 % of those near an edge)
+            if (lane == 0) *wq_count = 0u;
+            int jn = lane < T ? locate(lane) : c_begin;
+            uint4 qn = *reinterpret_cast<const uint4 *>(Qf + jn);
+            for (int cb = 0; cb < T; cb += 64) {
+                const int e = cb + lane;
+                const bool alive = e < T;
+                const int j = jn;
+                const uint4 qj = qn;
+                if (cb + 64 < T) {              // the next chunk's records are on their way while this one is evaluated
+                    jn = e + 64 < T ? locate(e + 64) : c_begin;
+                    qn = *reinterpret_cast<const uint4 *>(Qf + jn);
+                }
+                const unsigned *kp = koff + (qj.w >> CELL_SPECIES_SHIFT) * S;
+                // a partner among the cell's own atoms counts for the centres before it; everything else for every centre
+                const int e_own = !alive ? -1 : (e < nown ? e : 0x7fffffff);
+                // the cell's atoms are sorted by species (the table has an entry per cell and species): one histogram per
+                // species segment, its LDS offset read once -- the inner loop then holds no LDS read, so the NEXT centre's
+                // record can be on its way through the scalar cache while this one is evaluated
+                auto centres = [&](auto own_tag) {
+                    constexpr bool OWN = decltype(own_tag)::value;
+                    int seg_b = c_begin;
+                    for (int s = 0; s < S; s++) {
+                        const int seg_e = __builtin_amdgcn_readfirstlane((int)st[(size_t)cell * S + s + 1]);
+                        if (seg_e > seg_b) {
+                            unsigned *h = hist + kp[s];
+                            QAtom own = Qf[seg_b];
+                            for (int ci = seg_b; ci < seg_e; ci++) {
+                                const QAtom nxt = Qf[min(ci + 1, seg_e - 1)];          // wave-uniform: scalar loads
+                                const int ix = (int)(qj.x - own.ux), iy = (int)(qj.y - own.uy), iz = (int)(qj.z - own.uz);
+                                const float q = fast_q<ORTHO>(sc, ix, iy, iz);
+                                const bool live = OWN ? (e_own > ci - c_begin) : true;
+                                if (live && q < nb_hi) {
+                                    if (fabsf(__builtin_amdgcn_fractf(q) - 0.5f) < half_m_guard) {
+                                        atomicAdd(&h[(int)q], 1u);
+                                    } else {
+                                        const unsigned slot = atomicAdd(wq_count, 1u);
+                                        if (slot < (unsigned)CW_QCAP) wq[slot] = make_uint2((unsigned)j, (unsigned)ci);
+                                        else        // queue full: in place
+                                            rdf_pair_refine<ORTHO>(h, fa, fs->sc64, g, q, own.ux, own.uy, own.uz,
+                                                                   make_uint4(qj.x, qj.y, qj.z, qj.w & CELL_IDX_MASK), p, own.idx & CELL_IDX_MASK);
+                                    }
+                                }
+                                own = nxt;
+                            }
+                        }
+                        seg_b = seg_e;
+                    }
+                };
+                if (cb < nown) centres(std::true_type{});
+                else if (alive) centres(std::false_type{});
+            }
+            // ---- the cell's flagged pairs: one per lane, the candidate evaluated again from the same records ----
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nflag = min((int)*wq_count, CW_QCAP);
+            for (int k = lane; k < nflag; k += 64) {
+                const uint2 pr = wq[k];
+                const uint4 qb = *reinterpret_cast<const uint4 *>(Qf + pr.x);
+                const uint4 qa = *reinterpret_cast<const uint4 *>(Qf + pr.y);
+                unsigned *h = hist + koff[(qb.w >> CELL_SPECIES_SHIFT) * S + (qa.w >> CELL_SPECIES_SHIFT)];
+                const float q = fast_q<ORTHO>(sc, (int)(qb.x - qa.x), (int)(qb.y - qa.y), (int)(qb.z - qa.z));
+                rdf_pair_refine<ORTHO>(h, fa, fs->sc64, g, q, qa.x, qa.y, qa.z, make_uint4(qb.x, qb.y, qb.z, qb.w & CELL_IDX_MASK), p,
+                                       qa.w & CELL_IDX_MASK);
+            }
+            __builtin_amdgcn_wave_barrier();     // (the next cell overwrites the run table)
+        }
+    }   // frames of the chunk
+    __syncthreads();
+    for (int k = tid; k < ca.npk * nbins; k += CW_THREADS) {
+        const unsigned v = hist[k];
+        if (v) atomicAdd(&a.U[(size_t)ca.keyU[k / nbins] + (size_t)(k % nbins)], (unsigned long long)v);
+    }
+}
+
 // hist[a][b][k] += (a == b) ? 2*U[a][a][k] + nsp[a]*selfh[k] : U[min][max][k]
 __global__ void rdf_finalize_kernel(const unsigned long long *U, const unsigned long long *selfh,
                                     const long long *nsp, unsigned long long *hist, int S, int nbins)
@@ -1980,7 +2229,12 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                     ca.npk = npk;
                     ca.cpt = 1;
                     ca.trim = getenv("AMOF_RDF_NOTRIM") ? 0 : 1;
-                    const unsigned gx = (unsigned)((t->n_atoms + (int64_t)CELL_THREADS * ca.cpt - 1) / ((int64_t)CELL_THREADS * ca.cpt));
+                    // round 5: one wave per cell (rdf_cellwave_kernel) unless AMOF_RDF_CELL_GATHER=1 asks for the per-lane gather form
+                    const bool wavecell = !getenv("AMOF_RDF_CELL_GATHER");
+                    const int64_t ncell3 = (int64_t)nk[0] * nk[1] * nk[2];
+                    const size_t lds3w = lds3 + ((size_t)CW_WAVES * CW_WAVE_WORDS + 1) * sizeof(unsigned);
+                    unsigned gx = (unsigned)((t->n_atoms + (int64_t)CELL_THREADS * ca.cpt - 1) / ((int64_t)CELL_THREADS * ca.cpt));
+                    if (wavecell) gx = (unsigned)((ncell3 + CW_WAVES - 1) / CW_WAVES);
                     int64_t launches = 0;
                     for (int64_t fb = 0; fb < t->n_frames; fb += FB3) {
                         const int64_t nf = std::min<int64_t>(FB3, t->n_frames - fb);
@@ -2003,13 +2257,31 @@ static int rdf_run(amof_ctx *ctx, const amof_traj *t, double rmax, int32_t nbins
                             const int64_t chunks = (slots + fpc - 1) / fpc;
                             ca.frames_grid = (int32_t)(ca.f.xcd_map ? chunks * 8 : chunks);
                         }
+                        if (wavecell) {
+                            // cell groups per workgroup: the histogram flush (npk x nbins u64 atomics) is paid per workgroup and
+                            // chunk, a cell and frame bring ~1e3 pairs -- keep >= ~8k workgroups per launch, at most 8 groups
+                            const int64_t groups = (ncell3 + CW_WAVES - 1) / CW_WAVES;
+                            int64_t cpw = std::max<int64_t>(1, std::min<int64_t>(8, groups * ca.frames_grid / 8192));
+                            if (const char *ce = getenv("AMOF_RDF_CELL_CPW")) cpw = std::max(1, atoi(ce));            // experiments / tests
+                            cpw = std::min<int64_t>(cpw, groups);
+                            ca.cpt = (int32_t)cpw;
+                            gx = (unsigned)((groups + cpw - 1) / cpw);
+                        }
                         dim3 grid(gx, (unsigned)ca.frames_grid);
                         if (launches == 0) timing_dom_begin(ctx, "rdf_cell");
-                        hipError_t e = ortho ? allow_max_lds((const void *)rdf_cell_kernel<true>)
-                                             : allow_max_lds((const void *)rdf_cell_kernel<false>);
-                        AMOF_HIP_TRY(ctx, e);
-                        if (ortho) hipLaunchKernelGGL(rdf_cell_kernel<true>, grid, dim3(CELL_THREADS), lds3, ctx->stream, ca);
-                        else hipLaunchKernelGGL(rdf_cell_kernel<false>, grid, dim3(CELL_THREADS), lds3, ctx->stream, ca);
+                        if (wavecell) {
+                            hipError_t e = ortho ? allow_max_lds((const void *)rdf_cellwave_kernel<true>)
+                                                 : allow_max_lds((const void *)rdf_cellwave_kernel<false>);
+                            AMOF_HIP_TRY(ctx, e);
+                            if (ortho) hipLaunchKernelGGL(rdf_cellwave_kernel<true>, grid, dim3(CW_THREADS), lds3w, ctx->stream, ca);
+                            else hipLaunchKernelGGL(rdf_cellwave_kernel<false>, grid, dim3(CW_THREADS), lds3w, ctx->stream, ca);
+                        } else {
+                            hipError_t e = ortho ? allow_max_lds((const void *)rdf_cell_kernel<true>)
+                                                 : allow_max_lds((const void *)rdf_cell_kernel<false>);
+                            AMOF_HIP_TRY(ctx, e);
+                            if (ortho) hipLaunchKernelGGL(rdf_cell_kernel<true>, grid, dim3(CELL_THREADS), lds3, ctx->stream, ca);
+                            else hipLaunchKernelGGL(rdf_cell_kernel<false>, grid, dim3(CELL_THREADS), lds3, ctx->stream, ca);
+                        }
                         AMOF_HIP_TRY(ctx, hipGetLastError());
                         launches++;
                     }

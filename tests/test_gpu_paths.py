@@ -556,8 +556,12 @@ def test_rdf_cell_kernel_three_level_cell_list(hip_ctx, kind):
     kinds, sp = H.species_of(packed.numbers)
     for rmax, nb in cases:
         with _env(AMOF_RDF_FORCE_CELL="1"):
-            got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)           # (round 5: one wave per cell)
             assert hip_ctx.last_path() == "rdf_cell"
+        with _env(AMOF_RDF_FORCE_CELL="1", AMOF_RDF_CELL_GATHER="1"):      # the per-lane gather form
+            gathered, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+            assert hip_ctx.last_path() == "rdf_cell"
+        assert np.array_equal(gathered, got), (kind, rmax, nb)
         with _env(AMOF_RDF_NOCELL="1"):
             other, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
             assert hip_ctx.last_path() in ("rdf_tile_tri", "rdf_tile_zf", "rdf_range")
@@ -577,11 +581,12 @@ def test_rdf_cell_kernel_lattice_on_bin_edges(hip_ctx):
     packed = PackedTrajectory(np.stack([pts, pts + 0.5, pts - 3.25]), cell, numbers)
     kinds, sp = H.species_of(packed.numbers)
     for rmax, nb in [(3.0, 30), (3.0, 300), (2.0, 2), (3.5, 7)]:
-        with _env(AMOF_RDF_FORCE_CELL="1"):
-            got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
-            assert hip_ctx.last_path() == "rdf_cell"
         ref, _ = clib.rdf_hist(packed.pos, packed.cell, sp, 2, rmax, nb, cell_list=True)
-        assert np.array_equal(got, ref), (rmax, nb)
+        for gather in ("0", "1"):                                   # one wave per cell | one lane per centre
+            with _env(AMOF_RDF_FORCE_CELL="1", **({"AMOF_RDF_CELL_GATHER": "1"} if gather == "1" else {})):
+                got, _, _ = hip_ctx.rdf_accumulate(packed, rmax, nb)
+                assert hip_ctx.last_path() == "rdf_cell"
+            assert np.array_equal(got, ref), (rmax, nb, gather)
 
 
 @pytest.mark.parametrize("eps,jitter", [(0.02, 0.0), (0.10, 0.0), (0.03, 0.004)])
@@ -1023,6 +1028,15 @@ def test_rdf_cell_kernel_frame_chunks(hip_ctx, frames):
             got, _, _ = hip_ctx.rdf_accumulate(packed, 6.0, 600)
             assert hip_ctx.last_path() == "rdf_cell"
         assert np.array_equal(got, ref), (frames, fpc)
+        with _env(AMOF_RDF_FORCE_CELL="1", AMOF_RDF_CELL_FPC=fpc, AMOF_RDF_CELL_GATHER="1"):
+            got, _, _ = hip_ctx.rdf_accumulate(packed, 6.0, 600)
+        assert np.array_equal(got, ref), (frames, fpc, "gather")
+    # round 5, one wave per cell: cell groups per workgroup that divide the grid, leave a ragged last group, exceed it
+    for cpw in ("1", "3", "7", "1000"):
+        with _env(AMOF_RDF_FORCE_CELL="1", AMOF_RDF_CELL_CPW=cpw, AMOF_RDF_CELL_FPC="2"):
+            got, _, _ = hip_ctx.rdf_accumulate(packed, 6.0, 600)
+            assert hip_ctx.last_path() == "rdf_cell"
+        assert np.array_equal(got, ref), (frames, "cpw", cpw)
 
 
 def test_rdf_range_kernel_is_what_a_thin_long_cell_selects(hip_ctx):
