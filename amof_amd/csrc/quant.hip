@@ -414,6 +414,136 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const double *__restr
     Q3[(size_t)fl * N + slot] = q;
 }
 
+// The same sort in ONE kernel, one workgroup per frame (round 5): the key counters live in LDS as 16-bit halves (configs[4]:
+// 45 360 keys = 89 kB), so the three-kernel form's key array (written, read), its global count and cursor atomics and its
+// strided one-workgroup scan of the table in global memory are gone: positions are read and quantised twice (counting pass,
+// placement pass), the table is written once, the records once.  A thread scans a contiguous run of counter words; an atom's
+// place is its run's absolute start (32 bits, cbase) + a 16-bit cursor inside the run -- which requires that no run of ~45
+// adjacent keys holds more than 65 535 atoms: checked in the scan; a frame that violates it gets an EMPTY table (every cell
+// empty, nothing placed) and raises the flag, and the caller falls back as for far-away atoms.
+constexpr int CSF_THREADS = 1024;
+constexpr int CSF_AHEAD = 4;        // atoms a thread has in flight
+
+__global__ __launch_bounds__(CSF_THREADS) void cell_sort_frame_kernel(const double *__restrict__ pos, const double *__restrict__ geom,
+                                                                      int n_cells, const int32_t *__restrict__ species, int S,
+                                                                      int64_t N, int f0, int nx, int ny, int nz,
+                                                                      QAtom *__restrict__ Q3, uint32_t *__restrict__ start3,
+                                                                      int32_t *flag)
+{
+    extern __shared__ __align__(16) unsigned char csf_raw[];
+    unsigned *cnt = reinterpret_cast<unsigned *>(csf_raw);           // [nwords] two 16-bit counters / cursors per word
+    __shared__ unsigned cbase[CSF_THREADS];                          // absolute start of thread t's run of words
+    __shared__ unsigned wsum[CSF_THREADS / 64];
+    __shared__ int overflow;
+    const int fl = blockIdx.x, f = f0 + fl, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nkeys = nx * ny * nz * S, nwords = (nkeys + 1) >> 1;
+    const double *__restrict__ g = geom + (size_t)(n_cells == 1 ? 0 : f) * GEOM_STRIDE;
+    for (int k = tid; k < nwords; k += CSF_THREADS) cnt[k] = 0u;
+    if (tid == 0) overflow = 0;
+    __syncthreads();
+    // (a workgroup is alone on its CU with 16 waves: CSF_AHEAD atoms per thread are loaded before the first is used, or
+    //  every trip waits a whole memory latency -- 1.28 ms per 106 624-atom frame instead of 0.3)
+    const double *__restrict__ pf = pos + (size_t)f * (size_t)N * 3;
+    auto quant3 = [&](double x, double y, double z, int32_t *fl_out) {
+        QAtom q;
+        uint32_t u[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {               // (quantize_atom's arithmetic, operation for operation)
+            double sx = fma(z, g[15 + c], fma(y, g[12 + c], x * g[9 + c]));
+            if (!(fabs(sx) < 1.0e4)) *fl_out = 1;
+            sx = sx - floor(sx);
+            const double t = sx * 4294967296.0;
+            u[c] = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+        }
+        q.ux = u[0]; q.uy = u[1]; q.uz = u[2]; q.idx = 0u;
+        return q;
+    };
+    for (int64_t a0 = tid; a0 < N; a0 += (int64_t)CSF_THREADS * CSF_AHEAD) {
+        double xs[CSF_AHEAD], ys[CSF_AHEAD], zs[CSF_AHEAD];
+        int32_t sps[CSF_AHEAD];
+#pragma unroll
+        for (int u = 0; u < CSF_AHEAD; u++) {
+            const int64_t a = std::min<int64_t>(a0 + (int64_t)u * CSF_THREADS, N - 1);
+            xs[u] = pf[3 * a]; ys[u] = pf[3 * a + 1]; zs[u] = pf[3 * a + 2];
+            sps[u] = species[a];
+        }
+#pragma unroll
+        for (int u = 0; u < CSF_AHEAD; u++) {
+            if (a0 + (int64_t)u * CSF_THREADS < N) {
+                const QAtom q = quant3(xs[u], ys[u], zs[u], flag);
+                const uint32_t key = cell_key(q, nx, ny, nz, S, sps[u]);
+                atomicAdd(&cnt[key >> 1], 1u << ((key & 1u) * 16u));
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan: a contiguous run of words per thread (odd length: consecutive threads on different banks)
+    const int chunk = ((nwords + CSF_THREADS - 1) / CSF_THREADS) | 1;
+    const int w0 = min(tid * chunk, nwords), w1 = min(w0 + chunk, nwords);
+    unsigned s = 0;
+    for (int w = w0; w < w1; w++) {
+        const unsigned c = cnt[w];
+        s += (c & 0xffffu) + (c >> 16);
+    }
+    // (a half that counted past 65 535 has carried into its neighbour or wrapped: the total of the frame then differs from N)
+    if (s > 65535u) overflow = 1;
+    unsigned incl = s;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned run = incl - s;
+    for (int w = 0; w < wv; w++) run += wsum[w];
+    if (tid == CSF_THREADS - 1 && run + s != (unsigned)N) overflow = 1;
+    __syncthreads();
+    const bool bad = overflow != 0;
+    uint32_t *st = start3 + (size_t)fl * ((size_t)nkeys + 1);
+    cbase[tid] = run;
+    unsigned local = 0;
+    for (int w = w0; w < w1; w++) {
+        const unsigned c = cnt[w];
+        const unsigned lo = c & 0xffffu, hi = c >> 16;
+        cnt[w] = local | ((local + lo) << 16);                       // cursors of the placement pass
+        if (2 * w < nkeys) st[2 * w] = bad ? 0u : run + local;
+        if (2 * w + 1 < nkeys) st[2 * w + 1] = bad ? 0u : run + local + lo;
+        local += lo + hi;
+    }
+    if (tid == 0) st[nkeys] = bad ? 0u : (uint32_t)N;
+    if (bad) {
+        if (tid == 0) *flag = 1;
+        return;
+    }
+    __syncthreads();
+    QAtom *__restrict__ Qf = Q3 + (size_t)fl * N;
+    int32_t dummy = 0;
+    for (int64_t a0 = tid; a0 < N; a0 += (int64_t)CSF_THREADS * CSF_AHEAD) {
+        double xs[CSF_AHEAD], ys[CSF_AHEAD], zs[CSF_AHEAD];
+        int32_t sps[CSF_AHEAD];
+#pragma unroll
+        for (int u = 0; u < CSF_AHEAD; u++) {
+            const int64_t a = std::min<int64_t>(a0 + (int64_t)u * CSF_THREADS, N - 1);
+            xs[u] = pf[3 * a]; ys[u] = pf[3 * a + 1]; zs[u] = pf[3 * a + 2];
+            sps[u] = species[a];
+        }
+#pragma unroll
+        for (int u = 0; u < CSF_AHEAD; u++) {
+            const int64_t a = a0 + (int64_t)u * CSF_THREADS;
+            if (a < N) {
+                QAtom q = quant3(xs[u], ys[u], zs[u], &dummy);
+                const uint32_t sp = (uint32_t)sps[u];
+                const uint32_t key = cell_key(q, nx, ny, nz, S, sp);
+                const unsigned w = key >> 1, sh = (key & 1u) * 16u;
+                const unsigned old = atomicAdd(&cnt[w], 1u << sh);
+                const unsigned slot = cbase[w / (unsigned)chunk] + ((old >> sh) & 0xffffu);
+                q.idx = (sp << CELL_SPECIES_SHIFT) | (uint32_t)a;
+                if (slot < (unsigned)N) Qf[slot] = q;
+            }
+        }
+    }
+}
+
 int launch_cell_sort(amof_ctx *ctx, const double *pos_dev, const double *d_geom, int n_cells, const int32_t *d_species,
                      int S, int64_t N, int f0, int nf, int nx, int ny, int nz, QAtom *d_Q3, uint32_t *d_start3,
                      uint32_t *d_keys, uint32_t *d_cursor, int32_t *d_flag)
@@ -424,6 +554,15 @@ int launch_cell_sort(amof_ctx *ctx, const double *pos_dev, const double *d_geom,
     if (nx < 1 || ny < 1 || nz < 1 || nkeys64 > 0x3fffffff || N >= (1ll << CELL_SPECIES_SHIFT) || S > 64)
         return fail(ctx, AMOF_EINVAL, "bad cell grid");
     const int nkeys = (int)nkeys64;
+    // one workgroup per frame with the counters in LDS where they fit (and a frame has enough atoms to feed 1024 threads)
+    const size_t lds_frame = (size_t)((nkeys + 1) / 2) * sizeof(unsigned);
+    if (lds_frame <= 144 * 1024 && N >= 2048 && !getenv("AMOF_CELL_SORT_3K")) {
+        AMOF_HIP_TRY(ctx, allow_max_lds((const void *)cell_sort_frame_kernel));
+        hipLaunchKernelGGL(cell_sort_frame_kernel, dim3((unsigned)nf), dim3(CSF_THREADS), lds_frame, ctx->stream, pos_dev, d_geom,
+                           n_cells, d_species, S, N, f0, nx, ny, nz, d_Q3, d_start3, d_flag);
+        AMOF_HIP_TRY(ctx, hipGetLastError());
+        return AMOF_OK;
+    }
     AMOF_HIP_TRY(ctx, hipMemsetAsync(d_start3, 0, (size_t)nf * (nkeys + 1) * sizeof(uint32_t), ctx->stream));
     dim3 agrid((unsigned)((N + 255) / 256), (unsigned)nf);
     hipLaunchKernelGGL(cell_key_kernel, agrid, dim3(256), 0, ctx->stream, pos_dev, d_geom, n_cells, d_species, S, N, f0,
