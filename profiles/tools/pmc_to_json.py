@@ -121,7 +121,7 @@ with open(os.path.join(root, "profiles", "traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 
 model = {}
-for wl, prefix in (("rdf", "rdf_tile_kernel_fast"), ("cfg4", "rdf_cell_kernel")):
+for wl, prefix in (("rdf", "rdf_tile_kernel_fast"), ("cfg4", "rdf_cell")):      # (rdf_cellwave_kernel | rdf_cell_kernel)
     if wl not in tables:
         continue
     for k, c in tables[wl].items():
