@@ -73,3 +73,43 @@ def test_cfg5_device_resident_launch_across_frame_batches(hip_ctx):
             os.environ.pop("AMOF_RDF_BATCH", None)
         else:
             os.environ["AMOF_RDF_BATCH"] = old
+
+
+def test_cell_sort_counter_overflow_falls_back(hip_ctx):
+    """round 5: `cell_sort_frame_kernel` keeps the key counters as 16-bit halves in LDS.  A frame with more than 65 535 atoms in
+    one cell cannot be sorted that way: the kernel must notice (the scan's total differs from N), leave an EMPTY table behind
+    (nothing the pair kernel could walk out of bounds with), raise the flag -- and the call must still return the right
+    histogram through the exact kernels.  68 000 atoms in a 0.3 A cube of a 40 A box, against the same call with the cell list
+    switched off and (a 3 000-atom slice, same geometry) against the oracle."""
+    rng = np.random.default_rng(5)
+    N = 70000
+    cell = np.diag([40.0, 40.0, 40.0])
+    pos = 20.1 + rng.uniform(0.0, 0.3, (1, N, 3))                    # (inside ONE cell of the 32 x 33 x 33 grid the call picks)
+    pos[0, :2000] = rng.uniform(0.0, 40.0, (2000, 3))                # a thin gas around the clump
+    packed = PackedTrajectory(pos, cell, np.full(N, 8))
+    old = {k: os.environ.get(k) for k in ("AMOF_RDF_FORCE_CELL", "AMOF_RDF_NOCELL")}
+    try:
+        os.environ["AMOF_RDF_FORCE_CELL"] = "1"
+        got, _, _ = hip_ctx.rdf_accumulate(packed, 2.0, 20)
+        path = hip_ctx.last_path()
+        del os.environ["AMOF_RDF_FORCE_CELL"]
+        os.environ["AMOF_RDF_NOCELL"] = "1"
+        other, _, _ = hip_ctx.rdf_accumulate(packed, 2.0, 20)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert path != "rdf_cell", path                                  # the sorted table was refused
+    assert np.array_equal(got, other) and int(got.sum()) > N * 60000
+    small = PackedTrajectory(pos[:, 1000:4000], cell, np.full(3000, 8))
+    os.environ["AMOF_RDF_FORCE_CELL"] = "1"
+    try:
+        g2, _, _ = hip_ctx.rdf_accumulate(small, 2.0, 20)
+    finally:
+        os.environ.pop("AMOF_RDF_FORCE_CELL", None)
+        if old["AMOF_RDF_FORCE_CELL"] is not None:
+            os.environ["AMOF_RDF_FORCE_CELL"] = old["AMOF_RDF_FORCE_CELL"]
+    ref, _ = clib.rdf_hist(small.pos, small.cell, np.zeros(3000, dtype=np.int32), 1, 2.0, 20, cell_list=True)
+    assert np.array_equal(g2, ref)
