@@ -83,6 +83,22 @@ class DirectMsd(Msd):
         msd_class.compute_msd(trajectory, step, parallel, device=device)
         return msd_class
 
+    @staticmethod
+    def compute_species_msd(trajectory, atomic_number=None, device=None):
+        """MSD(t) of one species -- all atoms if ``atomic_number`` is None -- as the reference's static helper returns it
+        (amof/msd.py:84-107: one float per frame, 0 at t = 0), from the same kernel as the class (``amof_msd_direct``
+        computes every column of a trajectory at once; a caller that wants all of them uses ``from_trajectory``)."""
+        packed = pack_trajectory(trajectory)
+        if getattr(packed, "is_stream", False):
+            packed = packed.read_all()
+        dev = device if device is not None else getattr(packed, "device_index", None)
+        msd, kinds = _hip.get_context(dev).msd_direct(packed)
+        if atomic_number is None:
+            return np.array(msd[:, 0])
+        if int(atomic_number) not in kinds:
+            raise ValueError("no atom of atomic number %r in the trajectory" % (atomic_number,))
+        return np.array(msd[:, 1 + kinds.index(int(atomic_number))])
+
     def compute_msd(self, trajectory, step, parallel=False, device=None):
         packed = pack_trajectory(trajectory)
         if getattr(packed, "is_stream", False):
@@ -141,6 +157,29 @@ class WindowMsd(Msd, Deferred):
         time = timestep * window
         msd_class.compute_msd(trajectory, window, time, parallel, unwrap, device=device, distributed=distributed)
         return msd_class
+
+    @staticmethod
+    def compute_msd_of_m(delta_pos, m, device=None):
+        """MSD(m) of a list of successive displacements -- ``delta_pos[0]`` the initial positions, as
+        ``amof.trajectory.get_delta_pos`` returns it -- with the reference's normalisation (amof/msd.py:185-205: the sum over
+        the origins k = 1 .. F - m - 1 divided by F - m and by the number of atoms).  The reference's static helper, on the
+        GPU: the displacements are summed into positions once (no cell, no wrapping: the caller's displacements already are
+        the minimum images) and ONE window goes through the kernels of the class.  Deviation: ``delta_pos[0]`` is not
+        modified (the reference accumulates into it; successive calls on one list give the same values either way)."""
+        delta = np.asarray([np.asarray(d, dtype=np.float64) for d in delta_pos], dtype=np.float64)
+        if delta.ndim != 3 or delta.shape[2] != 3:
+            raise ValueError("delta_pos: a list of [n_atoms][3] arrays is expected")
+        F, n = delta.shape[0], delta.shape[1]
+        m = int(m)
+        if not 0 <= m < F:
+            raise ValueError("m = %d outside [0, %d)" % (m, F))
+        if n == 0:
+            return float("nan")                                     # (the reference divides by len(r) == 0)
+        pos = np.cumsum(delta, axis=0)
+        packed = PackedTrajectory(pos, np.eye(3), np.ones(n, dtype=np.int64), pbc=(False, False, False))
+        ctx = _hip.get_context(device if device is not None else _hip.default_device())
+        sumsq, _ = ctx.msd_window(packed, np.array([m], dtype=np.int32), unwrap=False, remove_com=False)
+        return float(sumsq[0][0]) / n / (F - m)
 
     def compute_msd(self, trajectory, window, time, parallel=False, unwrap=False, device=None, distributed=None):
         """compute the window MSD (reference amof/msd.py:207-268)"""

@@ -146,6 +146,37 @@ def test_direct_msd_matches_reference_dataframe():
     _check_df(d.data, g, rtol=1e-9)
 
 
+def test_static_helpers_of_the_msd_classes_against_the_reference_vectors():
+    """The reference's static helpers are part of its classes' surface (amof/msd.py:84-107, 185-205).  Here they run on the
+    GPU: `WindowMsd.compute_msd_of_m` against the vectors the REFERENCE's own function produced
+    (tests/golden/reference_msd_of_m.npz, made by tests/golden/make_reference_goldens.py -- pure reference numpy), single
+    calls and the reference's pattern of successive calls on one list; `DirectMsd.compute_species_msd` against the class's
+    columns, which `reference_e2e_directmsd_ortho.npz` ties to the reference."""
+    from amof_amd.msd import DirectMsd
+    g = np.load(os.path.join(GOLDEN, "reference_msd_of_m.npz"))
+    for k in range(int(g["n_cases"])):
+        base, ms, want = g["delta_%d" % k], g["m_%d" % k], g["msd_%d" % k]
+        for m, w in zip(ms, want):
+            got = WindowMsd.compute_msd_of_m([b.copy() for b in base], int(m))
+            assert got == pytest.approx(w, rel=1e-12, abs=1e-300), (k, int(m))
+    shared = [b.copy() for b in g["delta_shared"]]
+    first = shared[0].copy()
+    for m, w in zip(g["m_shared"], g["msd_shared"]):
+        assert WindowMsd.compute_msd_of_m(shared, int(m)) == pytest.approx(w, rel=1e-12, abs=1e-300)
+    assert np.array_equal(shared[0], first)                      # (documented deviation: the caller's list is not modified)
+    with pytest.raises(ValueError):
+        WindowMsd.compute_msd_of_m(shared, len(shared))
+    e = np.load(os.path.join(GOLDEN, "reference_e2e_directmsd_ortho.npz"))
+    frames = _frames(e)
+    d = DirectMsd.from_trajectory(frames, delta_Step=int(e["delta_Step"]), first_frame=int(e["first_frame"]))
+    assert np.array_equal(DirectMsd.compute_species_msd(frames), d.data["X"].values)
+    for z in sorted(set(int(n) for n in frames[0].get_atomic_numbers())):
+        from amof_amd import data as amdata
+        assert np.array_equal(DirectMsd.compute_species_msd(frames, z), d.data[amdata.chemical_symbols[z]].values)
+    with pytest.raises(ValueError):
+        DirectMsd.compute_species_msd(frames, 92)
+
+
 def test_to_device_round_trip(zif4):
     packed = H.random_walk(zif4, 5, 0.05, 9)
     dev = packed.to_device(0)
