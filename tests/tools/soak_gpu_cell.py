@@ -25,7 +25,8 @@ while time.time() < t_end:
     seed += 1
     rng = np.random.default_rng(seed)
     S = int(rng.integers(1, 7))
-    N = int(rng.choice([64, 65, 200, 777, 2500, 6000]))
+    # (AMOF_SOAK_BIG=1: frames of 2048 atoms and more only -- the one-kernel cell sort serves those)
+    N = int(rng.choice([2048, 2049, 5000, 12000, 30000] if os.environ.get("AMOF_SOAK_BIG") else [64, 65, 200, 777, 2500, 6000]))
     rho = rng.uniform(0.02, 0.1)
     shape = rng.choice([1.0, 1.0, 1.5, 3.0], 3)
     L = shape * (N / rho / shape.prod()) ** (1 / 3)
